@@ -1,0 +1,525 @@
+/*
+ * singlet_oracle.c -- CPU restatement of singlet's ALS hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under singlet_amd/ (the product) may
+ * import, link or call this file; only tests/, __graft_entry__.smoke() and
+ * the cpu_baseline leg of bench.py use it, and only as the checker / the
+ * timed CPU baseline.  The product path is the HIP library and fails loudly
+ * when it is missing.
+ *
+ * PARITY UNPINNED: the reference (zdebruine/singlet @ 2025-08-08) ships no
+ * golden vectors or known-answer tests for this path (its only test asserts
+ * TRUE, tests/testthat/test-pbmc3k.R:1-7) and its own sources cannot be built
+ * in this image (src/singlet.cpp needs Rcpp, RcppEigen/Eigen and R, none of
+ * which exist here; no stand-in headers are written).  This file is therefore
+ * a line-by-line restatement checked against (a) an independent numpy
+ * transcription of the same reference lines (oracle/np_transcription.py,
+ * bit-for-bit agreement is asserted in tests/test_oracle.py) and (b) the
+ * hash known-answer values derived by hand from src/singlet.cpp:30-64.
+ *
+ * Third-party arithmetic not under /root/reference: Eigen (via RcppEigen,
+ * DESCRIPTION:25,39-41, version unpinned).  Its call sites on the path are
+ * elementary (rankUpdate = syrk, rowwise().sum(), column axpy, dot).  Only the
+ * summation ORDER inside rankUpdate / sum / dot is Eigen-specific; this file
+ * uses plain left-to-right order for those and says so at each site.
+ *
+ * Arithmetic: FP64, no FMA contraction (build with -ffp-contract=off; R builds
+ * the reference with plain -O2 on x86-64, i.e. SSE2 mul + add).
+ *
+ * Every function cites the reference lines it follows (paths relative to
+ * /root/reference).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORA_API __attribute__((visibility("default")))
+
+/* ---------------------------------------------------------------- timing */
+static double now_sec(void) {
+#ifdef _OPENMP
+    return omp_get_wtime();
+#else
+    return 0.0;
+#endif
+}
+
+ORA_API int ora_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+static int pick_threads(int threads) {
+    /* `#pragma omp parallel for num_threads(threads)` with threads == 0 means
+     * "runtime default" in the reference (src/singlet.cpp:336-338, quirk 10). */
+    if (threads > 0) return threads;
+    return ora_max_threads();
+}
+
+/* ------------------------------------------------------------------- rng */
+/* class rng, rand(i) -- src/singlet.cpp:30-45 */
+static inline uint64_t rng_rand1(uint64_t state, uint64_t i) {
+    i ^= i << 19;
+    i ^= i >> 7;
+    i ^= i << 36;
+    uint64_t x = state + i;
+    x ^= x << 38;
+    x ^= x >> 13;
+    x ^= x << 23;
+    return x;
+}
+
+/* rand(i, j) -- src/singlet.cpp:47-64 */
+ORA_API uint64_t ora_rng_rand(uint64_t state, uint64_t i, uint64_t j) {
+    uint64_t x = rng_rand1(state, i);
+    j ^= j >> 7;
+    j ^= j << 23;
+    j ^= j >> 8;
+    x += j;
+    x ^= x >> 7;
+    x ^= x << 53;
+    x ^= x >> 4;
+    return x;
+}
+
+/* draw(i, j, probability) -- src/singlet.cpp:76-79, 91-95
+ * (sample = rand(i,j) % max_value; draw = sample == 0; the reference
+ * evaluates sample twice, which has no effect). */
+ORA_API int ora_rng_draw(uint64_t state, uint64_t i, uint64_t j, uint64_t inv_density) {
+    return (ora_rng_rand(state, i, j) % inv_density) == 0;
+}
+
+/* bulk helper for the tests: mask[cell*ngenes + gene] = draw(cell, gene) */
+ORA_API void ora_rng_mask(uint64_t state, uint64_t cell0, uint64_t ncells, uint64_t ngenes,
+                          uint64_t inv_density, uint8_t* mask) {
+    for (uint64_t c = 0; c < ncells; ++c)
+        for (uint64_t g = 0; g < ngenes; ++g)
+            mask[c * ngenes + g] = (uint8_t)ora_rng_draw(state, cell0 + c, g, inv_density);
+}
+
+/* ------------------------------------------------------------- helpers */
+/* cor(x, y) -- src/singlet.cpp:184-197 : 1 - Pearson, one-pass sums. */
+ORA_API double ora_cor(const double* x, const double* y, size_t n) {
+    double x_i, y_i, sum_x = 0, sum_y = 0, sum_xy = 0, sum_x2 = 0, sum_y2 = 0;
+    for (size_t i = 0; i < n; ++i) {
+        x_i = x[i];
+        y_i = y[i];
+        sum_x += x_i;
+        sum_y += y_i;
+        sum_xy += x_i * y_i;
+        sum_x2 += x_i * x_i;
+        sum_y2 += y_i * y_i;
+    }
+    return 1 - (n * sum_xy - sum_x * sum_y) / sqrt((n * sum_x2 - sum_x * sum_x) * (n * sum_y2 - sum_y * sum_y));
+}
+
+/* AAt(A) -- src/singlet.cpp:200-206.  F is k x cols column-major.
+ * rankUpdate on the Lower view, mirrored to Upper, then diag += 1e-15.
+ * Summation over columns is left-to-right (Eigen's internal blocking order is
+ * not reproducible without Eigen; see header). */
+ORA_API void ora_aat(const double* F, int k, int64_t cols, double* G) {
+    for (int i = 0; i < k * k; ++i) G[i] = 0.0;
+    for (int64_t c = 0; c < cols; ++c) {
+        const double* f = F + (size_t)c * k;
+        for (int j = 0; j < k; ++j) {
+            const double fj = f[j];
+            for (int i = j; i < k; ++i) G[(size_t)j * k + i] += f[i] * fj; /* lower: row i >= col j */
+        }
+    }
+    for (int j = 0; j < k; ++j)
+        for (int i = j + 1; i < k; ++i) G[(size_t)i * k + j] = G[(size_t)j * k + i]; /* upper = lower^T */
+    for (int i = 0; i < k; ++i) G[(size_t)i * k + i] += 1e-15;
+}
+
+/* scale(w, d) -- src/singlet.cpp:219-225.  Row sums left-to-right over
+ * columns, + 1e-15, then every entry divided by its row's d. */
+ORA_API void ora_scale(double* F, int k, int64_t cols, double* d) {
+    for (int i = 0; i < k; ++i) d[i] = 0.0;
+    for (int64_t c = 0; c < cols; ++c)
+        for (int i = 0; i < k; ++i) d[i] += F[(size_t)c * k + i];
+    for (int i = 0; i < k; ++i) d[i] += 1e-15;
+    for (int64_t c = 0; c < cols; ++c)
+        for (int i = 0; i < k; ++i) F[(size_t)c * k + i] /= d[i];
+}
+
+/* nnls(a, b, x, col, L1, L2) -- src/singlet.cpp:229-250.
+ * a: k x k column-major, b: k (destroyed), x: pointer to column `col` of X.
+ * Returns the number of sweeps run (diagnostic only; the reference does not
+ * return it). */
+static inline int nnls_col(const double* a, double* b, double* x, int k, double L1, double L2) {
+    double tol = 1;
+    uint8_t it = 0;
+    for (; it < 100 && (tol / k) > 1e-8; ++it) {
+        tol = 0;
+        for (int i = 0; i < k; ++i) {
+            double diff = b[i] / a[(size_t)i * k + i];
+            if (L1 != 0) diff -= L1;
+            if (L2 != 0) diff += L2 * x[i];
+            if (-diff > x[i]) {
+                if (x[i] != 0) {
+                    const double s = -x[i];
+                    const double* ai = a + (size_t)i * k;
+                    for (int j = 0; j < k; ++j) b[j] -= ai[j] * s;
+                    tol = 1;
+                    x[i] = 0;
+                }
+            } else if (diff != 0) {
+                x[i] += diff;
+                const double* ai = a + (size_t)i * k;
+                for (int j = 0; j < k; ++j) b[j] -= ai[j] * diff;
+                tol += fabs(diff / (x[i] + 1e-15));
+            }
+        }
+    }
+    return (int)it;
+}
+
+ORA_API int ora_nnls(const double* a, double* b, double* x, int k, double L1, double L2) {
+    return nnls_col(a, b, x, k, L1, L2);
+}
+
+/* CSC view = Rcpp::SparseMatrix, inst/include/singlet.h:36-72 */
+typedef struct {
+    const double* x;
+    const int32_t* i;
+    const int32_t* p;
+    int32_t nrow, ncol;
+} csc_t;
+
+/* predict(A, w, h, L1, L2, threads) sparse -- src/singlet.cpp:333-347
+ * F: k x A.nrow (operand factor), X: k x A.ncol (in/out, warm start).
+ * sweeps_out (optional): sum of NNLS sweeps over solved columns. */
+static void predict(csc_t A, const double* F, double* X, int k, double L1, double L2, int threads,
+                    int64_t* sweeps_out) {
+    double* a = (double*)malloc(sizeof(double) * k * k);
+    ora_aat(F, k, A.nrow, a);
+    int64_t sweeps = 0;
+#pragma omp parallel for num_threads(pick_threads(threads)) reduction(+ : sweeps)
+    for (int64_t c = 0; c < A.ncol; ++c) {
+        if (A.p[c] == A.p[c + 1]) continue;
+        double b[k];
+        for (int j = 0; j < k; ++j) b[j] = 0.0;
+        for (int32_t q = A.p[c]; q < A.p[c + 1]; ++q) {
+            const double v = A.x[q];
+            const double* f = F + (size_t)A.i[q] * k;
+            for (int j = 0; j < k; ++j) b[j] += v * f[j];
+        }
+        sweeps += nnls_col(a, b, X + (size_t)c * k, k, L1, L2);
+    }
+    if (sweeps_out) *sweeps_out += sweeps;
+    free(a);
+}
+
+ORA_API void ora_predict(const double* Ax, const int32_t* Ai, const int32_t* Ap, int32_t nrow, int32_t ncol,
+                         const double* F, double* X, int k, double L1, double L2, int threads) {
+    csc_t A = {Ax, Ai, Ap, nrow, ncol};
+    predict(A, F, X, k, L1, L2, threads, NULL);
+}
+
+/* the raw right-hand sides b_c = sum x * F[:, row] of predict (l.341-343),
+ * exposed so the HIP accumulate kernels can be checked on their own. */
+ORA_API void ora_rhs(const double* Ax, const int32_t* Ai, const int32_t* Ap, int32_t nrow, int32_t ncol,
+                     const double* F, double* B, int k) {
+    (void)nrow;
+    for (int64_t c = 0; c < ncol; ++c) {
+        double* b = B + (size_t)c * k;
+        for (int j = 0; j < k; ++j) b[j] = 0.0;
+        for (int32_t q = Ap[c]; q < Ap[c + 1]; ++q) {
+            const double v = Ax[q];
+            const double* f = F + (size_t)Ai[q] * k;
+            for (int j = 0; j < k; ++j) b[j] += v * f[j];
+        }
+    }
+}
+
+/* predict_mask(A, seed, inv_density, w, h, L1, L2, threads, mask_t) sparse
+ * -- src/singlet.cpp:436-466, with submat :211-216 and AAt :200-206.
+ * col_offset: global index of this matrix's first column (0 for the plain
+ * call; the reference's list variant adds `offset` the same way, :485). */
+static void predict_mask(csc_t A, uint64_t seed, uint64_t inv_density, const double* F, double* X, int k,
+                         double L1, double L2, int threads, int mask_t, uint64_t col_offset,
+                         uint64_t row_offset) {
+    double* a = (double*)malloc(sizeof(double) * k * k);
+    ora_aat(F, k, A.nrow, a);
+#pragma omp parallel for num_threads(pick_threads(threads))
+    for (int64_t c = 0; c < A.ncol; ++c) {
+        if (A.p[c] == A.p[c + 1]) continue;
+        double b[k];
+        for (int j = 0; j < k; ++j) b[j] = 0.0;
+        int32_t q = A.p[c];
+        const int32_t qend = A.p[c + 1];
+        int64_t* idx = (int64_t*)malloc(sizeof(int64_t) * (size_t)(A.nrow > 0 ? A.nrow : 1));
+        int64_t nidx = 0;
+        for (int64_t j = 0; j < A.nrow; ++j) {
+            const uint64_t gc = (uint64_t)c + col_offset, gj = (uint64_t)j + row_offset;
+            const int drawn = mask_t ? ora_rng_draw(seed, gj, gc, inv_density) : ora_rng_draw(seed, gc, gj, inv_density);
+            if (drawn) {
+                idx[nidx++] = j;
+                if (q < qend && j == A.i[q]) ++q;
+            } else if (q < qend && j == A.i[q]) {
+                const double v = A.x[q];
+                const double* f = F + (size_t)j * k;
+                for (int jj = 0; jj < k; ++jj) b[jj] += v * f[jj];
+                ++q;
+            }
+        }
+        /* wsub = submat(w, idx); asub = AAt(wsub); a_i = a - asub */
+        double* wsub = (double*)malloc(sizeof(double) * (size_t)k * (size_t)(nidx > 0 ? nidx : 1));
+        for (int64_t t = 0; t < nidx; ++t) memcpy(wsub + (size_t)t * k, F + (size_t)idx[t] * k, sizeof(double) * k);
+        double asub[k * k], a_i[k * k];
+        ora_aat(wsub, k, nidx, asub);
+        for (int t = 0; t < k * k; ++t) a_i[t] = a[t] - asub[t];
+        nnls_col(a_i, b, X + (size_t)c * k, k, L1, L2);
+        free(wsub);
+        free(idx);
+    }
+    free(a);
+}
+
+ORA_API void ora_predict_mask(const double* Ax, const int32_t* Ai, const int32_t* Ap, int32_t nrow, int32_t ncol,
+                              uint64_t seed, uint64_t inv_density, const double* F, double* X, int k, double L1,
+                              double L2, int threads, int mask_t) {
+    csc_t A = {Ax, Ai, Ap, nrow, ncol};
+    predict_mask(A, seed, inv_density, F, X, k, L1, L2, threads, mask_t, 0, 0);
+}
+
+/* mse_test(A, w, d, h, seed, inv_density, threads) sparse -- src/singlet.cpp:536-568
+ * w: k x m, h: k x n.  w_ = w^T with column j scaled by d(j); the k-long dot
+ * w_.row(i) * h.col(j) is summed left-to-right. */
+static double mse_test(csc_t A, const double* w, const double* d, const double* h, int k, uint64_t seed,
+                       uint64_t inv_density, int threads) {
+    const int64_t m = A.nrow, n = A.ncol;
+    double* w_ = (double*)malloc(sizeof(double) * (size_t)m * k); /* m x k, stored gene-major: w_[i*k + j] */
+    for (int64_t i = 0; i < m; ++i)
+        for (int j = 0; j < k; ++j) w_[(size_t)i * k + j] = w[(size_t)i * k + j] * d[j];
+    double* losses = (double*)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+#pragma omp parallel for num_threads(pick_threads(threads))
+    for (int64_t j = 0; j < n; ++j) {
+        uint64_t cnt = 0;
+        double s = 0;
+        int32_t q = A.p[j];
+        const int32_t qend = A.p[j + 1];
+        const double* hj = h + (size_t)j * k;
+        for (int64_t i = 0; i < m; ++i) {
+            if (ora_rng_draw(seed, (uint64_t)j, (uint64_t)i, inv_density)) {
+                ++cnt;
+                double pred = 0;
+                const double* wi = w_ + (size_t)i * k;
+                for (int t = 0; t < k; ++t) pred += wi[t] * hj[t];
+                if (q < qend && i == A.i[q]) {
+                    const double e = pred - A.x[q];
+                    s += e * e; /* std::pow(e, 2) is exact e*e */
+                    ++q;
+                } else {
+                    s += pred * pred;
+                }
+            } else if (q < qend && i == A.i[q]) {
+                ++q;
+            }
+        }
+        losses[j] = (cnt > 0) ? s / (double)cnt : 0;
+    }
+    double tot = 0;
+    for (int64_t j = 0; j < n; ++j) tot += losses[j];
+    free(losses);
+    free(w_);
+    return tot / (double)n;
+}
+
+ORA_API double ora_mse_test(const double* Ax, const int32_t* Ai, const int32_t* Ap, int32_t nrow, int32_t ncol,
+                            const double* w, const double* d, const double* h, int k, uint64_t seed,
+                            uint64_t inv_density, int threads) {
+    csc_t A = {Ax, Ai, Ap, nrow, ncol};
+    return mse_test(A, w, d, h, k, seed, inv_density, threads);
+}
+
+/* c_nmf_base -- src/singlet.cpp:638-666 (export c_nmf :669-672).
+ * w: k x m in/out (the reference copies its argument and returns the copy);
+ * h: k x n out; d: k out.  tol_trace (optional, maxit entries) receives tol_
+ * per iteration; returns the number of iterations run.  phase_sec (optional,
+ * 4 entries) accumulates wall time of: predict(A), scale(h), predict(At),
+ * scale(w)+cor.  sweeps (optional, 2 entries): NNLS sweep totals H / W. */
+ORA_API int ora_c_nmf(const double* Ax, const int32_t* Ai, const int32_t* Ap, const double* Atx, const int32_t* Ati,
+                      const int32_t* Atp, int32_t m, int32_t n, double tol, int maxit, double L1_w, double L1_h,
+                      double L2_w, double L2_h, int threads, int k, double* w, double* h, double* d,
+                      double* tol_trace, double* phase_sec, int64_t* sweeps) {
+    csc_t A = {Ax, Ai, Ap, m, n};
+    csc_t At = {Atx, Ati, Atp, n, m};
+    memset(h, 0, sizeof(double) * (size_t)k * (size_t)n);
+    for (int i = 0; i < k; ++i) d[i] = 1.0;
+    double tol_ = 1;
+    double* w_it = (double*)malloc(sizeof(double) * (size_t)k * (size_t)m);
+    int iter_ = 0;
+    for (; iter_ < maxit && tol_ > tol; ++iter_) {
+        memcpy(w_it, w, sizeof(double) * (size_t)k * (size_t)m);
+        double t0 = now_sec();
+        predict(A, w, h, k, L1_h, L2_h, threads, sweeps ? &sweeps[0] : NULL);
+        double t1 = now_sec();
+        ora_scale(h, k, n, d);
+        double t2 = now_sec();
+        predict(At, h, w, k, L1_w, L2_w, threads, sweeps ? &sweeps[1] : NULL);
+        double t3 = now_sec();
+        ora_scale(w, k, m, d);
+        tol_ = ora_cor(w, w_it, (size_t)k * (size_t)m);
+        double t4 = now_sec();
+        if (phase_sec) {
+            phase_sec[0] += t1 - t0;
+            phase_sec[1] += t2 - t1;
+            phase_sec[2] += t3 - t2;
+            phase_sec[3] += t4 - t3;
+        }
+        if (tol_trace) tol_trace[iter_] = tol_;
+    }
+    free(w_it);
+    return iter_;
+}
+
+/* c_project_model -- src/singlet.cpp:405-413.
+ * w_in has w_rows x w_cols (column-major); if w_rows == A.nrow it is
+ * transposed first (l.406).  h: k x n out, d: k out, with k = rows after the
+ * optional transpose.  Returns k. */
+ORA_API int ora_c_project_model(const double* Ax, const int32_t* Ai, const int32_t* Ap, int32_t m, int32_t n,
+                                const double* w_in, int32_t w_rows, int32_t w_cols, double L1, double L2,
+                                int threads, double* h, double* d) {
+    csc_t A = {Ax, Ai, Ap, m, n};
+    int k, cols;
+    double* w;
+    if (w_rows == m) {
+        k = w_cols;
+        cols = w_rows;
+        w = (double*)malloc(sizeof(double) * (size_t)k * cols);
+        for (int r = 0; r < w_rows; ++r)
+            for (int c = 0; c < w_cols; ++c) w[(size_t)r * k + c] = w_in[(size_t)c * w_rows + r];
+    } else {
+        k = w_rows;
+        cols = w_cols;
+        w = (double*)malloc(sizeof(double) * (size_t)k * cols);
+        memcpy(w, w_in, sizeof(double) * (size_t)k * cols);
+    }
+    for (int i = 0; i < k; ++i) d[i] = 1.0;
+    ora_scale(w, k, cols, d);
+    memset(h, 0, sizeof(double) * (size_t)k * (size_t)n);
+    predict(A, w, h, k, L1, L2, threads, NULL);
+    ora_scale(h, k, n, d);
+    free(w);
+    return k;
+}
+
+/* c_ard_nmf_base -- src/singlet.cpp:1090-1152 (export c_ard_nmf :1155-1159).
+ * Trace arrays must hold maxit + 1 entries; *n_trace receives their length.
+ * Returns the number of iterations run (iter_ after the loop). */
+ORA_API int ora_c_ard_nmf(const double* Ax, const int32_t* Ai, const int32_t* Ap, const double* Atx,
+                          const int32_t* Ati, const int32_t* Atp, int32_t m, int32_t n, double tol, int maxit,
+                          double L1, double L2, int threads, int k, double* w, double* h, double* d,
+                          uint64_t rng_seed, uint64_t inv_density, double overfit_threshold, int trace_test_mse,
+                          double* test_mse, int32_t* iter, double* fit_tol, double* score_overfit,
+                          int32_t* n_trace) {
+    csc_t A = {Ax, Ai, Ap, m, n};
+    csc_t At = {Atx, Ati, Atp, n, m};
+    memset(h, 0, sizeof(double) * (size_t)k * (size_t)n);
+    for (int i = 0; i < k; ++i) d[i] = 1.0;
+    double tol_ = 1;
+    int nt = 0;
+    double* w_it = (double*)malloc(sizeof(double) * (size_t)k * (size_t)m);
+    int iter_ = 0;
+    for (; iter_ < maxit && tol_ > tol; ++iter_) {
+        memcpy(w_it, w, sizeof(double) * (size_t)k * (size_t)m);
+        predict_mask(A, rng_seed, inv_density, w, h, k, L1, L2, threads, 0, 0, 0);
+        ora_scale(h, k, n, d);
+        predict_mask(At, rng_seed, inv_density, h, w, k, L1, L2, threads, 1, 0, 0);
+        ora_scale(w, k, m, d);
+        tol_ = ora_cor(w, w_it, (size_t)k * (size_t)m);
+        if (iter_ % trace_test_mse == 0) {
+            test_mse[nt] = mse_test(A, w, d, h, k, rng_seed, inv_density, threads);
+            iter[nt] = iter_;
+            fit_tol[nt] = tol_;
+            const double this_err = test_mse[nt];
+            double min_err = test_mse[0];
+            for (int t = 1; t <= nt; ++t)
+                if (test_mse[t] < min_err) min_err = test_mse[t];
+            score_overfit[nt] = (this_err - min_err) / (this_err + min_err);
+            ++nt;
+            if (score_overfit[nt - 1] > overfit_threshold) break;
+        }
+    }
+    if (iter_ % trace_test_mse != 0) {
+        test_mse[nt] = mse_test(A, w, d, h, k, rng_seed, inv_density, threads);
+        iter[nt] = iter_;
+        fit_tol[nt] = tol_;
+        double min_err = test_mse[0];
+        for (int t = 1; t <= nt; ++t)
+            if (test_mse[t] < min_err) min_err = test_mse[t];
+        const double this_err = test_mse[nt];
+        score_overfit[nt] = (this_err - min_err) / (this_err + min_err);
+        ++nt;
+    }
+    *n_trace = nt;
+    free(w_it);
+    return iter_;
+}
+
+/* ------------------------------------------------ synthetic generator --
+ * Not reference code: the deterministic benchmark input of SURVEY.md 8(d),
+ * restated here so CPU baseline and HIP path see bit-identical matrices.
+ * Entry (gene g, cell c) is non-zero iff rand_S(c, g) % inv_density == 0;
+ * value = levels[(rand_{S+1}(c, g) >> 11) % 16]; w_init[f, g] =
+ * ((rand_{S+2}(f, g) >> 11) + 0.5) * 2^-53. */
+ORA_API int64_t ora_synth_count(uint64_t S, uint64_t inv_density, int64_t cell0, int64_t ncells, int64_t ngenes,
+                                int32_t* p) {
+    int64_t tot = 0;
+    p[0] = 0;
+    for (int64_t c = 0; c < ncells; ++c) {
+        int64_t cnt = 0;
+        for (int64_t g = 0; g < ngenes; ++g) cnt += ora_rng_draw(S, (uint64_t)(cell0 + c), (uint64_t)g, inv_density);
+        tot += cnt;
+        p[c + 1] = (int32_t)tot;
+    }
+    return tot;
+}
+
+ORA_API void ora_synth_fill(uint64_t S, uint64_t inv_density, int64_t cell0, int64_t ncells, int64_t ngenes,
+                            const double* levels16, const int32_t* p, int32_t* i, double* x) {
+#pragma omp parallel for
+    for (int64_t c = 0; c < ncells; ++c) {
+        int64_t q = p[c];
+        for (int64_t g = 0; g < ngenes; ++g) {
+            if (ora_rng_draw(S, (uint64_t)(cell0 + c), (uint64_t)g, inv_density)) {
+                i[q] = (int32_t)g;
+                x[q] = levels16[(ora_rng_rand(S + 1, (uint64_t)(cell0 + c), (uint64_t)g) >> 11) % 16];
+                ++q;
+            }
+        }
+    }
+}
+
+ORA_API void ora_synth_winit(uint64_t S, int k, int64_t ngenes, double* w) {
+    for (int64_t g = 0; g < ngenes; ++g)
+        for (int f = 0; f < k; ++f)
+            w[(size_t)g * k + f] = ((double)(ora_rng_rand(S + 2, (uint64_t)f, (uint64_t)g) >> 11) + 0.5) * 0x1p-53;
+}
+
+/* CSC -> CSC of the transpose (what Matrix::t(A) gives R, R/run_nmf.R:40):
+ * rows ascending within each column by construction. */
+ORA_API void ora_transpose(const double* Ax, const int32_t* Ai, const int32_t* Ap, int32_t nrow, int32_t ncol,
+                           double* Tx, int32_t* Ti, int32_t* Tp) {
+    for (int32_t r = 0; r <= nrow; ++r) Tp[r] = 0;
+    const int32_t nnz = Ap[ncol];
+    for (int32_t q = 0; q < nnz; ++q) Tp[Ai[q] + 1]++;
+    for (int32_t r = 0; r < nrow; ++r) Tp[r + 1] += Tp[r];
+    int32_t* cur = (int32_t*)malloc(sizeof(int32_t) * (size_t)(nrow > 0 ? nrow : 1));
+    memcpy(cur, Tp, sizeof(int32_t) * (size_t)nrow);
+    for (int32_t c = 0; c < ncol; ++c)
+        for (int32_t q = Ap[c]; q < Ap[c + 1]; ++q) {
+            const int32_t dst = cur[Ai[q]]++;
+            Ti[dst] = c;
+            Tx[dst] = Ax[q];
+        }
+    free(cur);
+}
