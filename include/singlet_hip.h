@@ -1,0 +1,240 @@
+/*
+ * singlet_hip.h -- C ABI of libsinglet_hip.so, the MI355X (gfx950) engine for
+ * singlet's alternating-least-squares hot path.
+ *
+ * This is the drop-in boundary.  The reference's R wrappers c_nmf / c_ard_nmf /
+ * c_project_model (R/RcppExports.R:24-30, 78-80) reach C++ through the Rcpp
+ * glue _singlet_c_nmf / _singlet_c_ard_nmf / _singlet_c_project_model
+ * (src/RcppExports.cpp:98-116, 284-304, 444-447).  A maintainer replaces the
+ * bodies of those three glue functions by calls to section 1 below (stub in
+ * INTEGRATION.md); everything R-side stays unchanged.
+ *
+ * Conventions
+ *  - plain C types only; no exceptions cross the ABI.  Every function returns
+ *    0 on success or a negative SGL_E* code; sgl_last_error() gives the text
+ *    (the R shim turns it into Rf_error, as END_RCPP does for exceptions,
+ *    src/RcppExports.cpp:115).
+ *  - sparse matrices are dgCMatrix slots (inst/include/singlet.h:36-44):
+ *    x double[nnz], i int32[nnz] (row index, ascending within a column),
+ *    p int32[ncol+1], Dim = (nrow, ncol).
+ *  - dense matrices are column-major doubles exactly as R / Eigen hold them:
+ *    w is k x nrow(A), h is k x ncol(A).
+ *  - input pointers are never written through nor retained after return;
+ *    outputs go to caller-allocated buffers.
+ *  - all arithmetic on the path is FP64 on the GPU; there is no CPU fallback:
+ *    without a usable gfx950 device every entry point fails with SGL_ENODEV.
+ */
+#ifndef SINGLET_HIP_H
+#define SINGLET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGL_API __attribute__((visibility("default")))
+
+#define SGL_OK 0
+#define SGL_EINVAL (-1)   /* bad argument */
+#define SGL_ENODEV (-2)   /* no HIP device / wrong architecture */
+#define SGL_EHIP (-3)     /* a HIP runtime call failed */
+#define SGL_ENOMEM (-4)   /* device or host allocation failed */
+#define SGL_EINTR (-5)    /* the poll callback asked to stop (Rcpp::checkUserInterrupt) */
+#define SGL_ESTATE (-6)   /* call out of order on a context */
+#define SGL_ECOMM (-7)    /* the all-reduce callback failed */
+
+SGL_API const char* sgl_last_error(void);
+/* ABI version of this header; bumped on any signature change. */
+SGL_API int sgl_abi_version(void);
+/* Number of usable gfx950 devices (0 if none); never fails. */
+SGL_API int sgl_device_count(void);
+
+/* Callbacks, all invoked on the calling thread only (as Rprintf and
+ * Rcpp::checkUserInterrupt are in the reference, src/singlet.cpp:643-663). */
+typedef struct sgl_callbacks {
+    void* user;
+    /* per-iteration trace line: iter is 1-based as printed by the reference
+     * (src/singlet.cpp:661-662, 1115-1127); overfit is NaN where the reference
+     * prints "-" or has no such column. */
+    void (*log)(void* user, int iter, double tol, double overfit);
+    /* return non-zero to abort; polled at the two points where the reference
+     * calls Rcpp::checkUserInterrupt() (src/singlet.cpp:652, 663). */
+    int (*poll)(void* user);
+} sgl_callbacks;
+
+/* ------------------------------------------------------------------------
+ * 1. One-shot entry points: exactly what the Rcpp glue binds.
+ * ---------------------------------------------------------------------- */
+
+/* c_nmf (src/singlet.cpp:669-672 -> c_nmf_base :638-666).
+ * Replaces _singlet_c_nmf (src/RcppExports.cpp:98-116).
+ * A is nrow x ncol (genes x cells); At is its transpose (ncol x nrow) as
+ * R/run_nmf.R:40 builds it; Atx/Ati/Atp may all be NULL, then the transpose is
+ * built on the device.  `threads` and `verbose` are accepted for signature
+ * parity (threads is meaningless on the GPU; verbose output goes through
+ * cb->log).  w_init: k x nrow.  Outputs: w_out k x nrow, d_out k, h_out k x ncol;
+ * *n_iter = iterations run; tol_trace (optional, maxit doubles) = tol per
+ * iteration. */
+SGL_API int sgl_c_nmf(const double* Ax, const int32_t* Ai, const int32_t* Ap,
+              const double* Atx, const int32_t* Ati, const int32_t* Atp,
+              int32_t nrow, int32_t ncol,
+              double tol, uint16_t maxit, int verbose,
+              double L1_w, double L1_h, double L2_w, double L2_h, uint16_t threads,
+              const double* w_init, int32_t k,
+              double* w_out, double* d_out, double* h_out,
+              int32_t* n_iter, double* tol_trace, const sgl_callbacks* cb);
+
+/* c_ard_nmf (src/singlet.cpp:1155-1159 -> c_ard_nmf_base :1090-1152).
+ * Replaces _singlet_c_ard_nmf (src/RcppExports.cpp:284-304).
+ * Trace arrays (test_mse, iter, tol, score_overfit) must hold maxit + 1
+ * entries; *n_trace receives their used length (the reference returns them as
+ * R vectors, src/singlet.cpp:1144-1151). */
+SGL_API int sgl_c_ard_nmf(const double* Ax, const int32_t* Ai, const int32_t* Ap,
+                  const double* Atx, const int32_t* Ati, const int32_t* Atp,
+                  int32_t nrow, int32_t ncol,
+                  double tol, uint16_t maxit, int verbose,
+                  double L1, double L2, uint16_t threads,
+                  const double* w_init, int32_t k,
+                  uint64_t seed, uint64_t inv_density, double overfit_threshold, uint16_t trace_test_mse,
+                  double* w_out, double* d_out, double* h_out,
+                  double* test_mse, int32_t* iter, double* tol_out, double* score_overfit, int32_t* n_trace,
+                  const sgl_callbacks* cb);
+
+/* c_project_model (src/singlet.cpp:405-413).
+ * Replaces _singlet_c_project_model (src/RcppExports.cpp:444-447 region).
+ * w is w_rows x w_cols column-major; if w_rows == nrow it is transposed first
+ * (l.406).  k = the factor dimension after that.  h_out: k x ncol, d_out: k. */
+SGL_API int sgl_c_project_model(const double* Ax, const int32_t* Ai, const int32_t* Ap,
+                        int32_t nrow, int32_t ncol,
+                        const double* w, int32_t w_rows, int32_t w_cols,
+                        double L1, double L2, uint16_t threads,
+                        double* h_out, double* d_out);
+
+/* ------------------------------------------------------------------------
+ * 2. Context API: the same path with the matrix kept resident in HBM, for
+ *    rank sweeps (R/ard_nmf.R:95-160 calls c_ard_nmf many times on one A),
+ *    for cell-sharded multi-GPU runs and for the benchmark.  One context =
+ *    one device = one shard of cells.
+ * ---------------------------------------------------------------------- */
+typedef struct sgl_ctx sgl_ctx;
+
+SGL_API int sgl_create(int device, sgl_ctx** out);
+SGL_API int sgl_destroy(sgl_ctx* ctx);
+/* Launch all work of this context on `hip_stream` (a hipStream_t; NULL = the
+ * context's own stream).  Lets a host that owns a stream (torch's current
+ * stream) order collectives against the kernels without host syncs. */
+SGL_API int sgl_set_stream(sgl_ctx* ctx, void* hip_stream);
+
+/* Upload a shard: columns [cell_offset, cell_offset + ncol) of a genes x
+ * ncells_total matrix.  At describes the same shard transposed (ncol x nrow,
+ * row indices local to the shard); pass NULLs to have it built on the device.
+ * Replaces the Rcpp::SparseMatrix views (inst/include/singlet.h:108-127). */
+SGL_API int sgl_upload_csc(sgl_ctx* ctx, const double* Ax, const int32_t* Ai, const int32_t* Ap,
+                   const double* Atx, const int32_t* Ati, const int32_t* Atp,
+                   int32_t nrow, int32_t ncol, int64_t cell_offset, int64_t ncells_total);
+
+/* Generate the synthetic benchmark shard on the device:
+ * entry (gene g, cell c) non-zero iff rand_S(c,g) % inv_density == 0, value
+ * levels16[(rand_{S+1}(c,g) >> 11) % 16].  Both orientations are produced. */
+SGL_API int sgl_synth_csc(sgl_ctx* ctx, uint64_t S, uint64_t inv_density, const double* levels16,
+                  int32_t ngenes, int64_t cell_offset, int32_t ncells_local, int64_t ncells_total);
+
+/* Shape / size queries. */
+SGL_API int sgl_dims(const sgl_ctx* ctx, int32_t* nrow, int32_t* ncol, int64_t* nnz);
+/* Download the resident shard as dgCMatrix slots (tests of sgl_synth_csc and
+ * of the device transpose).  which = 0: A, 1: At.  Buffers sized from sgl_dims. */
+SGL_API int sgl_download_csc(sgl_ctx* ctx, int which, double* x, int32_t* i, int64_t* p);
+
+/* Start a fit at rank k.  w_init: k x nrow host array, or NULL to fill W on
+ * the device with the synthetic init ((rand_{S+2}(f,g) >> 11) + 0.5) * 2^-53.
+ * h = 0, d = 1 as in src/singlet.cpp:639-641. */
+SGL_API int sgl_fit_init(sgl_ctx* ctx, int32_t k, const double* w_init, uint64_t synth_seed);
+
+/* Collective hook for cell-sharded runs.  Called with a device pointer to
+ * `count` doubles that must be summed in place over all shards, on the
+ * context's stream semantics described at sgl_set_stream.  NULL = one shard. */
+typedef int (*sgl_allreduce_fn)(void* user, void* dev_ptr, int64_t count);
+SGL_API int sgl_set_allreduce(sgl_ctx* ctx, sgl_allreduce_fn fn, void* user);
+
+/* Step-level operators (what c_nmf_base's loop body is made of).  A sharded
+ * host runs them in this order per iteration; sgl_nmf_run does the same
+ * internally.
+ *   sgl_step_h      predict(A, w, h, L1_h, L2_h)    src/singlet.cpp:650
+ *   sgl_step_scale_h  scale(h, d)  (all-reduces k row sums if sharded)  :651
+ *   sgl_step_w      predict(At, h, w, L1_w, L2_w)   :654  (all-reduces the
+ *                   k x nrow right-hand sides and the k x k Gram if sharded)
+ *   sgl_step_scale_w  scale(w, d); tol = cor(w, w_prev)  :655-659
+ * sgl_step_begin snapshots w_it = w (:648). */
+SGL_API int sgl_step_begin(sgl_ctx* ctx);
+SGL_API int sgl_step_h(sgl_ctx* ctx, double L1, double L2);
+SGL_API int sgl_step_scale_h(sgl_ctx* ctx);
+SGL_API int sgl_step_w(sgl_ctx* ctx, double L1, double L2);
+SGL_API int sgl_step_scale_w(sgl_ctx* ctx, double* tol_out);
+
+/* Whole loops on the resident shard. */
+SGL_API int sgl_nmf_run(sgl_ctx* ctx, double tol, int32_t maxit,
+                double L1_w, double L1_h, double L2_w, double L2_h,
+                int32_t* n_iter, double* tol_trace, const sgl_callbacks* cb);
+SGL_API int sgl_ard_run(sgl_ctx* ctx, double tol, int32_t maxit, double L1, double L2,
+                uint64_t seed, uint64_t inv_density, double overfit_threshold, int32_t trace_test_mse,
+                double* test_mse, int32_t* iter, double* tol_out, double* score_overfit, int32_t* n_trace,
+                int32_t* n_iter, const sgl_callbacks* cb);
+/* One H-update against a fixed, already scaled W (the body of c_project_model). */
+SGL_API int sgl_project_run(sgl_ctx* ctx, double L1, double L2);
+
+/* Results of the current fit: w k x nrow, d k, h k x ncol_local (any may be NULL). */
+SGL_API int sgl_get_factors(sgl_ctx* ctx, double* w, double* d, double* h);
+/* Overwrite the current factors (warm start / tests).  Any may be NULL. */
+SGL_API int sgl_set_factors(sgl_ctx* ctx, const double* w, const double* d, const double* h);
+
+/* ------------------------------------------------------------------------
+ * 3. Single operators, exposed for the parity tests (each is one kernel
+ *    family of the path) and for profiling.
+ * ---------------------------------------------------------------------- */
+/* rng::rand(i, j) (src/singlet.cpp:47-64) for n (i, j) pairs, on the device. */
+SGL_API int sgl_op_rand(sgl_ctx* ctx, uint64_t state, const uint64_t* i, const uint64_t* j, int64_t n, uint64_t* out);
+/* draw(cell, gene, inv_density) (src/singlet.cpp:91-95) for the block
+ * cells [cell0, cell0+ncells) x genes [0, ngenes): out[c * ngenes + g]. */
+SGL_API int sgl_op_mask(sgl_ctx* ctx, uint64_t state, uint64_t inv_density, int64_t cell0, int32_t ncells, int32_t ngenes,
+                uint8_t* out);
+/* AAt (src/singlet.cpp:200-206): G = F F^T (+1e-15 on the diagonal), F k x cols. */
+SGL_API int sgl_op_gram(sgl_ctx* ctx, const double* F, int32_t k, int64_t cols, double* G);
+/* Right-hand sides of predict (src/singlet.cpp:341-343) for the resident
+ * shard: which = 0: B = F * A (F k x nrow, B k x ncol); which = 1: B = F * At. */
+SGL_API int sgl_op_rhs(sgl_ctx* ctx, int which, const double* F, int32_t k, double* B);
+/* nnls (src/singlet.cpp:229-250) on ncols independent columns sharing G:
+ * B k x ncols (destroyed on the device, not written back), X k x ncols in/out. */
+SGL_API int sgl_op_nnls(sgl_ctx* ctx, const double* G, const double* B, double* X, int32_t k, int64_t ncols,
+                double L1, double L2, int32_t* sweeps_out);
+/* scale (src/singlet.cpp:219-225) and cor (:184-197). */
+SGL_API int sgl_op_scale(sgl_ctx* ctx, double* F, int32_t k, int64_t cols, double* d);
+SGL_API int sgl_op_cor(sgl_ctx* ctx, const double* x, const double* y, int64_t n, double* out);
+/* mse_test (src/singlet.cpp:536-568) on the resident shard with the current factors. */
+SGL_API int sgl_op_mse_test(sgl_ctx* ctx, uint64_t seed, uint64_t inv_density, double* out);
+
+/* ------------------------------------------------------------------------
+ * 4. Timing (hipEvent based, on the context's stream).
+ * ---------------------------------------------------------------------- */
+#define SGL_PH_GRAM 0      /* AAt kernels */
+#define SGL_PH_RHS_H 1     /* sparse accumulate, H-update (over A) */
+#define SGL_PH_NNLS_H 2
+#define SGL_PH_RHS_W 3     /* sparse accumulate, W-update (over At) */
+#define SGL_PH_NNLS_W 4
+#define SGL_PH_SCALE 5     /* row sums, scale, cor, copies */
+#define SGL_PH_COMM 6      /* all-reduce callback */
+#define SGL_PH_MASK 7      /* masked-path extras: Gram downdates, mse_test */
+#define SGL_PH_COUNT 8
+/* Enable/disable per-phase timing (costs two event records per kernel group). */
+SGL_API int sgl_timing_enable(sgl_ctx* ctx, int on);
+/* ms[SGL_PH_COUNT] accumulated since the last reset, calls[SGL_PH_COUNT] launches. */
+SGL_API int sgl_timing_get(sgl_ctx* ctx, double* ms, int64_t* calls, int reset);
+/* NNLS sweep totals since the last reset: [0] H solves, [1] W solves; and
+ * number of columns solved [2], [3]. */
+SGL_API int sgl_sweeps_get(sgl_ctx* ctx, int64_t* out4, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SINGLET_HIP_H */

@@ -1,0 +1,10 @@
+"""singlet_amd: MI355X (gfx950) engine for singlet's ALS hot path
+(c_nmf / c_ard_nmf / c_project_model of src/singlet.cpp) behind a C ABI
+(include/singlet_hip.h), plus the Python mirror of the R interface above it."""
+from .sparse import dgCMatrix, as_dgCMatrix  # noqa: F401
+from .context import Context, LEVELS16, SYNTH_SEED  # noqa: F401
+from .api import (c_nmf, c_ard_nmf, c_project_model, run_nmf, ard_nmf, cross_validate_nmf,  # noqa: F401
+                  GetBestRank, project_model, CVData)
+from ._lib import SingletHipError, LIB_PATH  # noqa: F401
+
+__version__ = "0.1.0"

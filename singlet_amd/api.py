@@ -1,0 +1,315 @@
+"""Host-side mirror of singlet's R interface for the ALS hot path.
+
+The reference's host language is R (absent from this image), so the functions
+the R drivers call are mirrored here one-for-one in Python, with the same
+names, argument order, defaults and return fields:
+
+  c_nmf / c_ard_nmf / c_project_model   R/RcppExports.R:28-30, 78-80, 24-26
+  run_nmf                               R/run_nmf.R:18-77
+  ard_nmf                               R/ard_nmf.R:31-193
+  cross_validate_nmf                    R/cross_validate_nmf.R:18-105
+  GetBestRank                           R/GetBestRank.R:8-46
+  project_model                         R/ProjectData.R:11-19
+
+Matrices follow R's orientation: w is returned k x m by c_nmf and m x k by
+run_nmf / ard_nmf (they transpose and sort by d, R/run_nmf.R:65-68); h is
+k x n.  All numerics run in libsinglet_hip.so on the GPU; nothing here computes
+on the CPU beyond bookkeeping.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, f64p, i32p, ptr
+from .context import make_callbacks
+from .sparse import as_dgCMatrix, dgCMatrix
+
+
+# ---------------------------------------------------------------------------
+# RcppExports layer
+# ---------------------------------------------------------------------------
+def _w_in(w, nrow):
+    """R matrix k x m (column-major) -> (m, k) C-contiguous buffer."""
+    w = np.asarray(w, dtype=np.float64)
+    if w.ndim != 2 or w.shape[1] != nrow:
+        raise ValueError("w must be a k x nrow(A) matrix (got %r, nrow(A) = %d)" % (w.shape, nrow))
+    return np.ascontiguousarray(w.T)
+
+
+def _verbose_log(verbose, ard=False):
+    if not verbose:
+        return None
+    if ard:
+        print("\n%4s | %8s | %8s \n---------------------------" % ("iter", "tol", "overfit"))
+
+        def log(it, tol, of):
+            print("%4d | %8.2e | %s" % (it, tol, ("%8s" % "-") if math.isnan(of) else ("%8.2e" % of)))
+    else:
+        print("\n%4s | %8s \n---------------" % ("iter", "tol"))
+
+        def log(it, tol, of):
+            print("%4d | %8.2e" % (it, tol))
+    return log
+
+
+def c_nmf(A, At, tol, maxit, verbose, L1_w, L1_h, L2_w, L2_h, threads, w):
+    """.Call(`_singlet_c_nmf`, ...) -> list(w = k x m, d = k, h = k x n)  (src/singlet.cpp:665)."""
+    L = _lib.load()
+    A = as_dgCMatrix(A)
+    At = None if At is None else as_dgCMatrix(At)
+    wb = _w_in(w, A.nrow)
+    m, k = wb.shape
+    n = A.ncol
+    w_out, h_out, d_out = np.empty((m, k)), np.empty((n, k)), np.empty(k)
+    n_iter = C.c_int32()
+    tr = np.zeros(max(int(maxit), 1))
+    cb = make_callbacks(_verbose_log(verbose))
+    t = (ptr(At.x, f64p), ptr(At.i, i32p), ptr(At.p, i32p)) if At is not None else (None, None, None)
+    check(L.sgl_c_nmf(ptr(A.x, f64p), ptr(A.i, i32p), ptr(A.p, i32p), *t, A.nrow, A.ncol, float(tol), int(maxit),
+                      int(bool(verbose)), L1_w, L1_h, L2_w, L2_h, int(threads), ptr(wb, f64p), k, ptr(w_out, f64p),
+                      ptr(d_out, f64p), ptr(h_out, f64p), C.byref(n_iter), ptr(tr, f64p), C.byref(cb)))
+    return {"w": w_out.T, "d": d_out, "h": h_out.T, "iter": n_iter.value, "tol": tr[:n_iter.value].copy()}
+
+
+def c_ard_nmf(A, At, tol, maxit, verbose, L1, L2, threads, w, seed, inv_density, overfit_threshold, trace_test_mse):
+    """.Call(`_singlet_c_ard_nmf`, ...) -> list(w, d, h, test_mse, iter, tol, score_overfit) (src/singlet.cpp:1144-1151)."""
+    L = _lib.load()
+    A = as_dgCMatrix(A)
+    At = None if At is None else as_dgCMatrix(At)
+    wb = _w_in(w, A.nrow)
+    m, k = wb.shape
+    n = A.ncol
+    w_out, h_out, d_out = np.empty((m, k)), np.empty((n, k)), np.empty(k)
+    cap = int(maxit) + 2
+    tm, ft, so = np.zeros(cap), np.zeros(cap), np.zeros(cap)
+    itv = np.zeros(cap, dtype=np.int32)
+    nt = C.c_int32()
+    cb = make_callbacks(_verbose_log(verbose, ard=True))
+    t = (ptr(At.x, f64p), ptr(At.i, i32p), ptr(At.p, i32p)) if At is not None else (None, None, None)
+    check(L.sgl_c_ard_nmf(ptr(A.x, f64p), ptr(A.i, i32p), ptr(A.p, i32p), *t, A.nrow, A.ncol, float(tol), int(maxit),
+                          int(bool(verbose)), L1, L2, int(threads), ptr(wb, f64p), k, int(seed), int(inv_density),
+                          float(overfit_threshold), int(trace_test_mse), ptr(w_out, f64p), ptr(d_out, f64p),
+                          ptr(h_out, f64p), ptr(tm, f64p), ptr(itv, i32p), ptr(ft, f64p), ptr(so, f64p), C.byref(nt),
+                          C.byref(cb)))
+    q = nt.value
+    return {"w": w_out.T, "d": d_out, "h": h_out.T, "test_mse": tm[:q].copy(), "iter": itv[:q].copy(),
+            "tol": ft[:q].copy(), "score_overfit": so[:q].copy()}
+
+
+def c_project_model(A, w, L1, L2, threads):
+    """.Call(`_singlet_c_project_model`, ...) -> list(h = k x n, d = k)  (src/singlet.cpp:405-413)."""
+    L = _lib.load()
+    A = as_dgCMatrix(A)
+    w = np.asarray(w, dtype=np.float64)
+    if w.ndim != 2:
+        raise ValueError("w must be a matrix")
+    w_rows, w_cols = w.shape
+    wf = np.ascontiguousarray(w.T)  # column-major image of w
+    k = w_cols if w_rows == A.nrow else w_rows
+    h_out, d_out = np.empty((A.ncol, k)), np.empty(k)
+    check(L.sgl_c_project_model(ptr(A.x, f64p), ptr(A.i, i32p), ptr(A.p, i32p), A.nrow, A.ncol, ptr(wf, f64p),
+                                w_rows, w_cols, L1, L2, int(threads), ptr(h_out, f64p), ptr(d_out, f64p)))
+    return {"h": h_out.T, "d": d_out}
+
+
+# ---------------------------------------------------------------------------
+# R drivers
+# ---------------------------------------------------------------------------
+def _pair(v):
+    v = list(np.atleast_1d(v))
+    return (float(v[0]), float(v[0])) if len(v) != 2 else (float(v[0]), float(v[1]))
+
+
+def _rng(seed):
+    return seed if isinstance(seed, np.random.Generator) else np.random.default_rng(seed)
+
+
+def _sort_model(model, rn=None, cn=None):
+    # sort_index <- order(model$d, decreasing = TRUE)   R/run_nmf.R:65-68
+    idx = np.argsort(-model["d"], kind="stable")
+    model["d"] = model["d"][idx]
+    model["w"] = model["w"].T[:, idx]
+    model["h"] = model["h"][idx, :]
+    k = model["d"].shape[0]
+    model["factor_names"] = ["NMF_%d" % (q + 1) for q in range(k)]
+    model["rownames_w"] = rn
+    model["colnames_h"] = cn
+    return model
+
+
+def run_nmf(A, rank, tol=1e-4, maxit=100, verbose=True, L1=0.01, L2=0, threads=0, seed=None):
+    """R/run_nmf.R:18-77 (sparse, single-matrix branch).  `seed` replaces R's global RNG state
+    (stats::runif, l.55): an int or numpy Generator."""
+    A = as_dgCMatrix(A)
+    if verbose:
+        print("running with sparse optimization")
+    L1 = _pair(L1)
+    L2 = _pair(L2)
+    # w_init <- matrix(stats::runif(nrow(A) * rank), rank, nrow(A))
+    w_init = _rng(seed).random((A.nrow, rank)).T
+    model = c_nmf(A, None, tol, maxit, bool(verbose), L1[0], L1[1], L2[0], L2[1], threads, w_init)
+    return _sort_model(model, A.Dimnames[0], A.Dimnames[1])
+
+
+def project_model(A, w, L1=0.01, L2=0, threads=0):
+    """R/ProjectData.R:11-19."""
+    A = as_dgCMatrix(A)
+    w = np.asarray(w)
+    if w.shape[0] != A.nrow and w.shape[1] != A.nrow:
+        raise ValueError("'w' must share a common edge with the rows of 'A'")
+    return c_project_model(A, w, L1, L2, threads)
+
+
+class CVData(list):
+    """cv_data rows: dicts with k, rep, test_error, iter, tol (+ overfit_score from ard_nmf);
+    the column sets match R/ard_nmf.R:93,118 and R/cross_validate_nmf.R:90."""
+
+    def columns(self):
+        return list(self[0].keys()) if self else []
+
+    def column(self, name):
+        return [r[name] for r in self]
+
+
+def GetBestRank(df, tol_overfit=1e-4):
+    """R/GetBestRank.R:8-46, line for line."""
+    df = list(df)
+    best_ranks = []
+    for replicate in sorted({r["rep"] for r in df}):
+        df_rep = [r for r in df if r["rep"] == replicate]
+        max_rank = max(r["k"] for r in df_rep) + 1
+        seen = []
+        for r in df_rep:
+            if r["k"] not in seen:
+                seen.append(r["k"])
+        for rank in seen:
+            if rank < max_rank:
+                te = [r["test_error"] for r in df_rep if r["k"] == rank]
+                if len(te) > 1:
+                    v2 = te[1:]
+                    v1 = te[:-1]
+                    if len(v1) >= 2:
+                        for pos in range(1, len(v1)):
+                            if v1[pos] > v1[pos - 1]:
+                                v1[pos] = v1[pos - 1]
+                    if max([0.0] + [(b - a) / (b + a) for a, b in zip(v1, v2)]) > tol_overfit:
+                        max_rank = rank
+        df_rep = [r for r in df_rep if r["k"] < max_rank]
+        if len(df_rep) == 0:
+            best_ranks.append(2)
+        elif len(df) == 1:
+            best_ranks.append(df_rep[0]["k"])
+        else:
+            # group_by(rep, k) %>% slice(which.max(iter)): groups come out sorted by k
+            last = {}
+            for r in df_rep:
+                cur = last.get(r["k"])
+                if cur is None or r["iter"] > cur["iter"]:
+                    last[r["k"]] = r
+            rows = [last[kk] for kk in sorted(last)]
+            errs = [r["test_error"] for r in rows]
+            best_ranks.append(rows[errs.index(min(errs))]["k"])
+    return int(math.floor(sum(best_ranks) / len(best_ranks)))
+
+
+def ard_nmf(A, k_init=2, k_max=100, k_min=2, n_replicates=1, tol=1e-5, cv_tol=1e-4, maxit=100, verbose=1, L1=0.01,
+            L2=0, threads=0, test_density=0.05, learning_rate=1, tol_overfit=1e-3, trace_test_mse=1, seed=None):
+    """R/ard_nmf.R:31-193 (sparse, single-matrix branch): automatic rank search, then the final fit."""
+    if not L1 < 1:
+        raise ValueError("L1 penalty must be strictly in the range (0, 1]")
+    if k_init is None or (isinstance(k_init, float) and math.isnan(k_init)) or k_init < k_min:
+        k_init = k_min
+    if k_min < 2:
+        raise ValueError("k_min cannot be less than 2")
+    A = as_dgCMatrix(A)
+    if verbose > 0:
+        print("running with sparse optimization")
+    rng = _rng(seed)
+    # w_init <- lapply(1:n_replicates, function(x) matrix(runif(nrow(A) * k_max), k_max, nrow(A)))
+    w_init = [rng.random((A.nrow, k_max)).T for _ in range(n_replicates)]
+    test_seed = int(rng.integers(1, 2 ** 31 - 1))  # abs(.Random.seed[[3]])
+    inv_density = int(round(1 / test_density))
+    df = CVData()
+    for curr_rep in range(1, n_replicates + 1):
+        if verbose >= 1 and n_replicates > 1:
+            print("\nREPLICATE ", curr_rep, "/", n_replicates)
+        step_size = 1.0
+        curr_rank = k_init
+        while step_size >= 1 and curr_rank <= k_max and curr_rank >= k_min:
+            if verbose > 0:
+                print("k =", curr_rank, ", rep =", curr_rep)
+            w_init_this = w_init[curr_rep - 1][:curr_rank, :]
+            model = c_ard_nmf(A, None, cv_tol, maxit, verbose > 2, L1, L2, threads, w_init_this, test_seed + curr_rep,
+                              inv_density, tol_overfit, trace_test_mse)
+            overfit_score = float(model["score_overfit"][-1])
+            for q in range(len(model["test_mse"])):
+                df.append({"k": int(curr_rank), "rep": int(curr_rep), "test_error": float(model["test_mse"][q]),
+                           "iter": int(model["iter"][q]), "tol": float(model["tol"][q]),
+                           "overfit_score": overfit_score})
+            if overfit_score >= tol_overfit:
+                k_max = curr_rank
+            df_rep = sorted([r for r in df if r["rep"] == curr_rep], key=lambda r: r["k"])
+            best_rank = GetBestRank([r for r in df_rep if r["k"] < k_max])
+            ks = sorted({r["k"] for r in df_rep})
+            if best_rank not in ks:
+                raise RuntimeError("argument is of length zero")  # what R's `if (rank_ind == ...)` does here
+            rank_ind = ks.index(best_rank) + 1
+            if rank_ind == len(ks):
+                step_size = step_size * (1 + learning_rate)
+                curr_rank = best_rank + int(math.floor(step_size))
+            elif rank_ind == 1:
+                if math.floor(step_size) < best_rank:
+                    curr_rank = best_rank - int(math.floor(step_size))
+                    step_size = step_size * (learning_rate + 1)
+                else:
+                    curr_rank = best_rank // 2
+            else:
+                next_lower_rank = ks[rank_ind - 2]
+                next_higher_rank = ks[rank_ind]
+                diff_lower = best_rank - next_lower_rank
+                diff_higher = next_higher_rank - best_rank
+                higher_option = best_rank + diff_higher // 2
+                lower_option = best_rank - diff_lower // 2
+                if diff_lower <= 1 and diff_higher <= 1:
+                    break
+                elif diff_lower >= diff_higher:
+                    curr_rank = lower_option
+                else:
+                    curr_rank = higher_option
+    best_rank = GetBestRank(df, tol_overfit)
+    if verbose > 0:
+        print("\nFitting final model at k =", best_rank)
+    w_init_this = w_init[0][:best_rank, :]
+    model = c_nmf(A, None, tol, maxit, verbose > 2, L1, L1, L2, L2, threads, w_init_this)
+    model["cv_data"] = df
+    return _sort_model(model, A.Dimnames[0], A.Dimnames[1])
+
+
+def cross_validate_nmf(A, ranks, n_replicates=3, tol=1e-4, maxit=100, verbose=1, L1=0.01, L2=0, threads=0,
+                       test_density=0.05, tol_overfit=1e-4, trace_test_mse=5, seed=None):
+    """R/cross_validate_nmf.R:18-105 (sparse, single-matrix branch) -> cv table with k, rep, test_error, iter, tol."""
+    if L1 >= 1:
+        raise ValueError("L1 penalty must be strictly in the range (0, 1]")
+    A = as_dgCMatrix(A)
+    ranks = [int(r) for r in np.atleast_1d(ranks)]
+    rng = _rng(seed)
+    w_init = [rng.random((A.nrow, max(ranks))).T for _ in range(n_replicates)]
+    seeds = [int(rng.integers(1, 2 ** 31 - 1)) for _ in range(n_replicates)]  # abs(.Random.seed[[3 + rep]])
+    inv_density = int(round(1 / test_density))
+    df2 = CVData()
+    grid = [(k, rep) for rep in range(1, n_replicates + 1) for k in ranks]  # expand.grid(k = ranks, rep = 1:n)
+    for q, (k, rep) in enumerate(grid):
+        if verbose > 1:
+            print("k = %d, rep = %d (%d/%d):" % (k, rep, q + 1, len(grid)))
+        model = c_ard_nmf(A, None, tol, maxit, verbose > 1, L1, L2, threads, w_init[rep - 1][:k, :], seeds[rep - 1],
+                          inv_density, tol_overfit, trace_test_mse)
+        for t in range(len(model["test_mse"])):
+            df2.append({"k": k, "rep": rep, "test_error": float(model["test_mse"][t]), "iter": int(model["iter"][t]),
+                        "tol": float(model["tol"][t])})
+        if verbose > 1:
+            print("test set error: %#.4e\n" % model["test_mse"][-1])
+            if model["test_mse"][-1] / model["test_mse"][0] > (1 + tol_overfit):
+                print("overfitting detected, lower rank recommended")
+    return df2

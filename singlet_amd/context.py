@@ -1,0 +1,250 @@
+"""Device context: one resident shard of cells on one MI355X (sgl_ctx of
+include/singlet_hip.h section 2).  Thin object wrapper over the C ABI."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, f64p, i32p, i64p, ptr, u64p, u8p
+
+SYNTH_SEED = 0x5EED
+# 16 value levels of the synthetic generator: log1p(1 + level)
+LEVELS16 = np.log1p(1.0 + np.arange(16, dtype=np.float64))
+
+
+def _f(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def make_callbacks(log=None, poll=None):
+    """Builds an sgl_callbacks struct; keep the returned object alive during the call."""
+    cb = _lib.Callbacks()
+    keep = []
+    if log is not None:
+        fn = _lib.LOG_FN(lambda user, it, tol, of: log(it, tol, of))
+        cb.log = fn
+        keep.append(fn)
+    if poll is not None:
+        fn = _lib.POLL_FN(lambda user: int(bool(poll())))
+        cb.poll = fn
+        keep.append(fn)
+    cb._keep = keep
+    return cb
+
+
+class Context:
+    def __init__(self, device=0):
+        self._L = _lib.load()
+        h = C.c_void_p()
+        check(self._L.sgl_create(int(device), C.byref(h)))
+        self._h = h
+        self._keep = []
+        self.k = 0
+
+    # -- lifetime ---------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.sgl_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- matrix -----------------------------------------------------------
+    def upload(self, A, At=None, cell_offset=0, ncells_total=0):
+        a = (ptr(A.x, f64p), ptr(A.i, i32p), ptr(A.p, i32p))
+        if At is not None:
+            if At.Dim != (A.Dim[1], A.Dim[0]):
+                raise ValueError("At must be the transpose of A")
+            t = (ptr(At.x, f64p), ptr(At.i, i32p), ptr(At.p, i32p))
+        else:
+            t = (None, None, None)
+        check(self._L.sgl_upload_csc(self._h, *a, *t, A.nrow, A.ncol, int(cell_offset), int(ncells_total)))
+        self.k = 0
+
+    def synth(self, ngenes, ncells_local, inv_density=20, seed=SYNTH_SEED, cell_offset=0, ncells_total=0):
+        lv = _f(LEVELS16)
+        check(self._L.sgl_synth_csc(self._h, seed, inv_density, ptr(lv, f64p), int(ngenes), int(cell_offset),
+                                    int(ncells_local), int(ncells_total)))
+        self.k = 0
+
+    def dims(self):
+        nr, nc, nz = C.c_int32(), C.c_int32(), C.c_int64()
+        check(self._L.sgl_dims(self._h, C.byref(nr), C.byref(nc), C.byref(nz)))
+        return nr.value, nc.value, nz.value
+
+    def download(self, which=0):
+        nr, nc, nz = self.dims()
+        ncol = nr if which else nc
+        x = np.empty(nz)
+        i = np.empty(nz, dtype=np.int32)
+        p = np.empty(ncol + 1, dtype=np.int64)
+        check(self._L.sgl_download_csc(self._h, int(which), ptr(x, f64p), ptr(i, i32p), ptr(p, i64p)))
+        return x, i, p
+
+    # -- fit ----------------------------------------------------------------
+    def fit_init(self, k, w_init=None, synth_seed=SYNTH_SEED):
+        """w_init: (m, k) C-contiguous (== k x m column-major) or None for the synthetic init."""
+        w = None
+        if w_init is not None:
+            w = _f(w_init)
+            nr, _, _ = self.dims()
+            if w.shape != (nr, k):
+                raise ValueError("w_init must be k x nrow(A) (got %r for k=%d, nrow=%d)" % (w.shape[::-1], k, nr))
+        check(self._L.sgl_fit_init(self._h, int(k), ptr(w, f64p), synth_seed))
+        self.k = int(k)
+
+    def set_stream(self, stream_ptr):
+        check(self._L.sgl_set_stream(self._h, C.c_void_p(stream_ptr) if stream_ptr else None))
+
+    def set_allreduce(self, fn):
+        """fn(dev_ptr: int, count: int) -> None; sums `count` doubles at dev_ptr over all shards."""
+        if fn is None:
+            cfn = C.cast(None, _lib.ALLREDUCE_FN)
+        else:
+            def tramp(user, dev_ptr, count):
+                try:
+                    fn(int(dev_ptr), int(count))
+                    return 0
+                except Exception:  # noqa: BLE001 - must not unwind through C
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            cfn = _lib.ALLREDUCE_FN(tramp)
+        self._keep = [cfn]
+        check(self._L.sgl_set_allreduce(self._h, cfn, None))
+
+    def step_begin(self):
+        check(self._L.sgl_step_begin(self._h))
+
+    def step_h(self, L1, L2):
+        check(self._L.sgl_step_h(self._h, L1, L2))
+
+    def step_scale_h(self):
+        check(self._L.sgl_step_scale_h(self._h))
+
+    def step_w(self, L1, L2):
+        check(self._L.sgl_step_w(self._h, L1, L2))
+
+    def step_scale_w(self):
+        t = C.c_double()
+        check(self._L.sgl_step_scale_w(self._h, C.byref(t)))
+        return t.value
+
+    def nmf_run(self, tol, maxit, L1_w, L1_h, L2_w, L2_h, log=None, poll=None):
+        n_iter = C.c_int32()
+        tr = np.zeros(max(int(maxit), 1))
+        cb = make_callbacks(log, poll)
+        check(self._L.sgl_nmf_run(self._h, tol, int(maxit), L1_w, L1_h, L2_w, L2_h, C.byref(n_iter), ptr(tr, f64p),
+                                  C.byref(cb)))
+        return n_iter.value, tr[:n_iter.value].copy()
+
+    def ard_run(self, tol, maxit, L1, L2, seed, inv_density, overfit_threshold, trace_test_mse, log=None, poll=None):
+        cap = int(maxit) + 2
+        tm, ft, so = np.zeros(cap), np.zeros(cap), np.zeros(cap)
+        itv = np.zeros(cap, dtype=np.int32)
+        nt, nit = C.c_int32(), C.c_int32()
+        cb = make_callbacks(log, poll)
+        check(self._L.sgl_ard_run(self._h, tol, int(maxit), L1, L2, int(seed), int(inv_density), overfit_threshold,
+                                  int(trace_test_mse), ptr(tm, f64p), ptr(itv, i32p), ptr(ft, f64p), ptr(so, f64p),
+                                  C.byref(nt), C.byref(nit), C.byref(cb)))
+        q = nt.value
+        return dict(test_mse=tm[:q].copy(), iter=itv[:q].copy(), tol=ft[:q].copy(), score_overfit=so[:q].copy(),
+                    n_iter=nit.value)
+
+    def project_run(self, L1, L2):
+        check(self._L.sgl_project_run(self._h, L1, L2))
+
+    def get_factors(self, w=True, d=True, h=True):
+        nr, nc, _ = self.dims()
+        k = self.k
+        W = np.empty((nr, k)) if w else None
+        D = np.empty(k) if d else None
+        H = np.empty((nc, k)) if h else None
+        check(self._L.sgl_get_factors(self._h, ptr(W, f64p), ptr(D, f64p), ptr(H, f64p)))
+        return W, D, H
+
+    def set_factors(self, w=None, d=None, h=None):
+        w = None if w is None else _f(w)
+        d = None if d is None else _f(d)
+        h = None if h is None else _f(h)
+        check(self._L.sgl_set_factors(self._h, ptr(w, f64p), ptr(d, f64p), ptr(h, f64p)))
+
+    # -- single operators ---------------------------------------------------
+    def op_rand(self, state, i, j):
+        i = np.ascontiguousarray(i, dtype=np.uint64)
+        j = np.ascontiguousarray(j, dtype=np.uint64)
+        out = np.empty(i.shape, dtype=np.uint64)
+        check(self._L.sgl_op_rand(self._h, int(state), ptr(i, u64p), ptr(j, u64p), i.size, ptr(out, u64p)))
+        return out
+
+    def op_mask(self, state, inv_density, cell0, ncells, ngenes):
+        out = np.empty((ncells, ngenes), dtype=np.uint8)
+        check(self._L.sgl_op_mask(self._h, int(state), int(inv_density), int(cell0), ncells, ngenes, ptr(out, u8p)))
+        return out
+
+    def op_gram(self, F):
+        F = _f(F)
+        cols, k = F.shape
+        G = np.empty((k, k))
+        check(self._L.sgl_op_gram(self._h, ptr(F, f64p), k, cols, ptr(G, f64p)))
+        return G
+
+    def op_rhs(self, which, F):
+        F = _f(F)
+        nr, nc, _ = self.dims()
+        k = F.shape[1]
+        ncol = nr if which else nc
+        B = np.empty((ncol, k))
+        check(self._L.sgl_op_rhs(self._h, int(which), ptr(F, f64p), k, ptr(B, f64p)))
+        return B
+
+    def op_nnls(self, G, B, X, L1=0.0, L2=0.0):
+        G, B = _f(G), _f(B)
+        X = np.array(X, dtype=np.float64, order="C")
+        ncols, k = B.shape
+        sw = C.c_int32()
+        check(self._L.sgl_op_nnls(self._h, ptr(G, f64p), ptr(B, f64p), ptr(X, f64p), k, ncols, L1, L2, C.byref(sw)))
+        return X, sw.value
+
+    def op_scale(self, F):
+        F = np.array(F, dtype=np.float64, order="C")
+        cols, k = F.shape
+        d = np.empty(k)
+        check(self._L.sgl_op_scale(self._h, ptr(F, f64p), k, cols, ptr(d, f64p)))
+        return F, d
+
+    def op_cor(self, x, y):
+        x, y = _f(x), _f(y)
+        out = C.c_double()
+        check(self._L.sgl_op_cor(self._h, ptr(x, f64p), ptr(y, f64p), x.size, C.byref(out)))
+        return out.value
+
+    def op_mse_test(self, seed, inv_density):
+        out = C.c_double()
+        check(self._L.sgl_op_mse_test(self._h, int(seed), int(inv_density), C.byref(out)))
+        return out.value
+
+    # -- timing -------------------------------------------------------------
+    def timing_enable(self, on=True):
+        check(self._L.sgl_timing_enable(self._h, int(bool(on))))
+
+    def timing_get(self, reset=False):
+        ms = np.zeros(_lib.SGL_PH_COUNT)
+        calls = np.zeros(_lib.SGL_PH_COUNT, dtype=np.int64)
+        check(self._L.sgl_timing_get(self._h, ptr(ms, f64p), ptr(calls, i64p), int(reset)))
+        return {n: (float(ms[q]), int(calls[q])) for q, n in enumerate(_lib.SGL_PH_NAMES)}
+
+    def sweeps_get(self, reset=False):
+        out = np.zeros(4, dtype=np.int64)
+        check(self._L.sgl_sweeps_get(self._h, ptr(out, i64p), int(reset)))
+        return dict(h_sweeps=int(out[0]), w_sweeps=int(out[1]), h_cols=int(out[2]), w_cols=int(out[3]))

@@ -1,0 +1,327 @@
+// Dense FP64 helpers of the ALS loop: AAt (src/singlet.cpp:200-206), scale
+// (:219-225), cor (:184-197).  All reductions are two-stage with a fixed
+// order, so results are run-to-run deterministic.
+#include "sgl_internal.h"
+
+// ---------------------------------------------------------------- Gram ------
+// G = F F^T for F k x cols (column-major).  The one dense contraction of the
+// c_nmf path: done on the FP64 matrix cores, v_mfma_f64_16x16x4_f64.
+//   D(16x16) += A(16x4) * B(4x16); per lane one f64 of A and one of B:
+//   A[row = lane & 15][kk = lane >> 4], B[kk = lane >> 4][col = lane & 15];
+//   D: 4 f64 per lane, D[row = (lane >> 4) + 4 * r][col = lane & 15]
+//   (cdna_hip_programming.md:247-249).
+// With A = F[16 rows of block bi, 4 columns c..c+3] and B = the same columns of
+// row block bj transposed, both operands are ONE load of F each:
+//   a = F[bi*16 + (lane&15), c + (lane>>4)],  b = F[bj*16 + (lane&15), c + (lane>>4)].
+// A workgroup of 4 waves walks a contiguous chunk of columns; wave w takes
+// columns c0 + 4*w, + 16, ...; every wave keeps all NT*(NT+1)/2 lower-triangle
+// 16x16 tiles in registers (NT = ceil(k/16) <= 4 -> at most 10 tiles = 80 VGPRs).
+// Partials go to ws[block][k*k] and are summed in block order by gram_reduce.
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+template <int NT>
+__global__ __launch_bounds__(256) void gram_mfma_kernel(const double* __restrict__ F, int k, int64_t cols,
+                                                        int64_t cols_per_block, double* __restrict__ part) {
+    constexpr int NTILES = NT * (NT + 1) / 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r16 = lane & 15, kk = lane >> 4;
+    const int64_t c_begin = (int64_t)blockIdx.x * cols_per_block;
+    int64_t c_end = c_begin + cols_per_block;
+    if (c_end > cols) c_end = cols;
+
+    d4 acc[NTILES];
+#pragma unroll
+    for (int t = 0; t < NTILES; ++t) acc[t] = d4{0, 0, 0, 0};
+
+    for (int64_t c = c_begin + 4 * wave; c < c_end; c += 16) {
+        const int64_t cc = c + kk;
+        double f[NT];
+#pragma unroll
+        for (int b = 0; b < NT; ++b) {
+            const int row = b * 16 + r16;
+            f[b] = (cc < c_end && row < k) ? F[cc * k + row] : 0.0;
+        }
+        int t = 0;
+#pragma unroll
+        for (int bi = 0; bi < NT; ++bi)
+#pragma unroll
+            for (int bj = 0; bj <= bi; ++bj) {
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[bi], f[bj], acc[t], 0, 0, 0);
+                ++t;
+            }
+    }
+
+    // reduce the 4 waves through LDS, then write the block's partial (full k x k, both triangles)
+    __shared__ double sm[4][64 * 4];
+    double* out = part + (size_t)blockIdx.x * k * k;
+    int t = 0;
+#pragma unroll
+    for (int bi = 0; bi < NT; ++bi)
+#pragma unroll
+        for (int bj = 0; bj <= bi; ++bj) {
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sm[wave][lane * 4 + r] = acc[t][r];
+            __syncthreads();
+            if (wave == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double v = ((sm[0][lane * 4 + r] + sm[1][lane * 4 + r]) + sm[2][lane * 4 + r]) + sm[3][lane * 4 + r];
+                    const int row = bi * 16 + kk + 4 * r;  // D row (lane>>4) + 4r
+                    const int col = bj * 16 + r16;         // D col lane & 15
+                    if (row < k && col < k) {
+                        out[(size_t)col * k + row] = v;
+                        if (bi != bj) out[(size_t)row * k + col] = v;
+                    }
+                }
+            }
+            ++t;
+        }
+}
+
+// generic VALU fallback for k > 64 (NT > 4 would need > 10 accumulator tiles).
+__global__ __launch_bounds__(256) void gram_valu_kernel(const double* __restrict__ F, int k, int64_t cols,
+                                                        int64_t cols_per_block, double* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* tile = reinterpret_cast<double*>(smem_raw);  // [TC][k]
+    constexpr int TC = 16;
+    const int64_t c_begin = (int64_t)blockIdx.x * cols_per_block;
+    int64_t c_end = c_begin + cols_per_block;
+    if (c_end > cols) c_end = cols;
+    const int npairs = k * k;
+    constexpr int MAXP = (SGL_MAX_K * SGL_MAX_K + 255) / 256;
+    double acc[MAXP];
+#pragma unroll 1
+    for (int q = 0; q < MAXP; ++q) acc[q] = 0.0;
+    for (int64_t c0 = c_begin; c0 < c_end; c0 += TC) {
+        const int nc = (int)((c_end - c0 < TC) ? (c_end - c0) : TC);
+        __syncthreads();
+        for (int e = threadIdx.x; e < nc * k; e += 256) tile[e] = F[c0 * k + e];
+        __syncthreads();
+        int q = 0;
+        for (int pr = threadIdx.x; pr < npairs; pr += 256, ++q) {
+            const int i = pr % k, j = pr / k;
+            double a = acc[q];
+            for (int cc = 0; cc < nc; ++cc) a = fma(tile[cc * k + i], tile[cc * k + j], a);
+            acc[q] = a;
+        }
+    }
+    double* out = part + (size_t)blockIdx.x * k * k;
+    int q = 0;
+    for (int pr = threadIdx.x; pr < npairs; pr += 256, ++q) out[pr] = acc[q];
+}
+
+__global__ void gram_reduce_kernel(const double* __restrict__ part, int nblocks, int k, double diag_add,
+                                   double* __restrict__ G) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= k * k) return;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += part[(size_t)b * k * k + e];
+    const int i = e % k, j = e / k;
+    if (i == j) s += diag_add;
+    G[e] = s;
+}
+
+int k_gram(sgl_ctx* c, const double* F, int k, int64_t cols, double* G, double diag_add) {
+    if (k <= 0 || k > SGL_MAX_K) { sgl_set_error("k_gram: k=%d out of range", k); return SGL_EINVAL; }
+    int nblocks = (int)((cols + 1023) / 1024);
+    if (nblocks > 1024) nblocks = 1024;
+    if (nblocks < 1) nblocks = 1;
+    int64_t cpb = (cols + nblocks - 1) / nblocks;
+    cpb = (cpb + 15) / 16 * 16;  // whole 16-column steps per block
+    nblocks = (int)((cols + cpb - 1) / cpb);
+    if (nblocks < 1) nblocks = 1;
+    SGLCHK(sgl_ws_reserve(c, sizeof(double) * (size_t)nblocks * k * k));
+    hipStream_t s = c->stream;
+    const int NT = (k + 15) / 16;
+    if (NT == 1) gram_mfma_kernel<1><<<dim3(nblocks), dim3(256), 0, s>>>(F, k, cols, cpb, c->ws);
+    else if (NT == 2) gram_mfma_kernel<2><<<dim3(nblocks), dim3(256), 0, s>>>(F, k, cols, cpb, c->ws);
+    else if (NT == 3) gram_mfma_kernel<3><<<dim3(nblocks), dim3(256), 0, s>>>(F, k, cols, cpb, c->ws);
+    else if (NT == 4) gram_mfma_kernel<4><<<dim3(nblocks), dim3(256), 0, s>>>(F, k, cols, cpb, c->ws);
+    else gram_valu_kernel<<<dim3(nblocks), dim3(256), sizeof(double) * 16 * k, s>>>(F, k, cols, cpb, c->ws);
+    HIPCHK(hipGetLastError());
+    gram_reduce_kernel<<<dim3((k * k + 255) / 256), dim3(256), 0, s>>>(c->ws, nblocks, k, diag_add, G);
+    HIPCHK(hipGetLastError());
+    return SGL_OK;
+}
+
+__global__ void add_diag_kernel(double* __restrict__ G, int k, double v) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < k) G[(size_t)i * k + i] += v;
+}
+
+int k_gram_add_diag(hipStream_t s, double* G, int k, double v) {
+    add_diag_kernel<<<dim3((k + 63) / 64), dim3(64), 0, s>>>(G, k, v);
+    HIPCHK(hipGetLastError());
+    return SGL_OK;
+}
+
+// ---------------------------------------------------------------- row sums --
+// part[block][row] = sum over the block's columns of F[row, c].  Threads:
+// tx = row (strided by 64), ty = 4 column lanes.
+__global__ __launch_bounds__(256) void rowsum_kernel(const double* __restrict__ F, int k, int64_t cols,
+                                                     int64_t cols_per_block, double* __restrict__ part) {
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t c_begin = (int64_t)blockIdx.x * cols_per_block;
+    int64_t c_end = c_begin + cols_per_block;
+    if (c_end > cols) c_end = cols;
+    __shared__ double sm[4][64];
+    for (int r0 = 0; r0 < k; r0 += 64) {
+        const int row = r0 + tx;
+        double s0 = 0.0, s1 = 0.0;
+        if (row < k) {
+            int64_t cc = c_begin + ty;
+            for (; cc + 4 < c_end; cc += 8) {
+                s0 += F[cc * k + row];
+                s1 += F[(cc + 4) * k + row];
+            }
+            if (cc < c_end) s0 += F[cc * k + row];
+        }
+        __syncthreads();
+        sm[ty][tx] = s0 + s1;
+        __syncthreads();
+        if (ty == 0 && row < k) part[(size_t)blockIdx.x * k + row] = ((sm[0][tx] + sm[1][tx]) + sm[2][tx]) + sm[3][tx];
+    }
+}
+
+__global__ void rowsum_reduce_kernel(const double* __restrict__ part, int nblocks, int k, double* __restrict__ d) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= k) return;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += part[(size_t)b * k + row];
+    d[row] = s;
+}
+
+int k_rowsum(sgl_ctx* c, const double* F, int k, int64_t cols, double* d_out) {
+    int nblocks = (int)((cols + 2047) / 2048);
+    if (nblocks > 2048) nblocks = 2048;
+    if (nblocks < 1) nblocks = 1;
+    const int64_t cpb = (cols + nblocks - 1) / nblocks;
+    SGLCHK(sgl_ws_reserve(c, sizeof(double) * (size_t)nblocks * k));
+    rowsum_kernel<<<dim3(nblocks), dim3(256), 0, c->stream>>>(F, k, cols, cpb, c->ws);
+    HIPCHK(hipGetLastError());
+    rowsum_reduce_kernel<<<dim3((k + 63) / 64), dim3(64), 0, c->stream>>>(c->ws, nblocks, k, d_out);
+    HIPCHK(hipGetLastError());
+    return SGL_OK;
+}
+
+// d[i] += 1e-15 (once, by the add_eps kernel) and F[i, c] /= d[i]  (src/singlet.cpp:221-224)
+__global__ void add_eps_kernel(double* __restrict__ d, int k) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < k) d[i] += 1e-15;
+}
+
+__global__ void scale_kernel(double* __restrict__ F, int k, int64_t n, const double* __restrict__ d) {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x)
+        F[t] = F[t] / d[t % k];
+}
+
+int k_scale_apply(hipStream_t s, double* F, int k, int64_t cols, double* d, int add_eps) {
+    if (add_eps) {
+        add_eps_kernel<<<dim3((k + 63) / 64), dim3(64), 0, s>>>(d, k);
+        HIPCHK(hipGetLastError());
+    }
+    const int64_t n = (int64_t)k * cols;
+    if (n <= 0) return SGL_OK;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    scale_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(F, k, n, d);
+    HIPCHK(hipGetLastError());
+    return SGL_OK;
+}
+
+// ---------------------------------------------------------------- cor -------
+__global__ __launch_bounds__(256) void cor_partial_kernel(const double* __restrict__ x, const double* __restrict__ y,
+                                                          int64_t n, double* __restrict__ part) {
+    double s[5] = {0, 0, 0, 0, 0};
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        const double a = x[t], b = y[t];
+        s[0] += a;
+        s[1] += b;
+        s[2] = fma(a, b, s[2]);
+        s[3] = fma(a, a, s[3]);
+        s[4] = fma(b, b, s[4]);
+    }
+    __shared__ double sm[5][256];
+    for (int q = 0; q < 5; ++q) sm[q][threadIdx.x] = s[q];
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w)
+            for (int q = 0; q < 5; ++q) sm[q][threadIdx.x] += sm[q][threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x < 5) part[(size_t)blockIdx.x * 5 + threadIdx.x] = sm[threadIdx.x][0];
+}
+
+__global__ void cor_final_kernel(const double* __restrict__ part, int nblocks, int64_t n, double* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double s[5] = {0, 0, 0, 0, 0};
+    for (int b = 0; b < nblocks; ++b)
+        for (int q = 0; q < 5; ++q) s[q] += part[(size_t)b * 5 + q];
+    const double nn = (double)n;
+    // 1 - (n*sum_xy - sum_x*sum_y) / sqrt((n*sum_x2 - sum_x^2) * (n*sum_y2 - sum_y^2)), src/singlet.cpp:196;
+    // written without contraction so the final formula rounds as the reference's does.
+    const double num = __dsub_rn(__dmul_rn(nn, s[2]), __dmul_rn(s[0], s[1]));
+    const double vx = __dsub_rn(__dmul_rn(nn, s[3]), __dmul_rn(s[0], s[0]));
+    const double vy = __dsub_rn(__dmul_rn(nn, s[4]), __dmul_rn(s[1], s[1]));
+    out[0] = 1.0 - num / sqrt(__dmul_rn(vx, vy));
+}
+
+int k_cor(sgl_ctx* c, const double* x, const double* y, int64_t n, double* out_dev) {
+    int nblocks = (int)((n + 4095) / 4096);
+    if (nblocks > 512) nblocks = 512;
+    if (nblocks < 1) nblocks = 1;
+    SGLCHK(sgl_ws_reserve(c, sizeof(double) * 5 * (size_t)nblocks));
+    cor_partial_kernel<<<dim3(nblocks), dim3(256), 0, c->stream>>>(x, y, n, c->ws);
+    HIPCHK(hipGetLastError());
+    cor_final_kernel<<<dim3(1), dim3(64), 0, c->stream>>>(c->ws, nblocks, n, out_dev);
+    HIPCHK(hipGetLastError());
+    return SGL_OK;
+}
+
+// ---------------------------------------------------------------- misc ------
+// Gpad[j + KP*i] = G[j + k*i] inside k x k, 0 outside.
+__global__ void pad_gram_kernel(const double* __restrict__ G, int k, int KP, double* __restrict__ Gpad) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= KP * KP) return;
+    const int j = e % KP, i = e / KP;
+    Gpad[e] = (i < k && j < k) ? G[j + k * i] : 0.0;
+}
+
+int k_pad_gram(hipStream_t s, const double* G, int k, int KP, double* Gpad) {
+    pad_gram_kernel<<<dim3((KP * KP + 255) / 256), dim3(256), 0, s>>>(G, k, KP, Gpad);
+    HIPCHK(hipGetLastError());
+    return SGL_OK;
+}
+
+// out (cols x rows, column-major) = in^T, in is rows x cols column-major.
+__global__ void transpose_kernel(const double* __restrict__ in, int rows, int cols, double* __restrict__ out) {
+    const int64_t n = (int64_t)rows * cols;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t c = t / rows, r = t - c * rows;  // in[r, c]
+        out[r * cols + c] = in[t];
+    }
+}
+
+int k_transpose_dense(hipStream_t s, const double* in, int rows, int cols, double* out) {
+    transpose_kernel<<<dim3(1024), dim3(256), 0, s>>>(in, rows, cols, out);
+    HIPCHK(hipGetLastError());
+    return SGL_OK;
+}
+
+// Wd[t, g] = W[t, g] * d[t]   (w_ of mse_test, src/singlet.cpp:539-542)
+__global__ void wd_kernel(const double* __restrict__ W, const double* __restrict__ d, int k, int64_t n,
+                          double* __restrict__ Wd) {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x)
+        Wd[t] = W[t] * d[t % k];
+}
+
+int k_wd(hipStream_t s, const double* W, const double* d, int k, int64_t cols, double* Wd) {
+    const int64_t n = (int64_t)k * cols;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    wd_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(W, d, k, n, Wd);
+    HIPCHK(hipGetLastError());
+    return SGL_OK;
+}

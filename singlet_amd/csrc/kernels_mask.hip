@@ -1,0 +1,222 @@
+// Masked (cross-validation) extras of c_ard_nmf:
+//  * per-column Gram downdate a_i = a - AAt(submat(w, idx)) of predict_mask
+//    (src/singlet.cpp:458-463, submat :211-216, AAt :200-206), where idx is the
+//    set of rows j with draw(cell, gene) true for this column;
+//  * mse_test (src/singlet.cpp:536-568).
+// The hash is the bit-exact uint64 rng of kernels_hash.hip.
+#include "sgl_internal.h"
+
+// lower-triangle pair p -> (i, j), i >= j, p = i*(i+1)/2 + j
+__device__ __forceinline__ void tri_unrank(int p, int& i, int& j) {
+    int ii = (int)((sqrt(8.0 * (double)p + 1.0) - 1.0) * 0.5);
+    while ((ii + 1) * (ii + 2) / 2 <= p) ++ii;
+    while (ii * (ii + 1) / 2 > p) --ii;
+    i = ii;
+    j = p - ii * (ii + 1) / 2;
+}
+
+// One workgroup (256 threads) per column.  Gout[c] = G - (Gsub + 1e-15 I).
+template <int PMAX>
+__global__ __launch_bounds__(256) void mask_gram_kernel(int64_t col0, int64_t ncols, int32_t nrow,
+                                                        const int64_t* __restrict__ col_nnz,
+                                                        const double* __restrict__ F, const double* __restrict__ G,
+                                                        int k, uint64_t seed, uint64_t inv_density, int mask_t,
+                                                        int64_t col_off, int64_t row_off, double* __restrict__ Gout) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    int* list = reinterpret_cast<int*>(smem_raw);                 // [256] drawn rows of the current chunk
+    int* wcount = list + 256;                                      // [4] per-wave counts (+pad to 8 ints)
+    double* tile = reinterpret_cast<double*>(smem_raw + 264 * 4);  // [16][k]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t lc = blockIdx.x;  // local column in this launch
+    if (lc >= ncols) return;
+    const int64_t col = col0 + lc;
+    double* out = Gout + (size_t)lc * k * k;
+    if (col_nnz != nullptr && col_nnz[col] == 0) return;  // column is skipped by predict_mask (l.444)
+
+    const int npairs = k * (k + 1) / 2;
+    int pi[PMAX], pj[PMAX];
+    double acc[PMAX];
+#pragma unroll
+    for (int q = 0; q < PMAX; ++q) {
+        const int p = tid + 256 * q;
+        pi[q] = 0; pj[q] = 0; acc[q] = 0.0;
+        if (p < npairs) tri_unrank(p, pi[q], pj[q]);
+    }
+    const uint64_t gcol = (uint64_t)(col + col_off);
+    for (int64_t r0 = 0; r0 < nrow; r0 += 256) {
+        const int64_t r = r0 + tid;
+        bool drawn = false;
+        if (r < nrow) {
+            const uint64_t grow = (uint64_t)(r + row_off);
+            drawn = mask_t ? sgl_draw(seed, grow, gcol, inv_density) : sgl_draw(seed, gcol, grow, inv_density);
+        }
+        const unsigned long long m = __ballot(drawn);
+        __syncthreads();  // previous chunk's list fully consumed
+        if (lane == 0) wcount[wave] = __popcll(m);
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < wave; ++w) base += wcount[w];
+        const int total = wcount[0] + wcount[1] + wcount[2] + wcount[3];
+        if (drawn) list[base + __popcll(m & ((1ull << lane) - 1ull))] = (int)r;
+        __syncthreads();
+        for (int t0 = 0; t0 < total; t0 += 16) {
+            const int nb = (total - t0 < 16) ? (total - t0) : 16;
+            for (int e = tid; e < nb * k; e += 256) {
+                const int t = e / k, f = e - t * k;
+                tile[t * k + f] = F[(int64_t)list[t0 + t] * k + f];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < PMAX; ++q) {
+                if (tid + 256 * q < npairs) {
+                    double a = acc[q];
+                    for (int t = 0; t < nb; ++t) a = fma(tile[t * k + pi[q]], tile[t * k + pj[q]], a);
+                    acc[q] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < PMAX; ++q) {
+        if (tid + 256 * q < npairs) {
+            const int i = pi[q], j = pj[q];
+            double sub = acc[q];
+            if (i == j) sub += 1e-15;  // AAt(wsub) adds it too (quirk 8)
+            const double v = G[(size_t)j * k + i] - sub;
+            out[(size_t)j * k + i] = v;
+            out[(size_t)i * k + j] = v;
+        }
+    }
+}
+
+int k_mask_gram_cols(hipStream_t s, int64_t col0, int64_t ncols, int32_t nrow, const int64_t* col_nnz,
+                     const double* F, const double* G, int k, uint64_t seed, uint64_t inv_density, int mask_t,
+                     int64_t col_offset, int64_t row_offset, double* Gcols) {
+    if (ncols <= 0) return SGL_OK;
+    const int npairs = k * (k + 1) / 2;
+    const int P = (npairs + 255) / 256;
+    const size_t smem = 264 * 4 + sizeof(double) * 16 * (size_t)k;
+    dim3 g((unsigned)ncols), b(256);
+#define SGL_MG(PM) mask_gram_kernel<PM><<<g, b, smem, s>>>(col0, ncols, nrow, col_nnz, F, G, k, seed, inv_density, mask_t, col_offset, row_offset, Gcols)
+    if (P <= 4) SGL_MG(4);
+    else if (P <= 9) SGL_MG(9);
+    else if (P <= 20) SGL_MG(20);
+    else if (P <= 33) SGL_MG(33);
+    else { sgl_set_error("masked path supports k <= 128 (got %d)", k); return SGL_EINVAL; }
+#undef SGL_MG
+    HIPCHK(hipGetLastError());
+    return SGL_OK;
+}
+
+// ---------------------------------------------------------------- mse_test --
+// One wave per cell.  Drawn genes are queued in LDS and processed 64 at a
+// time, one gene per lane: pred = Wd[:, g] . h[:, cell]; the matrix value at
+// (g, cell) comes from a binary search of the cell's (ascending) row indices.
+__global__ __launch_bounds__(256) void mse_test_kernel(const double* __restrict__ Ax, const int32_t* __restrict__ Ai,
+                                                       const int64_t* __restrict__ Ap, int32_t m, int64_t n,
+                                                       int64_t cell_off, const double* __restrict__ Wd,
+                                                       const double* __restrict__ H, int k, uint64_t seed,
+                                                       uint64_t inv_density, double* __restrict__ losses) {
+    __shared__ int queue[4][128];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t gw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    int* qv = queue[wave];
+    for (int64_t cell = gw; cell < n; cell += nwaves) {
+        const uint64_t xi = sgl_rand_i(seed, (uint64_t)(cell + cell_off));
+        const int64_t lo0 = Ap[cell], hi0 = Ap[cell + 1];
+        const double* h = H + cell * k;
+        double s = 0.0;
+        long long cnt = 0;
+        int qn = 0;
+        for (int g0 = 0; g0 < m + 64; g0 += 64) {
+            const int g = g0 + lane;
+            const bool last = g0 >= m;
+            bool drawn = false;
+            if (!last && g < m) drawn = (sgl_rand_j(xi, (uint64_t)g) % inv_density) == 0;
+            const unsigned long long mk = __ballot(drawn);
+            if (drawn) qv[qn + __popcll(mk & ((1ull << lane) - 1ull))] = g;
+            qn += __popcll(mk);
+            __builtin_amdgcn_wave_barrier();
+            if (qn >= 64 || (last && qn > 0)) {
+                const int take = qn < 64 ? qn : 64;
+                if (lane < take) {
+                    const int gene = qv[lane];
+                    double pred = 0.0;
+                    const double* wd = Wd + (int64_t)gene * k;
+                    for (int t = 0; t < k; ++t) pred = fma(wd[t], h[t], pred);
+                    int64_t lo = lo0, hi = hi0;
+                    while (lo < hi) {
+                        const int64_t mid = (lo + hi) >> 1;
+                        if (Ai[mid] < gene) lo = mid + 1; else hi = mid;
+                    }
+                    const double val = (lo < hi0 && Ai[lo] == gene) ? Ax[lo] : 0.0;
+                    const double e = pred - val;
+                    s = fma(e, e, s);
+                    ++cnt;
+                }
+                __builtin_amdgcn_wave_barrier();
+                // shift the remainder down
+                const int rem = qn - take;
+                int mv = 0;
+                if (lane < rem) mv = qv[take + lane];
+                __builtin_amdgcn_wave_barrier();
+                if (lane < rem) qv[lane] = mv;
+                qn = rem;
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            s += __shfl_down(s, off, 64);
+            cnt += __shfl_down(cnt, off, 64);
+        }
+        if (lane == 0) losses[cell] = (cnt > 0) ? s / (double)cnt : 0.0;
+    }
+}
+
+__global__ __launch_bounds__(256) void sum_partial_kernel(const double* __restrict__ v, int64_t n,
+                                                          double* __restrict__ part) {
+    double s = 0.0;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) s += v[t];
+    __shared__ double sm[256];
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sm[threadIdx.x] += sm[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = sm[0];
+}
+
+__global__ void sum_final_kernel(const double* __restrict__ part, int nblocks, double* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += part[b];
+    out[0] = s;
+}
+
+// out_dev[0] = sum over local cells of the per-cell mean squared test error
+// (the caller divides by the global number of cells, src/singlet.cpp:567).
+int k_mse_test(sgl_ctx* c, const double* Wd, const double* H, int k, uint64_t seed, uint64_t inv_density,
+               double* out_dev) {
+    const int64_t n = c->A.ncol;
+    if (n <= 0) return SGL_OK;
+    int nblocks = (int)((n + 4095) / 4096);
+    if (nblocks > 256) nblocks = 256;
+    if (nblocks < 1) nblocks = 1;
+    SGLCHK(sgl_ws_reserve(c, sizeof(double) * ((size_t)n + (size_t)nblocks)));
+    double* losses = c->ws;
+    double* part = c->ws + n;
+    int64_t blocks = (n + 3) / 4;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    mse_test_kernel<<<dim3((unsigned)blocks), dim3(256), 0, c->stream>>>(c->A.x, c->A.i, c->A.p, c->A.nrow, n,
+                                                                         c->cell_offset, Wd, H, k, seed, inv_density,
+                                                                         losses);
+    HIPCHK(hipGetLastError());
+    sum_partial_kernel<<<dim3(nblocks), dim3(256), 0, c->stream>>>(losses, n, part);
+    HIPCHK(hipGetLastError());
+    sum_final_kernel<<<dim3(1), dim3(64), 0, c->stream>>>(part, nblocks, out_dev);
+    HIPCHK(hipGetLastError());
+    return SGL_OK;
+}

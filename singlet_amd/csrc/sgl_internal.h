@@ -1,0 +1,177 @@
+// Internal declarations shared by the translation units of libsinglet_hip.so.
+// gfx950 (MI355X, CDNA4) only: wave = 64 lanes, no other target is supported.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <vector>
+#include <algorithm>
+
+#include "../../include/singlet_hip.h"
+
+#define SGL_WAVE 64
+#define SGL_MAX_K 256          // generic (wave-per-column) NNLS handles k <= 256
+#define SGL_LANE_NNLS_MAX_K 64  // register-resident lane-per-column NNLS handles k <= 64
+
+void sgl_set_error(const char* fmt, ...);
+
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e__ = (expr);                                                                       \
+        if (e__ != hipSuccess) {                                                                       \
+            sgl_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+            return SGL_EHIP;                                                                           \
+        }                                                                                              \
+    } while (0)
+
+#define SGLCHK(expr)              \
+    do {                          \
+        int r__ = (expr);         \
+        if (r__ != SGL_OK) return r__; \
+    } while (0)
+
+// One orientation of the resident shard: CSC with 64-bit column pointers.
+struct DevCSC {
+    double* x = nullptr;
+    int32_t* i = nullptr;
+    int64_t* p = nullptr;
+    int32_t nrow = 0, ncol = 0;
+    int64_t nnz = 0;
+    // Tiling of the row range into L2-sized pieces for the sparse accumulate:
+    // seg[t * ncol + c] = first non-zero of column c with row >= t * tile_rows
+    // (t = 0..ntiles), so tile t of column c is [seg[t][c], seg[t+1][c]).
+    int64_t* seg = nullptr;
+    int32_t tile_rows = 0, ntiles = 0;
+};
+
+struct PhaseEvent {
+    int phase;
+    hipEvent_t e0, e1;
+};
+
+struct sgl_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+
+    DevCSC A, At;  // A: genes x local cells; At: local cells x genes
+    int64_t cell_offset = 0, ncells_total = 0;
+    int64_t* col_nnz_A = nullptr;   // n_local: nnz per cell (skip rule of predict, l.340)
+    int64_t* col_nnz_At = nullptr;  // m: GLOBAL nnz per gene (after all-reduce when sharded)
+    bool gene_nnz_global = false;
+
+    int k = 0;
+    double *W = nullptr, *Wprev = nullptr, *H = nullptr, *d = nullptr;
+    double* B = nullptr;    // k x ncol_local right-hand sides of the H-update
+    double* red = nullptr;  // [k*m right-hand sides of the W-update | k*k Gram of H | k row sums]
+    double* G = nullptr;    // k x k Gram (+1e-15 diagonal)
+    double* Gpad = nullptr; // KP x KP zero-padded copy for the lane NNLS kernel
+    double* ws = nullptr;   // partial-reduction workspace
+    size_t ws_bytes = 0;
+    double* scalars = nullptr;       // device scratch for cor / mse results
+    int* sweep_counters = nullptr;   // device: [0] H sweeps, [1] W sweeps
+    int64_t sweeps_acc[4] = {0, 0, 0, 0};
+    double* pinned = nullptr;        // host pinned scratch (8 doubles)
+
+    sgl_allreduce_fn allreduce = nullptr;
+    void* allreduce_user = nullptr;
+
+    bool timing = false;
+    std::vector<PhaseEvent> pending;
+    std::vector<hipEvent_t> event_pool;
+    double phase_ms[SGL_PH_COUNT] = {0};
+    int64_t phase_calls[SGL_PH_COUNT] = {0};
+};
+
+// RAII-free phase timer helpers (driver side).
+int sgl_phase_begin(sgl_ctx* c, int phase, PhaseEvent* pe);
+int sgl_phase_end(sgl_ctx* c, PhaseEvent* pe);
+int sgl_ws_reserve(sgl_ctx* c, size_t bytes);
+
+// ---- kernel launchers (each enqueues on `s`, returns SGL_* code) ----------
+// hash / synthetic generator / mask
+int k_rand(hipStream_t s, uint64_t state, const uint64_t* i, const uint64_t* j, int64_t n, uint64_t* out);
+int k_mask(hipStream_t s, uint64_t state, uint64_t inv_density, int64_t cell0, int32_t ncells, int32_t ngenes, uint8_t* out);
+// counts per column of the synthetic matrix.  transposed = 0: column = cell
+// (rows = genes); 1: column = gene (rows = local cells).
+int k_synth_count(hipStream_t s, uint64_t S, uint64_t inv_density, int transposed, int64_t cell_offset,
+                  int32_t ncells, int32_t ngenes, int64_t* counts);
+int k_synth_fill(hipStream_t s, uint64_t S, uint64_t inv_density, const double* levels16_dev, int transposed,
+                 int64_t cell_offset, int32_t ncells, int32_t ngenes, const int64_t* p, int32_t* idx, double* x);
+int k_synth_winit(hipStream_t s, uint64_t S, int k, int32_t ngenes, double* W);
+int k_exclusive_scan(sgl_ctx* c, const int64_t* in, int64_t* out, int64_t n);  // out has n+1 entries
+int k_scan_total(hipStream_t s, const int64_t* in, int64_t* out, int64_t n);
+int k_col_counts(hipStream_t s, const int64_t* p, int64_t ncol, int64_t* counts);
+int k_widen_p(hipStream_t s, const int32_t* p32, int64_t n1, int64_t* p64);
+int k_build_segments(hipStream_t s, const DevCSC& M);
+
+// dense helpers
+int k_gram(sgl_ctx* c, const double* F, int k, int64_t cols, double* G, double diag_add);
+int k_gram_add_diag(hipStream_t s, double* G, int k, double v);
+int k_rowsum(sgl_ctx* c, const double* F, int k, int64_t cols, double* d_out);  // no +1e-15
+int k_scale_apply(hipStream_t s, double* F, int k, int64_t cols, double* d, int add_eps);
+int k_cor(sgl_ctx* c, const double* x, const double* y, int64_t n, double* out_dev);
+int k_pad_gram(hipStream_t s, const double* G, int k, int KP, double* Gpad);
+int k_transpose_dense(hipStream_t s, const double* in, int rows, int cols, double* out);
+
+// sparse accumulate: B[:, c] (+)= sum_{nz in tile t of column c} x * F[:, row]
+int k_acc(hipStream_t s, const DevCSC& M, const double* F, int k, double* B,
+          uint64_t mask_seed, uint64_t inv_density, int mask_mode, int64_t mask_col_offset, int64_t mask_row_offset);
+
+// NNLS
+int k_nnls_lane(hipStream_t s, const double* Gpad, int KP, const double* B, double* X, const int64_t* col_nnz,
+                int k, int64_t ncols, double L1, double L2, int* sweep_counter);
+int k_nnls_wave(hipStream_t s, const double* G, int64_t gstride, const double* B, double* X, const int64_t* col_nnz,
+                int k, int64_t ncols, double L1, double L2, int* sweep_counter);
+
+// masked path
+int k_mask_gram_cols(hipStream_t s, int64_t col0, int64_t ncols, int32_t nrow, const int64_t* col_nnz,
+                     const double* F, const double* G, int k, uint64_t seed, uint64_t inv_density, int mask_t,
+                     int64_t col_offset, int64_t row_offset, double* Gcols);
+int k_mse_test(sgl_ctx* c, const double* Wd, const double* H, int k, uint64_t seed, uint64_t inv_density,
+               double* out_dev);
+int k_wd(hipStream_t s, const double* W, const double* d, int k, int64_t cols, double* Wd);
+
+// ---- device-side hash (rng::rand, src/singlet.cpp:30-64) ------------------
+__device__ __forceinline__ uint64_t sgl_rand2(uint64_t state, uint64_t i, uint64_t j) {
+    i ^= i << 19;
+    i ^= i >> 7;
+    i ^= i << 36;
+    uint64_t x = state + i;
+    x ^= x << 38;
+    x ^= x >> 13;
+    x ^= x << 23;
+    j ^= j >> 7;
+    j ^= j << 23;
+    j ^= j >> 8;
+    x += j;
+    x ^= x >> 7;
+    x ^= x << 53;
+    x ^= x >> 4;
+    return x;
+}
+// the i-only half of the hash, hoistable out of loops over j
+__device__ __forceinline__ uint64_t sgl_rand_i(uint64_t state, uint64_t i) {
+    i ^= i << 19;
+    i ^= i >> 7;
+    i ^= i << 36;
+    uint64_t x = state + i;
+    x ^= x << 38;
+    x ^= x >> 13;
+    x ^= x << 23;
+    return x;
+}
+__device__ __forceinline__ uint64_t sgl_rand_j(uint64_t xi, uint64_t j) {
+    j ^= j >> 7;
+    j ^= j << 23;
+    j ^= j >> 8;
+    uint64_t x = xi + j;
+    x ^= x >> 7;
+    x ^= x << 53;
+    x ^= x >> 4;
+    return x;
+}
+__device__ __forceinline__ bool sgl_draw(uint64_t state, uint64_t i, uint64_t j, uint64_t inv_density) {
+    return (sgl_rand2(state, i, j) % inv_density) == 0;
+}

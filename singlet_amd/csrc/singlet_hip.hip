@@ -1,0 +1,922 @@
+// C ABI of libsinglet_hip.so (include/singlet_hip.h): context management, the
+// ALS loops c_nmf_base / c_ard_nmf_base / c_project_model (src/singlet.cpp:
+// 638-666, 1090-1152, 405-413) driven from the host over the HIP kernels of
+// this directory.  No CPU compute path exists here: without a gfx950 device
+// every entry point returns SGL_ENODEV.
+#include "sgl_internal.h"
+
+#include <math.h>
+#include <string.h>
+#include <algorithm>
+#include <string>
+
+// ------------------------------------------------------------------ errors --
+static thread_local char g_err[1024] = "";
+
+void sgl_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* sgl_last_error(void) { return g_err; }
+extern "C" int sgl_abi_version(void) { return 1; }
+
+static bool device_is_gfx950(int dev) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
+    return strncmp(prop.gcnArchName, "gfx950", 6) == 0;
+}
+
+extern "C" int sgl_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    int ok = 0;
+    for (int d = 0; d < n; ++d) ok += device_is_gfx950(d) ? 1 : 0;
+    return ok;
+}
+
+// ------------------------------------------------------------- ctx helpers --
+template <typename T>
+static int dev_alloc(T** p, size_t count) {
+    *p = nullptr;
+    if (count == 0) count = 1;
+    hipError_t e = hipMalloc((void**)p, count * sizeof(T));
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        sgl_set_error("hipMalloc of %zu bytes failed: %s", count * sizeof(T), hipGetErrorString(e));
+        return SGL_ENOMEM;
+    }
+    return SGL_OK;
+}
+
+template <typename T>
+static void dev_free(T*& p) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+int sgl_ws_reserve(sgl_ctx* c, size_t bytes) {
+    if (bytes <= c->ws_bytes) return SGL_OK;
+    // grow; callers never hold ws contents across a reserve
+    HIPCHK(hipStreamSynchronize(c->stream));
+    dev_free(c->ws);
+    size_t want = std::max(bytes, (size_t)1 << 20);
+    want = (want + 255) & ~(size_t)255;
+    char* p = nullptr;
+    SGLCHK(dev_alloc(&p, want));
+    c->ws = reinterpret_cast<double*>(p);
+    c->ws_bytes = want;
+    return SGL_OK;
+}
+
+static hipEvent_t take_event(sgl_ctx* c) {
+    if (!c->event_pool.empty()) {
+        hipEvent_t e = c->event_pool.back();
+        c->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+int sgl_phase_begin(sgl_ctx* c, int phase, PhaseEvent* pe) {
+    pe->phase = phase;
+    pe->e0 = pe->e1 = nullptr;
+    if (!c->timing) return SGL_OK;
+    pe->e0 = take_event(c);
+    pe->e1 = take_event(c);
+    HIPCHK(hipEventRecord(pe->e0, c->stream));
+    return SGL_OK;
+}
+
+int sgl_phase_end(sgl_ctx* c, PhaseEvent* pe) {
+    if (!c->timing || pe->e0 == nullptr) return SGL_OK;
+    HIPCHK(hipEventRecord(pe->e1, c->stream));
+    c->pending.push_back(*pe);
+    return SGL_OK;
+}
+
+static int drain_timing(sgl_ctx* c) {
+    if (c->pending.empty()) return SGL_OK;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (auto& pe : c->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, pe.e0, pe.e1) == hipSuccess) {
+            c->phase_ms[pe.phase] += (double)ms;
+            c->phase_calls[pe.phase] += 1;
+        } else {
+            (void)hipGetLastError();
+        }
+        c->event_pool.push_back(pe.e0);
+        c->event_pool.push_back(pe.e1);
+    }
+    c->pending.clear();
+    return SGL_OK;
+}
+
+struct Phase {  // scope guard
+    sgl_ctx* c;
+    PhaseEvent pe;
+    Phase(sgl_ctx* c_, int phase) : c(c_) { (void)sgl_phase_begin(c, phase, &pe); }
+    ~Phase() { (void)sgl_phase_end(c, &pe); }
+};
+
+static void free_csc(DevCSC& M) {
+    dev_free(M.x);
+    dev_free(M.i);
+    dev_free(M.p);
+    dev_free(M.seg);
+    M = DevCSC();
+}
+
+static void free_fit(sgl_ctx* c) {
+    dev_free(c->W);
+    dev_free(c->Wprev);
+    dev_free(c->H);
+    dev_free(c->d);
+    dev_free(c->B);
+    dev_free(c->red);
+    dev_free(c->G);
+    dev_free(c->Gpad);
+    dev_free(c->A.seg);
+    dev_free(c->At.seg);
+    c->k = 0;
+}
+
+static void free_matrix(sgl_ctx* c) {
+    free_csc(c->A);
+    free_csc(c->At);
+    dev_free(c->col_nnz_A);
+    dev_free(c->col_nnz_At);
+    c->gene_nnz_global = false;
+}
+
+#define CTX_GUARD(c)                                                 \
+    do {                                                             \
+        if ((c) == nullptr) { sgl_set_error("null context"); return SGL_EINVAL; } \
+        HIPCHK(hipSetDevice((c)->device));                           \
+    } while (0)
+
+// ----------------------------------------------------------------- create ---
+extern "C" int sgl_create(int device, sgl_ctx** out) {
+    if (out == nullptr) { sgl_set_error("sgl_create: out is NULL"); return SGL_EINVAL; }
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        sgl_set_error("no HIP device available: libsinglet_hip has no CPU path");
+        return SGL_ENODEV;
+    }
+    if (device < 0 || device >= n) { sgl_set_error("device %d out of range (have %d)", device, n); return SGL_EINVAL; }
+    if (!device_is_gfx950(device)) {
+        sgl_set_error("device %d is not gfx950 (MI355X); this library is built for gfx950 only", device);
+        return SGL_ENODEV;
+    }
+    HIPCHK(hipSetDevice(device));
+    sgl_ctx* c = new (std::nothrow) sgl_ctx();
+    if (!c) { sgl_set_error("out of host memory"); return SGL_ENOMEM; }
+    c->device = device;
+    HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    int rc = dev_alloc(&c->scalars, 16);
+    if (rc == SGL_OK) rc = dev_alloc(&c->sweep_counters, 4);
+    if (rc != SGL_OK) { sgl_destroy(c); return rc; }
+    HIPCHK(hipMemsetAsync(c->sweep_counters, 0, 4 * sizeof(int), c->stream));
+    HIPCHK(hipHostMalloc((void**)&c->pinned, 16 * sizeof(double), hipHostMallocDefault));
+    *out = c;
+    return SGL_OK;
+}
+
+extern "C" int sgl_destroy(sgl_ctx* c) {
+    if (!c) return SGL_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    (void)drain_timing(c);
+    for (auto e : c->event_pool) (void)hipEventDestroy(e);
+    free_fit(c);
+    free_matrix(c);
+    dev_free(c->ws);
+    dev_free(c->scalars);
+    dev_free(c->sweep_counters);
+    if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return SGL_OK;
+}
+
+extern "C" int sgl_set_stream(sgl_ctx* c, void* hip_stream) {
+    CTX_GUARD(c);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    SGLCHK(drain_timing(c));
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return SGL_OK;
+}
+
+extern "C" int sgl_set_allreduce(sgl_ctx* c, sgl_allreduce_fn fn, void* user) {
+    CTX_GUARD(c);
+    c->allreduce = fn;
+    c->allreduce_user = user;
+    return SGL_OK;
+}
+
+static int do_allreduce(sgl_ctx* c, double* dev_ptr, int64_t count) {
+    if (!c->allreduce) return SGL_OK;
+    Phase ph(c, SGL_PH_COMM);
+    const int rc = c->allreduce(c->allreduce_user, dev_ptr, count);
+    if (rc != 0) { sgl_set_error("all-reduce callback failed with code %d", rc); return SGL_ECOMM; }
+    return SGL_OK;
+}
+
+// ----------------------------------------------------------------- upload ---
+static int upload_one(sgl_ctx* c, DevCSC& M, const double* x, const int32_t* i, const int32_t* p, int32_t nrow,
+                      int32_t ncol) {
+    const int64_t nnz = (int64_t)p[ncol];
+    if (p[0] != 0 || nnz < 0) { sgl_set_error("invalid column pointer array (p[0]=%d, p[ncol]=%lld)", p[0], (long long)nnz); return SGL_EINVAL; }
+    M.nrow = nrow;
+    M.ncol = ncol;
+    M.nnz = nnz;
+    SGLCHK(dev_alloc(&M.x, (size_t)nnz));
+    SGLCHK(dev_alloc(&M.i, (size_t)nnz));
+    SGLCHK(dev_alloc(&M.p, (size_t)ncol + 1));
+    HIPCHK(hipMemcpyAsync(M.x, x, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(M.i, i, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice, c->stream));
+    int32_t* p32 = nullptr;
+    SGLCHK(dev_alloc(&p32, (size_t)ncol + 1));
+    HIPCHK(hipMemcpyAsync(p32, p, sizeof(int32_t) * ((size_t)ncol + 1), hipMemcpyHostToDevice, c->stream));
+    int rc = k_widen_p(c->stream, p32, (int64_t)ncol + 1, M.p);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    dev_free(p32);
+    return rc;
+}
+
+static int finish_matrix(sgl_ctx* c) {
+    SGLCHK(dev_alloc(&c->col_nnz_A, (size_t)c->A.ncol));
+    SGLCHK(dev_alloc(&c->col_nnz_At, (size_t)c->At.ncol));
+    SGLCHK(k_col_counts(c->stream, c->A.p, c->A.ncol, c->col_nnz_A));
+    SGLCHK(k_col_counts(c->stream, c->At.p, c->At.ncol, c->col_nnz_At));
+    c->gene_nnz_global = false;
+    return SGL_OK;
+}
+
+int sgl_device_transpose(sgl_ctx* c);  // kernels_transpose.hip
+
+extern "C" int sgl_upload_csc(sgl_ctx* c, const double* Ax, const int32_t* Ai, const int32_t* Ap, const double* Atx,
+                              const int32_t* Ati, const int32_t* Atp, int32_t nrow, int32_t ncol, int64_t cell_offset,
+                              int64_t ncells_total) {
+    CTX_GUARD(c);
+    if (!Ax || !Ai || !Ap || nrow <= 0 || ncol <= 0) { sgl_set_error("sgl_upload_csc: missing slot or empty matrix"); return SGL_EINVAL; }
+    if ((Atx || Ati || Atp) && !(Atx && Ati && Atp)) { sgl_set_error("sgl_upload_csc: At must be fully given or fully NULL"); return SGL_EINVAL; }
+    free_fit(c);
+    free_matrix(c);
+    c->cell_offset = cell_offset;
+    c->ncells_total = ncells_total > 0 ? ncells_total : ncol;
+    SGLCHK(upload_one(c, c->A, Ax, Ai, Ap, nrow, ncol));
+    if (Atx) {
+        if ((int64_t)Atp[nrow] != c->A.nnz) { sgl_set_error("At has %d non-zeros, A has %lld", Atp[nrow], (long long)c->A.nnz); return SGL_EINVAL; }
+        SGLCHK(upload_one(c, c->At, Atx, Ati, Atp, ncol, nrow));
+    } else {
+        SGLCHK(sgl_device_transpose(c));
+    }
+    return finish_matrix(c);
+}
+
+// A only (c_project_model never walks At): At becomes an empty nrow-column matrix.
+static int sgl_upload_csc_A_only(sgl_ctx* c, const double* Ax, const int32_t* Ai, const int32_t* Ap, int32_t nrow,
+                                 int32_t ncol) {
+    CTX_GUARD(c);
+    if (!Ax || !Ai || !Ap || nrow <= 0 || ncol <= 0) { sgl_set_error("missing slot or empty matrix"); return SGL_EINVAL; }
+    free_fit(c);
+    free_matrix(c);
+    c->cell_offset = 0;
+    c->ncells_total = ncol;
+    SGLCHK(upload_one(c, c->A, Ax, Ai, Ap, nrow, ncol));
+    DevCSC& T = c->At;
+    T.nrow = ncol; T.ncol = nrow; T.nnz = 0;
+    SGLCHK(dev_alloc(&T.x, 1));
+    SGLCHK(dev_alloc(&T.i, 1));
+    SGLCHK(dev_alloc(&T.p, (size_t)nrow + 1));
+    HIPCHK(hipMemsetAsync(T.p, 0, sizeof(int64_t) * ((size_t)nrow + 1), c->stream));
+    return finish_matrix(c);
+}
+
+extern "C" int sgl_synth_csc(sgl_ctx* c, uint64_t S, uint64_t inv_density, const double* levels16, int32_t ngenes,
+                             int64_t cell_offset, int32_t ncells_local, int64_t ncells_total) {
+    CTX_GUARD(c);
+    if (!levels16 || ngenes <= 0 || ncells_local <= 0 || inv_density == 0) { sgl_set_error("sgl_synth_csc: bad arguments"); return SGL_EINVAL; }
+    free_fit(c);
+    free_matrix(c);
+    c->cell_offset = cell_offset;
+    c->ncells_total = ncells_total > 0 ? ncells_total : ncells_local;
+    double* lv = nullptr;
+    SGLCHK(dev_alloc(&lv, 16));
+    HIPCHK(hipMemcpyAsync(lv, levels16, 16 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    for (int tr = 0; tr < 2; ++tr) {
+        DevCSC& M = tr ? c->At : c->A;
+        M.nrow = tr ? ncells_local : ngenes;
+        M.ncol = tr ? ngenes : ncells_local;
+        int64_t* counts = nullptr;
+        SGLCHK(dev_alloc(&counts, (size_t)M.ncol));
+        SGLCHK(dev_alloc(&M.p, (size_t)M.ncol + 1));
+        SGLCHK(k_synth_count(c->stream, S, inv_density, tr, cell_offset, ncells_local, ngenes, counts));
+        SGLCHK(k_exclusive_scan(c, counts, M.p, M.ncol));
+        SGLCHK(k_scan_total(c->stream, counts, M.p, M.ncol));
+        int64_t nnz = 0;
+        HIPCHK(hipMemcpyAsync(&nnz, M.p + M.ncol, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        dev_free(counts);
+        M.nnz = nnz;
+        SGLCHK(dev_alloc(&M.x, (size_t)nnz));
+        SGLCHK(dev_alloc(&M.i, (size_t)nnz));
+        SGLCHK(k_synth_fill(c->stream, S, inv_density, lv, tr, cell_offset, ncells_local, ngenes, M.p, M.i, M.x));
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    dev_free(lv);
+    if (c->A.nnz != c->At.nnz) { sgl_set_error("synthetic generator: orientations disagree (%lld vs %lld)", (long long)c->A.nnz, (long long)c->At.nnz); return SGL_EHIP; }
+    return finish_matrix(c);
+}
+
+extern "C" int sgl_dims(const sgl_ctx* c, int32_t* nrow, int32_t* ncol, int64_t* nnz) {
+    if (!c) { sgl_set_error("null context"); return SGL_EINVAL; }
+    if (nrow) *nrow = c->A.nrow;
+    if (ncol) *ncol = c->A.ncol;
+    if (nnz) *nnz = c->A.nnz;
+    return SGL_OK;
+}
+
+extern "C" int sgl_download_csc(sgl_ctx* c, int which, double* x, int32_t* i, int64_t* p) {
+    CTX_GUARD(c);
+    const DevCSC& M = which ? c->At : c->A;
+    if (!M.p) { sgl_set_error("no matrix resident"); return SGL_ESTATE; }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (x) HIPCHK(hipMemcpy(x, M.x, sizeof(double) * (size_t)M.nnz, hipMemcpyDeviceToHost));
+    if (i) HIPCHK(hipMemcpy(i, M.i, sizeof(int32_t) * (size_t)M.nnz, hipMemcpyDeviceToHost));
+    if (p) HIPCHK(hipMemcpy(p, M.p, sizeof(int64_t) * ((size_t)M.ncol + 1), hipMemcpyDeviceToHost));
+    return SGL_OK;
+}
+
+// ------------------------------------------------------------------- fit ----
+static int pick_tile_rows(int k, int64_t nrow) {
+    // slice of the operand factor per tile ~3 MiB: fits one XCD's 4 MiB L2 next to the streamed non-zeros
+    int64_t rows = (3ll << 20) / ((int64_t)k * 8);
+    rows = std::max<int64_t>(256, rows / 256 * 256);
+    if (rows > nrow) rows = nrow;
+    return (int)rows;
+}
+
+static int build_tiles(sgl_ctx* c, DevCSC& M, int k) {
+    dev_free(M.seg);
+    M.tile_rows = pick_tile_rows(k, M.nrow);
+    M.ntiles = (int)((M.nrow + M.tile_rows - 1) / M.tile_rows);
+    SGLCHK(dev_alloc(&M.seg, (size_t)(M.ntiles + 1) * (size_t)M.ncol));
+    return k_build_segments(c->stream, M);
+}
+
+static int lane_kp(int k) { return (k + 3) / 4 * 4; }
+
+extern "C" int sgl_fit_init(sgl_ctx* c, int32_t k, const double* w_init, uint64_t synth_seed) {
+    CTX_GUARD(c);
+    if (!c->A.p || !c->At.p) { sgl_set_error("sgl_fit_init: no matrix resident"); return SGL_ESTATE; }
+    if (k <= 0 || k > SGL_MAX_K) { sgl_set_error("rank k=%d unsupported (1..%d)", k, SGL_MAX_K); return SGL_EINVAL; }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    free_fit(c);
+    const int64_t m = c->A.nrow, n = c->A.ncol;
+    c->k = k;
+    SGLCHK(dev_alloc(&c->W, (size_t)k * m));
+    SGLCHK(dev_alloc(&c->Wprev, (size_t)k * m));
+    SGLCHK(dev_alloc(&c->H, (size_t)k * n));
+    SGLCHK(dev_alloc(&c->d, (size_t)k));
+    SGLCHK(dev_alloc(&c->B, (size_t)k * n));
+    SGLCHK(dev_alloc(&c->red, (size_t)k * m + (size_t)k * k + (size_t)k));
+    SGLCHK(dev_alloc(&c->G, (size_t)k * k));
+    const int KP = lane_kp(k);
+    SGLCHK(dev_alloc(&c->Gpad, (size_t)KP * KP));
+    if (w_init) HIPCHK(hipMemcpyAsync(c->W, w_init, sizeof(double) * (size_t)k * m, hipMemcpyHostToDevice, c->stream));
+    else SGLCHK(k_synth_winit(c->stream, synth_seed, k, (int32_t)m, c->W));
+    HIPCHK(hipMemsetAsync(c->H, 0, sizeof(double) * (size_t)k * n, c->stream));
+    std::vector<double> ones((size_t)k, 1.0);
+    HIPCHK(hipMemcpyAsync(c->d, ones.data(), sizeof(double) * k, hipMemcpyHostToDevice, c->stream));
+    SGLCHK(build_tiles(c, c->A, k));
+    SGLCHK(build_tiles(c, c->At, k));
+    // global per-gene non-zero counts decide which W columns predict() skips (l.340)
+    if (c->allreduce && !c->gene_nnz_global) {
+        double* tmp = nullptr;  // counts as doubles through the f64 all-reduce hook (exact below 2^53)
+        SGLCHK(dev_alloc(&tmp, (size_t)m));
+        std::vector<int64_t> hc((size_t)m);
+        HIPCHK(hipMemcpyAsync(hc.data(), c->col_nnz_At, sizeof(int64_t) * m, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        std::vector<double> hd((size_t)m);
+        for (int64_t g = 0; g < m; ++g) hd[g] = (double)hc[g];
+        HIPCHK(hipMemcpyAsync(tmp, hd.data(), sizeof(double) * m, hipMemcpyHostToDevice, c->stream));
+        int rc = do_allreduce(c, tmp, m);
+        if (rc == SGL_OK) {
+            HIPCHK(hipMemcpyAsync(hd.data(), tmp, sizeof(double) * m, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            for (int64_t g = 0; g < m; ++g) hc[g] = (int64_t)hd[g];
+            HIPCHK(hipMemcpyAsync(c->col_nnz_At, hc.data(), sizeof(int64_t) * m, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            c->gene_nnz_global = true;
+        }
+        dev_free(tmp);
+        SGLCHK(rc);
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SGL_OK;
+}
+
+#define FIT_GUARD(c)                                                            \
+    do {                                                                        \
+        CTX_GUARD(c);                                                           \
+        if ((c)->k == 0) { sgl_set_error("no fit initialised (call sgl_fit_init)"); return SGL_ESTATE; } \
+    } while (0)
+
+// NNLS dispatch for a Gram shared by all columns.
+static int nnls_shared(sgl_ctx* c, const double* G, const double* B, double* X, const int64_t* col_nnz, int64_t ncols,
+                       double L1, double L2, int* counter) {
+    const int k = c->k;
+    if (k <= SGL_LANE_NNLS_MAX_K) {
+        const int KP = lane_kp(k);
+        SGLCHK(k_pad_gram(c->stream, G, k, KP, c->Gpad));
+        return k_nnls_lane(c->stream, c->Gpad, KP, B, X, col_nnz, k, ncols, L1, L2, counter);
+    }
+    return k_nnls_wave(c->stream, G, 0, B, X, col_nnz, k, ncols, L1, L2, counter);
+}
+
+extern "C" int sgl_step_begin(sgl_ctx* c) {
+    FIT_GUARD(c);
+    Phase ph(c, SGL_PH_SCALE);
+    HIPCHK(hipMemcpyAsync(c->Wprev, c->W, sizeof(double) * (size_t)c->k * c->A.nrow, hipMemcpyDeviceToDevice, c->stream));
+    return SGL_OK;
+}
+
+// predict(A, w, h, L1, L2): src/singlet.cpp:333-347
+extern "C" int sgl_step_h(sgl_ctx* c, double L1, double L2) {
+    FIT_GUARD(c);
+    const int k = c->k;
+    { Phase ph(c, SGL_PH_GRAM); SGLCHK(k_gram(c, c->W, k, c->A.nrow, c->G, 1e-15)); }
+    { Phase ph(c, SGL_PH_RHS_H); SGLCHK(k_acc(c->stream, c->A, c->W, k, c->B, 0, 1, 0, 0, 0)); }
+    { Phase ph(c, SGL_PH_NNLS_H);
+      SGLCHK(nnls_shared(c, c->G, c->B, c->H, c->col_nnz_A, c->A.ncol, L1, L2, c->sweep_counters + 0)); }
+    return SGL_OK;
+}
+
+// scale(h, d): src/singlet.cpp:219-225; row sums are global over all shards
+extern "C" int sgl_step_scale_h(sgl_ctx* c) {
+    FIT_GUARD(c);
+    { Phase ph(c, SGL_PH_SCALE); SGLCHK(k_rowsum(c, c->H, c->k, c->A.ncol, c->d)); }
+    SGLCHK(do_allreduce(c, c->d, c->k));
+    { Phase ph(c, SGL_PH_SCALE); SGLCHK(k_scale_apply(c->stream, c->H, c->k, c->A.ncol, c->d, 1)); }
+    return SGL_OK;
+}
+
+// predict(At, h, w, L1, L2): right-hand sides and Gram are sums over cells ->
+// one all-reduce of [k*m | k*k] doubles when sharded.
+extern "C" int sgl_step_w(sgl_ctx* c, double L1, double L2) {
+    FIT_GUARD(c);
+    const int k = c->k;
+    const int64_t m = c->A.nrow;
+    double* Bw = c->red;
+    double* Gh = c->red + (size_t)k * m;
+    { Phase ph(c, SGL_PH_RHS_W); SGLCHK(k_acc(c->stream, c->At, c->H, k, Bw, 0, 1, 0, 0, 0)); }
+    { Phase ph(c, SGL_PH_GRAM); SGLCHK(k_gram(c, c->H, k, c->A.ncol, Gh, 0.0)); }
+    SGLCHK(do_allreduce(c, c->red, (int64_t)k * m + (int64_t)k * k));
+    { Phase ph(c, SGL_PH_GRAM);
+      // G = Gh + 1e-15 I (AAt, src/singlet.cpp:204) -- reuse the scale kernel family: tiny
+      HIPCHK(hipMemcpyAsync(c->G, Gh, sizeof(double) * k * k, hipMemcpyDeviceToDevice, c->stream));
+      SGLCHK(k_gram_add_diag(c->stream, c->G, k, 1e-15)); }
+    { Phase ph(c, SGL_PH_NNLS_W);
+      SGLCHK(nnls_shared(c, c->G, Bw, c->W, c->col_nnz_At, m, L1, L2, c->sweep_counters + 1)); }
+    return SGL_OK;
+}
+
+// scale(w, d); tol = cor(w, w_it): src/singlet.cpp:655-659
+extern "C" int sgl_step_scale_w(sgl_ctx* c, double* tol_out) {
+    FIT_GUARD(c);
+    const int k = c->k;
+    const int64_t m = c->A.nrow;
+    {
+        Phase ph(c, SGL_PH_SCALE);
+        SGLCHK(k_rowsum(c, c->W, k, m, c->d));
+        SGLCHK(k_scale_apply(c->stream, c->W, k, m, c->d, 1));
+        SGLCHK(k_cor(c, c->W, c->Wprev, (int64_t)k * m, c->scalars));
+    }
+    HIPCHK(hipMemcpyAsync(c->pinned, c->scalars, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (tol_out) *tol_out = c->pinned[0];
+    return SGL_OK;
+}
+
+static int fetch_sweeps(sgl_ctx* c) {
+    int h[4] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpyAsync(h, c->sweep_counters, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemsetAsync(c->sweep_counters, 0, sizeof(h), c->stream));
+    c->sweeps_acc[0] += h[0];
+    c->sweeps_acc[1] += h[1];
+    return SGL_OK;
+}
+
+extern "C" int sgl_nmf_run(sgl_ctx* c, double tol, int32_t maxit, double L1_w, double L1_h, double L2_w, double L2_h,
+                           int32_t* n_iter, double* tol_trace, const sgl_callbacks* cb) {
+    FIT_GUARD(c);
+    double tol_ = 1.0;
+    int it = 0;
+    // for (iter_ = 0; iter_ < maxit && tol_ > tol; ++iter_)  -- src/singlet.cpp:647
+    for (; it < maxit && tol_ > tol; ++it) {
+        SGLCHK(sgl_step_begin(c));
+        SGLCHK(sgl_step_h(c, L1_h, L2_h));
+        SGLCHK(sgl_step_scale_h(c));
+        if (cb && cb->poll && cb->poll(cb->user)) { sgl_set_error("interrupted"); return SGL_EINTR; }
+        SGLCHK(sgl_step_w(c, L1_w, L2_w));
+        SGLCHK(sgl_step_scale_w(c, &tol_));
+        c->sweeps_acc[2] += c->A.ncol;
+        c->sweeps_acc[3] += c->A.nrow;
+        if (tol_trace) tol_trace[it] = tol_;
+        if (cb && cb->log) cb->log(cb->user, it + 1, tol_, NAN);
+        if (cb && cb->poll && cb->poll(cb->user)) { sgl_set_error("interrupted"); return SGL_EINTR; }
+    }
+    SGLCHK(fetch_sweeps(c));
+    if (n_iter) *n_iter = it;
+    return SGL_OK;
+}
+
+// One H-update against the resident (already scaled) W: body of c_project_model l.409-411
+extern "C" int sgl_project_run(sgl_ctx* c, double L1, double L2) {
+    FIT_GUARD(c);
+    HIPCHK(hipMemsetAsync(c->H, 0, sizeof(double) * (size_t)c->k * c->A.ncol, c->stream));
+    SGLCHK(sgl_step_h(c, L1, L2));
+    SGLCHK(sgl_step_scale_h(c));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SGL_OK;
+}
+
+extern "C" int sgl_get_factors(sgl_ctx* c, double* w, double* d, double* h) {
+    FIT_GUARD(c);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (w) HIPCHK(hipMemcpy(w, c->W, sizeof(double) * (size_t)c->k * c->A.nrow, hipMemcpyDeviceToHost));
+    if (d) HIPCHK(hipMemcpy(d, c->d, sizeof(double) * (size_t)c->k, hipMemcpyDeviceToHost));
+    if (h) HIPCHK(hipMemcpy(h, c->H, sizeof(double) * (size_t)c->k * c->A.ncol, hipMemcpyDeviceToHost));
+    return SGL_OK;
+}
+
+extern "C" int sgl_set_factors(sgl_ctx* c, const double* w, const double* d, const double* h) {
+    FIT_GUARD(c);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (w) HIPCHK(hipMemcpy(c->W, w, sizeof(double) * (size_t)c->k * c->A.nrow, hipMemcpyHostToDevice));
+    if (d) HIPCHK(hipMemcpy(c->d, d, sizeof(double) * (size_t)c->k, hipMemcpyHostToDevice));
+    if (h) HIPCHK(hipMemcpy(c->H, h, sizeof(double) * (size_t)c->k * c->A.ncol, hipMemcpyHostToDevice));
+    return SGL_OK;
+}
+
+// ------------------------------------------------------------- masked path --
+// predict_mask (src/singlet.cpp:436-466) for one orientation, columns in
+// chunks so the per-column Grams a_i (k*k doubles each) stay bounded.
+static int predict_mask_dev(sgl_ctx* c, const DevCSC& M, const int64_t* col_nnz, const double* F, double* X,
+                            double* Bbuf, uint64_t seed, uint64_t inv_density, double L1, double L2, int mask_t,
+                            int rhs_phase, int nnls_phase, int* counter) {
+    const int k = c->k;
+    // hash argument order: A pass draw(cell = col + cell_offset, gene = row); At pass draw(cell = row + cell_offset, gene = col)
+    const int64_t col_off = mask_t ? 0 : c->cell_offset;
+    const int64_t row_off = mask_t ? c->cell_offset : 0;
+    { Phase ph(c, SGL_PH_GRAM); SGLCHK(k_gram(c, F, k, M.nrow, c->G, 1e-15)); }
+    { Phase ph(c, rhs_phase);
+      SGLCHK(k_acc(c->stream, M, F, k, Bbuf, seed, inv_density, mask_t ? 2 : 1, col_off, row_off)); }
+    const int64_t chunk = std::max<int64_t>(256, std::min<int64_t>(M.ncol, ((int64_t)256 << 20) / ((int64_t)k * k * 8)));
+    double* Gcols = nullptr;
+    SGLCHK(dev_alloc(&Gcols, (size_t)chunk * k * k));
+    int rc = SGL_OK;
+    for (int64_t c0 = 0; c0 < M.ncol && rc == SGL_OK; c0 += chunk) {
+        const int64_t nc = std::min<int64_t>(chunk, M.ncol - c0);
+        { Phase ph(c, SGL_PH_MASK);
+          rc = k_mask_gram_cols(c->stream, c0, nc, M.nrow, col_nnz, F, c->G, k, seed, inv_density, mask_t, col_off, row_off, Gcols); }
+        if (rc != SGL_OK) break;
+        { Phase ph(c, nnls_phase);
+          rc = k_nnls_wave(c->stream, Gcols, (int64_t)k * k, Bbuf + (size_t)c0 * k, X + (size_t)c0 * k,
+                           col_nnz ? col_nnz + c0 : nullptr, k, nc, L1, L2, counter); }
+    }
+    hipError_t e = hipStreamSynchronize(c->stream);
+    dev_free(Gcols);
+    if (rc == SGL_OK && e != hipSuccess) { sgl_set_error("masked predict failed: %s", hipGetErrorString(e)); rc = SGL_EHIP; }
+    return rc;
+}
+
+static int mse_test_dev(sgl_ctx* c, uint64_t seed, uint64_t inv_density, double* out) {
+    const int k = c->k;
+    const int64_t m = c->A.nrow;
+    double* Wd = nullptr;
+    SGLCHK(dev_alloc(&Wd, (size_t)k * m));
+    int rc;
+    {
+        Phase ph(c, SGL_PH_MASK);
+        rc = k_wd(c->stream, c->W, c->d, k, m, Wd);
+        if (rc == SGL_OK) rc = k_mse_test(c, Wd, c->H, k, seed, inv_density, c->scalars + 1);
+    }
+    if (rc == SGL_OK) rc = do_allreduce(c, c->scalars + 1, 1);
+    if (rc == SGL_OK) {
+        hipError_t e = hipMemcpyAsync(c->pinned + 1, c->scalars + 1, sizeof(double), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { sgl_set_error("mse_test copy failed: %s", hipGetErrorString(e)); rc = SGL_EHIP; }
+    } else {
+        (void)hipStreamSynchronize(c->stream);
+    }
+    dev_free(Wd);
+    if (rc == SGL_OK) *out = c->pinned[1] / (double)c->ncells_total;  // losses.sum() / h.cols(), l.567
+    return rc;
+}
+
+extern "C" int sgl_op_mse_test(sgl_ctx* c, uint64_t seed, uint64_t inv_density, double* out) {
+    FIT_GUARD(c);
+    if (!out || inv_density == 0) { sgl_set_error("sgl_op_mse_test: bad arguments"); return SGL_EINVAL; }
+    return mse_test_dev(c, seed, inv_density, out);
+}
+
+// c_ard_nmf_base: src/singlet.cpp:1090-1152
+extern "C" int sgl_ard_run(sgl_ctx* c, double tol, int32_t maxit, double L1, double L2, uint64_t seed,
+                           uint64_t inv_density, double overfit_threshold, int32_t trace_test_mse, double* test_mse,
+                           int32_t* iter, double* tol_out, double* score_overfit, int32_t* n_trace, int32_t* n_iter,
+                           const sgl_callbacks* cb) {
+    FIT_GUARD(c);
+    if (c->allreduce) { sgl_set_error("the masked (ARD) path is not cell-sharded yet; run it on one shard"); return SGL_EINVAL; }
+    if (trace_test_mse <= 0 || inv_density == 0 || !test_mse || !iter || !tol_out || !score_overfit || !n_trace) {
+        sgl_set_error("sgl_ard_run: bad arguments"); return SGL_EINVAL;
+    }
+    const int k = c->k;
+    const int64_t m = c->A.nrow;
+    double tol_ = 1.0;
+    int nt = 0;
+    int it = 0;
+    auto push_trace = [&](int iter_now) -> int {
+        double err = 0.0;
+        SGLCHK(mse_test_dev(c, seed, inv_density, &err));
+        test_mse[nt] = err;
+        iter[nt] = iter_now;
+        tol_out[nt] = tol_;
+        double min_err = test_mse[0];
+        for (int t = 1; t <= nt; ++t) min_err = std::min(min_err, test_mse[t]);
+        score_overfit[nt] = (err - min_err) / (err + min_err);
+        ++nt;
+        return SGL_OK;
+    };
+    for (; it < maxit && tol_ > tol; ++it) {
+        SGLCHK(sgl_step_begin(c));
+        SGLCHK(predict_mask_dev(c, c->A, c->col_nnz_A, c->W, c->H, c->B, seed, inv_density, L1, L2, 0, SGL_PH_RHS_H,
+                                SGL_PH_NNLS_H, c->sweep_counters + 0));
+        SGLCHK(sgl_step_scale_h(c));
+        if (cb && cb->poll && cb->poll(cb->user)) { sgl_set_error("interrupted"); return SGL_EINTR; }
+        SGLCHK(predict_mask_dev(c, c->At, c->col_nnz_At, c->H, c->W, c->red, seed, inv_density, L1, L2, 1,
+                                SGL_PH_RHS_W, SGL_PH_NNLS_W, c->sweep_counters + 1));
+        SGLCHK(sgl_step_scale_w(c, &tol_));
+        (void)k; (void)m;
+        if (it % trace_test_mse == 0) {
+            SGLCHK(push_trace(it));
+            if (cb && cb->log) cb->log(cb->user, it + 1, tol_, score_overfit[nt - 1]);
+            if (score_overfit[nt - 1] > overfit_threshold) break;
+        } else if (cb && cb->log) {
+            cb->log(cb->user, it + 1, tol_, NAN);
+        }
+        if (cb && cb->poll && cb->poll(cb->user)) { sgl_set_error("interrupted"); return SGL_EINTR; }
+    }
+    if (it % trace_test_mse != 0) SGLCHK(push_trace(it));
+    SGLCHK(fetch_sweeps(c));
+    *n_trace = nt;
+    if (n_iter) *n_iter = it;
+    return SGL_OK;
+}
+
+// ---------------------------------------------------------- one-shot ABI ----
+struct CtxHolder {
+    sgl_ctx* c = nullptr;
+    ~CtxHolder() { if (c) sgl_destroy(c); }
+};
+
+static int current_device_or_zero() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) { (void)hipGetLastError(); d = 0; }
+    return d;
+}
+
+extern "C" int sgl_c_nmf(const double* Ax, const int32_t* Ai, const int32_t* Ap, const double* Atx, const int32_t* Ati,
+                         const int32_t* Atp, int32_t nrow, int32_t ncol, double tol, uint16_t maxit, int verbose,
+                         double L1_w, double L1_h, double L2_w, double L2_h, uint16_t threads, const double* w_init,
+                         int32_t k, double* w_out, double* d_out, double* h_out, int32_t* n_iter, double* tol_trace,
+                         const sgl_callbacks* cb) {
+    (void)verbose; (void)threads;
+    if (!w_init || !w_out || !d_out || !h_out) { sgl_set_error("sgl_c_nmf: NULL factor buffer"); return SGL_EINVAL; }
+    CtxHolder hd;
+    SGLCHK(sgl_create(current_device_or_zero(), &hd.c));
+    SGLCHK(sgl_upload_csc(hd.c, Ax, Ai, Ap, Atx, Ati, Atp, nrow, ncol, 0, ncol));
+    SGLCHK(sgl_fit_init(hd.c, k, w_init, 0));
+    SGLCHK(sgl_nmf_run(hd.c, tol, maxit, L1_w, L1_h, L2_w, L2_h, n_iter, tol_trace, cb));
+    return sgl_get_factors(hd.c, w_out, d_out, h_out);
+}
+
+extern "C" int sgl_c_ard_nmf(const double* Ax, const int32_t* Ai, const int32_t* Ap, const double* Atx,
+                             const int32_t* Ati, const int32_t* Atp, int32_t nrow, int32_t ncol, double tol,
+                             uint16_t maxit, int verbose, double L1, double L2, uint16_t threads, const double* w_init,
+                             int32_t k, uint64_t seed, uint64_t inv_density, double overfit_threshold,
+                             uint16_t trace_test_mse, double* w_out, double* d_out, double* h_out, double* test_mse,
+                             int32_t* iter, double* tol_out, double* score_overfit, int32_t* n_trace,
+                             const sgl_callbacks* cb) {
+    (void)verbose; (void)threads;
+    if (!w_init || !w_out || !d_out || !h_out) { sgl_set_error("sgl_c_ard_nmf: NULL factor buffer"); return SGL_EINVAL; }
+    CtxHolder hd;
+    SGLCHK(sgl_create(current_device_or_zero(), &hd.c));
+    SGLCHK(sgl_upload_csc(hd.c, Ax, Ai, Ap, Atx, Ati, Atp, nrow, ncol, 0, ncol));
+    SGLCHK(sgl_fit_init(hd.c, k, w_init, 0));
+    int32_t nit = 0;
+    SGLCHK(sgl_ard_run(hd.c, tol, maxit, L1, L2, seed, inv_density, overfit_threshold, trace_test_mse, test_mse, iter,
+                       tol_out, score_overfit, n_trace, &nit, cb));
+    return sgl_get_factors(hd.c, w_out, d_out, h_out);
+}
+
+extern "C" int sgl_c_project_model(const double* Ax, const int32_t* Ai, const int32_t* Ap, int32_t nrow, int32_t ncol,
+                                   const double* w, int32_t w_rows, int32_t w_cols, double L1, double L2,
+                                   uint16_t threads, double* h_out, double* d_out) {
+    (void)threads;
+    if (!w || !h_out || !d_out) { sgl_set_error("sgl_c_project_model: NULL buffer"); return SGL_EINVAL; }
+    // if (w.rows() == A.rows()) w = w.transpose();   src/singlet.cpp:406
+    const bool tr = (w_rows == nrow);
+    const int k = tr ? w_cols : w_rows;
+    const int64_t cols = tr ? w_rows : w_cols;
+    if (cols != nrow) { sgl_set_error("'w' must share a common edge with the rows of 'A' (w is %d x %d, A has %d rows)", w_rows, w_cols, nrow); return SGL_EINVAL; }
+    CtxHolder hd;
+    SGLCHK(sgl_create(current_device_or_zero(), &hd.c));
+    sgl_ctx* c = hd.c;
+    // the projection only walks A; give the context an empty At of the right shape
+    SGLCHK(sgl_upload_csc_A_only(c, Ax, Ai, Ap, nrow, ncol));
+    std::vector<double> wk;
+    const double* wsrc = w;
+    if (tr) {
+        wk.resize((size_t)k * cols);
+        for (int64_t r = 0; r < w_rows; ++r)
+            for (int cidx = 0; cidx < w_cols; ++cidx) wk[(size_t)r * k + cidx] = w[(size_t)cidx * w_rows + r];
+        wsrc = wk.data();
+    }
+    SGLCHK(sgl_fit_init(c, k, wsrc, 0));
+    // scale(w, d) (l.408) then one predict + scale(h, d) (l.410-411)
+    SGLCHK(k_rowsum(c, c->W, k, nrow, c->d));
+    SGLCHK(k_scale_apply(c->stream, c->W, k, nrow, c->d, 1));
+    SGLCHK(sgl_project_run(c, L1, L2));
+    return sgl_get_factors(c, nullptr, d_out, h_out);
+}
+
+// ------------------------------------------------------------ operators -----
+extern "C" int sgl_op_rand(sgl_ctx* c, uint64_t state, const uint64_t* i, const uint64_t* j, int64_t n, uint64_t* out) {
+    CTX_GUARD(c);
+    if (n < 0 || (n > 0 && (!i || !j || !out))) { sgl_set_error("sgl_op_rand: bad arguments"); return SGL_EINVAL; }
+    if (n == 0) return SGL_OK;
+    uint64_t *di = nullptr, *dj = nullptr, *dout = nullptr;
+    SGLCHK(dev_alloc(&di, (size_t)n));
+    SGLCHK(dev_alloc(&dj, (size_t)n));
+    SGLCHK(dev_alloc(&dout, (size_t)n));
+    HIPCHK(hipMemcpyAsync(di, i, sizeof(uint64_t) * n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(dj, j, sizeof(uint64_t) * n, hipMemcpyHostToDevice, c->stream));
+    int rc = k_rand(c->stream, state, di, dj, n, dout);
+    HIPCHK(hipMemcpyAsync(out, dout, sizeof(uint64_t) * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    dev_free(di); dev_free(dj); dev_free(dout);
+    return rc;
+}
+
+extern "C" int sgl_op_mask(sgl_ctx* c, uint64_t state, uint64_t inv_density, int64_t cell0, int32_t ncells,
+                           int32_t ngenes, uint8_t* out) {
+    CTX_GUARD(c);
+    if (ncells < 0 || ngenes < 0 || inv_density == 0 || !out) { sgl_set_error("sgl_op_mask: bad arguments"); return SGL_EINVAL; }
+    const size_t n = (size_t)ncells * (size_t)ngenes;
+    if (n == 0) return SGL_OK;
+    uint8_t* dout = nullptr;
+    SGLCHK(dev_alloc(&dout, n));
+    int rc = k_mask(c->stream, state, inv_density, cell0, ncells, ngenes, dout);
+    HIPCHK(hipMemcpyAsync(out, dout, n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    dev_free(dout);
+    return rc;
+}
+
+extern "C" int sgl_op_gram(sgl_ctx* c, const double* F, int32_t k, int64_t cols, double* G) {
+    CTX_GUARD(c);
+    if (!F || !G || k <= 0 || cols < 0) { sgl_set_error("sgl_op_gram: bad arguments"); return SGL_EINVAL; }
+    double *dF = nullptr, *dG = nullptr;
+    SGLCHK(dev_alloc(&dF, (size_t)k * cols));
+    SGLCHK(dev_alloc(&dG, (size_t)k * k));
+    HIPCHK(hipMemcpyAsync(dF, F, sizeof(double) * (size_t)k * cols, hipMemcpyHostToDevice, c->stream));
+    int rc = k_gram(c, dF, k, cols, dG, 1e-15);
+    HIPCHK(hipMemcpyAsync(G, dG, sizeof(double) * (size_t)k * k, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    dev_free(dF); dev_free(dG);
+    return rc;
+}
+
+extern "C" int sgl_op_rhs(sgl_ctx* c, int which, const double* F, int32_t k, double* B) {
+    CTX_GUARD(c);
+    DevCSC& M = which ? c->At : c->A;
+    if (!M.p) { sgl_set_error("no matrix resident"); return SGL_ESTATE; }
+    if (!F || !B || k <= 0 || k > SGL_MAX_K) { sgl_set_error("sgl_op_rhs: bad arguments"); return SGL_EINVAL; }
+    double *dF = nullptr, *dB = nullptr;
+    SGLCHK(dev_alloc(&dF, (size_t)k * M.nrow));
+    SGLCHK(dev_alloc(&dB, (size_t)k * M.ncol));
+    HIPCHK(hipMemcpyAsync(dF, F, sizeof(double) * (size_t)k * M.nrow, hipMemcpyHostToDevice, c->stream));
+    // tiles depend on k: build a temporary table unless a fit with the same k owns one
+    int64_t* saved = M.seg; int32_t str = M.tile_rows, snt = M.ntiles;
+    M.seg = nullptr;
+    int rc = build_tiles(c, M, k);
+    if (rc == SGL_OK) rc = k_acc(c->stream, M, dF, k, dB, 0, 1, 0, 0, 0);
+    HIPCHK(hipMemcpyAsync(B, dB, sizeof(double) * (size_t)k * M.ncol, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    dev_free(M.seg);
+    M.seg = saved; M.tile_rows = str; M.ntiles = snt;
+    dev_free(dF); dev_free(dB);
+    return rc;
+}
+
+extern "C" int sgl_op_nnls(sgl_ctx* c, const double* G, const double* B, double* X, int32_t k, int64_t ncols,
+                           double L1, double L2, int32_t* sweeps_out) {
+    CTX_GUARD(c);
+    if (!G || !B || !X || k <= 0 || k > SGL_MAX_K || ncols < 0) { sgl_set_error("sgl_op_nnls: bad arguments"); return SGL_EINVAL; }
+    double *dG = nullptr, *dB = nullptr, *dX = nullptr, *dGp = nullptr;
+    SGLCHK(dev_alloc(&dG, (size_t)k * k));
+    SGLCHK(dev_alloc(&dB, (size_t)k * ncols));
+    SGLCHK(dev_alloc(&dX, (size_t)k * ncols));
+    HIPCHK(hipMemcpyAsync(dG, G, sizeof(double) * (size_t)k * k, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(dB, B, sizeof(double) * (size_t)k * ncols, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(dX, X, sizeof(double) * (size_t)k * ncols, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemsetAsync(c->sweep_counters + 2, 0, sizeof(int), c->stream));
+    int rc;
+    if (k <= SGL_LANE_NNLS_MAX_K) {
+        const int KP = lane_kp(k);
+        rc = dev_alloc(&dGp, (size_t)KP * KP);
+        if (rc == SGL_OK) rc = k_pad_gram(c->stream, dG, k, KP, dGp);
+        if (rc == SGL_OK) rc = k_nnls_lane(c->stream, dGp, KP, dB, dX, nullptr, k, ncols, L1, L2, c->sweep_counters + 2);
+    } else {
+        rc = k_nnls_wave(c->stream, dG, 0, dB, dX, nullptr, k, ncols, L1, L2, c->sweep_counters + 2);
+    }
+    int sw = 0;
+    HIPCHK(hipMemcpyAsync(X, dX, sizeof(double) * (size_t)k * ncols, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(&sw, c->sweep_counters + 2, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (sweeps_out) *sweeps_out = sw;
+    dev_free(dG); dev_free(dB); dev_free(dX); dev_free(dGp);
+    return rc;
+}
+
+extern "C" int sgl_op_scale(sgl_ctx* c, double* F, int32_t k, int64_t cols, double* d) {
+    CTX_GUARD(c);
+    if (!F || !d || k <= 0 || cols < 0) { sgl_set_error("sgl_op_scale: bad arguments"); return SGL_EINVAL; }
+    double *dF = nullptr, *dd = nullptr;
+    SGLCHK(dev_alloc(&dF, (size_t)k * cols));
+    SGLCHK(dev_alloc(&dd, (size_t)k));
+    HIPCHK(hipMemcpyAsync(dF, F, sizeof(double) * (size_t)k * cols, hipMemcpyHostToDevice, c->stream));
+    int rc = k_rowsum(c, dF, k, cols, dd);
+    if (rc == SGL_OK) rc = k_scale_apply(c->stream, dF, k, cols, dd, 1);
+    HIPCHK(hipMemcpyAsync(F, dF, sizeof(double) * (size_t)k * cols, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(d, dd, sizeof(double) * (size_t)k, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    dev_free(dF); dev_free(dd);
+    return rc;
+}
+
+extern "C" int sgl_op_cor(sgl_ctx* c, const double* x, const double* y, int64_t n, double* out) {
+    CTX_GUARD(c);
+    if (!x || !y || !out || n <= 0) { sgl_set_error("sgl_op_cor: bad arguments"); return SGL_EINVAL; }
+    double *dx = nullptr, *dy = nullptr;
+    SGLCHK(dev_alloc(&dx, (size_t)n));
+    SGLCHK(dev_alloc(&dy, (size_t)n));
+    HIPCHK(hipMemcpyAsync(dx, x, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(dy, y, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    int rc = k_cor(c, dx, dy, n, c->scalars + 2);
+    HIPCHK(hipMemcpyAsync(out, c->scalars + 2, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    dev_free(dx); dev_free(dy);
+    return rc;
+}
+
+// --------------------------------------------------------------- timing -----
+extern "C" int sgl_timing_enable(sgl_ctx* c, int on) {
+    CTX_GUARD(c);
+    SGLCHK(drain_timing(c));
+    c->timing = on != 0;
+    return SGL_OK;
+}
+
+extern "C" int sgl_timing_get(sgl_ctx* c, double* ms, int64_t* calls, int reset) {
+    CTX_GUARD(c);
+    SGLCHK(drain_timing(c));
+    for (int p = 0; p < SGL_PH_COUNT; ++p) {
+        if (ms) ms[p] = c->phase_ms[p];
+        if (calls) calls[p] = c->phase_calls[p];
+        if (reset) { c->phase_ms[p] = 0; c->phase_calls[p] = 0; }
+    }
+    return SGL_OK;
+}
+
+extern "C" int sgl_sweeps_get(sgl_ctx* c, int64_t* out4, int reset) {
+    CTX_GUARD(c);
+    SGLCHK(fetch_sweeps(c));
+    for (int q = 0; q < 4; ++q) {
+        if (out4) out4[q] = c->sweeps_acc[q];
+        if (reset) c->sweeps_acc[q] = 0;
+    }
+    return SGL_OK;
+}

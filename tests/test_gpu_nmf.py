@@ -1,0 +1,118 @@
+"""End-to-end parity of the ALS loops against the CPU oracle through the
+reference-shaped entry points (c_nmf / c_ard_nmf / c_project_model)."""
+import numpy as np
+import pytest
+
+from conftest import rel_fro, same_zero_pattern, to_dgc
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-9   # asserted; the north star allows 1e-5
+
+
+def _check(got, ref, keys=("w", "h", "d")):
+    for key in keys:
+        g = got[key].T if got[key].ndim == 2 else got[key]
+        assert rel_fro(g, ref[key]) < TOL, key
+        if g.ndim == 2:
+            assert same_zero_pattern(g, ref[key]), key
+
+
+@pytest.mark.parametrize("m,n,k,L1,L2,maxit", [
+    (300, 400, 8, 0.0, 0.0, 5), (300, 400, 8, 0.01, 0.0, 5), (300, 400, 8, 0.01, 0.01, 5),
+    (500, 260, 30, 0.01, 0.0, 4), (257, 1031, 50, 0.01, 0.0, 3), (200, 300, 1, 0.0, 0.0, 3),
+    (150, 200, 64, 0.01, 0.0, 2), (150, 220, 70, 0.01, 0.0, 2)])
+def test_c_nmf_parity(sa, ora, m, n, k, L1, L2, maxit):
+    A = ora.synth_csc(m, n, 20)
+    At = A.t()
+    w0 = ora.synth_winit(k, m)
+    ref = ora.c_nmf(A, At, 0.0, maxit, L1, L1, L2, L2, 0, w0)
+    got = sa.c_nmf(to_dgc(sa, A), to_dgc(sa, At), 0.0, maxit, False, L1, L1, L2, L2, 0, w0.T)
+    _check(got, ref)
+    assert got["iter"] == ref["iter"] == maxit
+    assert np.allclose(got["tol"], ref["tol"], rtol=1e-8, atol=0)
+
+
+def test_c_nmf_without_At_and_distinct_penalties(sa, ora):
+    A = ora.synth_csc(280, 350, 10)
+    w0 = ora.synth_winit(9, 280)
+    ref = ora.c_nmf(A, A.t(), 0.0, 4, 0.02, 0.005, 0.01, 0.0, 0, w0)
+    got = sa.c_nmf(to_dgc(sa, A), None, 0.0, 4, False, 0.02, 0.005, 0.01, 0.0, 0, w0.T)
+    _check(got, ref)
+
+
+def test_c_nmf_stop_decision(sa, ora):
+    """tol > 0: the loop must stop at the same iteration as the oracle (well separated case)."""
+    A = ora.synth_csc(300, 400, 20)
+    w0 = ora.synth_winit(6, 300)
+    ref = ora.c_nmf(A, A.t(), 1e-2, 100, 0.01, 0.01, 0, 0, 0, w0)
+    got = sa.c_nmf(to_dgc(sa, A), None, 1e-2, 100, False, 0.01, 0.01, 0, 0, 0, w0.T)
+    assert got["iter"] == ref["iter"] and 1 < ref["iter"] < 100
+    _check(got, ref)
+
+
+def test_c_nmf_empty_columns_keep_stale_values(sa, ora):
+    rng = np.random.default_rng(5)
+    D = (rng.random((120, 150)) < 0.1) * (rng.random((120, 150)) + 0.5)
+    D[:, 7] = 0      # empty cell: h[:, 7] stays 0 then is only rescaled
+    D[33, :] = 0     # empty gene: w[:, 33] keeps its (rescaled) initial values
+    from test_gpu_ops import _csc_from_dense
+    A = ora.CSC(*_csc_from_dense(D))
+    w0 = ora.synth_winit(5, 120)
+    ref = ora.c_nmf(A, A.t(), 0.0, 3, 0.01, 0.01, 0, 0, 0, w0)
+    got = sa.c_nmf(to_dgc(sa, A), None, 0.0, 3, False, 0.01, 0.01, 0, 0, 0, w0.T)
+    _check(got, ref)
+    assert np.all(got["h"][:, 7] == 0) and np.all(got["w"][:, 33] > 0)
+
+
+@pytest.mark.parametrize("orient", ["m_by_k", "k_by_m"])
+def test_c_project_model(sa, ora, orient):
+    A = ora.synth_csc(300, 410, 20)
+    w = np.random.default_rng(1).random((300, 11))
+    win = w if orient == "m_by_k" else w.T.copy()
+    ref = ora.c_project_model(A, win, 0.01, 0.0)
+    got = sa.c_project_model(to_dgc(sa, A), win, 0.01, 0.0, 0)
+    _check(got, ref, ("h", "d"))
+
+
+@pytest.mark.parametrize("k,trace,maxit", [(6, 1, 4), (8, 2, 5), (5, 3, 4)])
+def test_c_ard_nmf_parity(sa, ora, k, trace, maxit):
+    A = ora.synth_csc(220, 260, 20)
+    At = A.t()
+    w0 = ora.synth_winit(k, 220)
+    ref = ora.c_ard_nmf(A, At, 0.0, maxit, 0.01, 0.0, 0, w0, 77, 20, 1e-3, trace)
+    got = sa.c_ard_nmf(to_dgc(sa, A), to_dgc(sa, At), 0.0, maxit, False, 0.01, 0.0, 0, w0.T, 77, 20, 1e-3, trace)
+    _check(got, ref)
+    assert np.array_equal(got["iter"], ref["iter"])
+    assert np.allclose(got["test_mse"], ref["test_mse"], rtol=1e-9, atol=0)
+    assert np.allclose(got["tol"], ref["tol"], rtol=1e-7, atol=0)
+    assert np.allclose(got["score_overfit"], ref["score_overfit"], rtol=1e-6, atol=1e-12)
+
+
+def test_c_ard_nmf_overfit_break(sa, ora):
+    """A tiny overfit threshold makes the reference break out of the loop early; same here."""
+    A = ora.synth_csc(200, 240, 20)
+    w0 = ora.synth_winit(12, 200)
+    ref = ora.c_ard_nmf(A, A.t(), 0.0, 30, 0.0, 0.0, 0, w0, 5, 10, 1e-7, 1)
+    got = sa.c_ard_nmf(to_dgc(sa, A), None, 0.0, 30, False, 0.0, 0.0, 0, w0.T, 5, 10, 1e-7, 1)
+    assert np.array_equal(got["iter"], ref["iter"])
+    assert len(ref["iter"]) < 30
+    _check(got, ref)
+
+
+def test_step_api_matches_run(sa, ora, ctx):
+    """The step-level operators chained by the host equal sgl_nmf_run (what a sharded host does)."""
+    A = ora.synth_csc(260, 300, 20)
+    w0 = ora.synth_winit(10, 260)
+    ref = ora.c_nmf(A, A.t(), 0.0, 3, 0.01, 0.01, 0, 0, 0, w0)
+    ctx.upload(to_dgc(sa, A), None)
+    ctx.fit_init(10, w0)
+    tols = []
+    for _ in range(3):
+        ctx.step_begin()
+        ctx.step_h(0.01, 0.0)
+        ctx.step_scale_h()
+        ctx.step_w(0.01, 0.0)
+        tols.append(ctx.step_scale_w())
+    W, d, H = ctx.get_factors()
+    assert rel_fro(W, ref["w"]) < TOL and rel_fro(H, ref["h"]) < TOL and rel_fro(d, ref["d"]) < TOL
+    assert np.allclose(tols, ref["tol"], rtol=1e-8)

@@ -1,0 +1,144 @@
+"""Parity of each HIP operator of the path against the CPU oracle, through the
+C ABI (singlet_amd.Context wraps sgl_op_* one-to-one).  Integer work is
+bit-exact; FP64 work is held to 1e-11 relative (the only arithmetic difference
+is FMA contraction and reduction order), far inside the 1e-5 the north star asks."""
+import numpy as np
+import pytest
+
+from conftest import rel_fro, to_dgc
+
+pytestmark = pytest.mark.gpu
+
+KATS = [((123, 0, 0), 0x692656729eb6707c), ((123, 1, 2), 0xd1c4f6746e22623f), ((123, 2, 1), 0xa171855b28d239a7),
+        ((123, 999999, 29999), 0x3ffec3e4f2d21eea), ((2147483647, 5, 7), 0x3b72606ab1a2d601),
+        ((1, 0, 1), 0x000112648b36e912)]
+
+
+def test_rand_kats(ctx):
+    for (s, i, j), v in KATS:
+        assert int(ctx.op_rand(s, [i], [j])[0]) == v
+
+
+def test_rand_bulk_bit_exact(ctx, ora):
+    rng = np.random.default_rng(7)
+    i = rng.integers(0, 2 ** 63, 5000, dtype=np.uint64)
+    j = rng.integers(0, 2 ** 63, 5000, dtype=np.uint64)
+    i[:4] = [0, 1, 2 ** 64 - 1, 2 ** 32]
+    j[:4] = [2 ** 64 - 1, 0, 2 ** 64 - 1, 2 ** 31]
+    for state in (0, 123, 2 ** 64 - 1):
+        got = ctx.op_rand(state, i, j)
+        exp = np.array([ora.rng_rand(state, int(a), int(b)) for a, b in zip(i, j)], dtype=np.uint64)
+        assert np.array_equal(got, exp)
+
+
+@pytest.mark.parametrize("inv_density", [20, 5, 1])
+def test_mask_bit_exact(ctx, ora, inv_density):
+    got = ctx.op_mask(42, inv_density, 1000, 37, 515)
+    exp = ora.rng_mask(42, 1000, 37, 515, inv_density)
+    assert np.array_equal(got, exp)
+
+
+@pytest.mark.parametrize("k,cols", [(1, 5), (8, 400), (16, 33), (30, 2000), (50, 777), (64, 300), (70, 129), (100, 50)])
+def test_gram(ctx, ora, k, cols):
+    F = np.random.default_rng(k * 1000 + cols).random((cols, k))
+    G = ctx.op_gram(F)
+    E = ora.aat(F)
+    assert rel_fro(G, E) < 1e-13
+    assert np.array_equal(G, G.T)
+
+
+def test_gram_transpose_detecting(ctx, ora):
+    # asymmetric factor rows: a swapped MFMA C-layout would show up here
+    F = np.zeros((40, 20))
+    F[:, 3] = np.arange(40) + 1
+    F[:, 17] = 1.0 / (np.arange(40) + 1)
+    assert rel_fro(ctx.op_gram(F), ora.aat(F)) < 1e-14
+
+
+@pytest.mark.parametrize("k", [1, 7, 30, 50, 64, 65, 100, 130])
+def test_rhs_both_orientations(ctx, ora, sa, k):
+    A = ora.synth_csc(300, 450, 20)
+    At = A.t()
+    ctx.upload(to_dgc(sa, A), to_dgc(sa, At))
+    rng = np.random.default_rng(k)
+    W = rng.random((A.nrow, k))
+    H = rng.random((A.ncol, k))
+    assert rel_fro(ctx.op_rhs(0, W), ora.rhs(A, W)) < 1e-14
+    assert rel_fro(ctx.op_rhs(1, H), ora.rhs(At, H)) < 1e-14
+
+
+def test_rhs_ragged_and_empty_columns(ctx, ora, sa):
+    rng = np.random.default_rng(3)
+    D = (rng.random((90, 140)) < 0.3) * rng.random((90, 140))
+    D[:, 5] = 0
+    D[:, 139] = 0
+    D[:, 17] = rng.random(90) + 0.1   # full column
+    D[40, :] = 0                       # empty row -> empty column of At
+    A = ora.CSC(*_csc_from_dense(D))
+    ctx.upload(to_dgc(sa, A), to_dgc(sa, A.t()))
+    W = rng.random((90, 9))
+    B = ctx.op_rhs(0, W)
+    assert rel_fro(B, ora.rhs(A, W)) < 1e-14
+    assert np.all(B[5] == 0) and np.all(B[139] == 0)
+
+
+def _csc_from_dense(D):
+    nrow, ncol = D.shape
+    xs, is_, p = [], [], [0]
+    for c in range(ncol):
+        r = np.nonzero(D[:, c])[0]
+        is_.append(r)
+        xs.append(D[r, c])
+        p.append(p[-1] + r.size)
+    return np.concatenate(xs), np.concatenate(is_), np.array(p), nrow, ncol
+
+
+@pytest.mark.parametrize("k", [2, 8, 10, 30, 50, 52, 64, 65, 100])
+@pytest.mark.parametrize("L1,L2", [(0.0, 0.0), (0.01, 0.0), (0.01, 0.05)])
+def test_nnls(ctx, ora, k, L1, L2):
+    rng = np.random.default_rng(k)
+    ncols = 300
+    F = rng.random((4 * k + 5, k))
+    G = ora.aat(F)
+    B = rng.normal(size=(ncols, k)) * 3 + 1.0
+    X0 = np.abs(rng.normal(size=(ncols, k))) * (rng.random((ncols, k)) < 0.6) * 1e-3
+    X, sweeps = ctx.op_nnls(G, B, X0, L1, L2)
+    E = np.empty_like(X0)
+    esw = 0
+    for c in range(ncols):
+        E[c], _, it = ora.nnls(G, B[c], X0[c], L1, L2)
+        esw += it
+    assert rel_fro(X, E) < 1e-10
+    assert np.array_equal(X == 0, E == 0)
+    assert sweeps == esw
+
+
+def test_scale_and_cor(ctx, ora):
+    rng = np.random.default_rng(11)
+    F = rng.random((1234, 17))
+    S, d = ctx.op_scale(F)
+    ES, ed = ora.scale(F)
+    assert rel_fro(d, ed) < 1e-14 and rel_fro(S, ES) < 1e-14
+    x, y = rng.random(50000), rng.random(50000)
+    y = 0.7 * x + 0.3 * y
+    assert abs(ctx.op_cor(x, y) - ora.cor(x, y)) < 1e-12
+    assert np.isnan(ctx.op_cor(np.ones(10), np.ones(10)))  # zero variance -> NaN ends the loop (quirk 9)
+
+
+def test_synth_matches_oracle_generator(ctx, ora):
+    m, n, off = 257, 130, 1000
+    ctx.synth(m, n, 20, cell_offset=off, ncells_total=5000)
+    A = ora.synth_csc(m, n, 20, cell0=off)
+    x, i, p = ctx.download(0)
+    assert np.array_equal(p, A.p.astype(np.int64)) and np.array_equal(i, A.i) and np.array_equal(x, A.x)
+    At = A.t()
+    x, i, p = ctx.download(1)
+    assert np.array_equal(p, At.p.astype(np.int64)) and np.array_equal(i, At.i) and np.array_equal(x, At.x)
+
+
+def test_device_transpose(ctx, ora, sa):
+    A = ora.synth_csc(123, 321, 7)
+    ctx.upload(to_dgc(sa, A), None)
+    At = A.t()
+    x, i, p = ctx.download(1)
+    assert np.array_equal(p, At.p.astype(np.int64)) and np.array_equal(i, At.i) and np.array_equal(x, At.x)
