@@ -473,12 +473,16 @@ ORA_API int ora_c_ard_nmf(const double* Ax, const int32_t* Ai, const int32_t* Ap
  * ((rand_{S+2}(f, g) >> 11) + 0.5) * 2^-53. */
 ORA_API int64_t ora_synth_count(uint64_t S, uint64_t inv_density, int64_t cell0, int64_t ncells, int64_t ngenes,
                                 int32_t* p) {
-    int64_t tot = 0;
     p[0] = 0;
+#pragma omp parallel for
     for (int64_t c = 0; c < ncells; ++c) {
-        int64_t cnt = 0;
+        int32_t cnt = 0;
         for (int64_t g = 0; g < ngenes; ++g) cnt += ora_rng_draw(S, (uint64_t)(cell0 + c), (uint64_t)g, inv_density);
-        tot += cnt;
+        p[c + 1] = cnt;
+    }
+    int64_t tot = 0;
+    for (int64_t c = 0; c < ncells; ++c) {
+        tot += p[c + 1];
         p[c + 1] = (int32_t)tot;
     }
     return tot;

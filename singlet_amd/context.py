@@ -247,4 +247,4 @@ class Context:
     def sweeps_get(self, reset=False):
         out = np.zeros(4, dtype=np.int64)
         check(self._L.sgl_sweeps_get(self._h, ptr(out, i64p), int(reset)))
-        return dict(h_sweeps=int(out[0]), w_sweeps=int(out[1]), h_cols=int(out[2]), w_cols=int(out[3]))
+        return dict(h_sweeps=int(out[0]), w_sweeps=int(out[1]), h_wave_sweeps=int(out[2]), w_wave_sweeps=int(out[3]))

@@ -35,7 +35,7 @@ template <int KP>
 __global__ __launch_bounds__(256) void nnls_lane_kernel(const double* __restrict__ Gpad, const double* __restrict__ B,
                                                         double* __restrict__ X, const int64_t* __restrict__ col_nnz,
                                                         int k, int64_t ncols, double L1, double L2,
-                                                        int* __restrict__ sweep_counter) {
+                                                        unsigned long long* __restrict__ sweep_counter) {
     const int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     // empty columns are skipped and keep their stale values (src/singlet.cpp:340)
     const bool valid = (col < ncols) && (col_nnz == nullptr || col_nnz[col] != 0);
@@ -50,14 +50,16 @@ __global__ __launch_bounds__(256) void nnls_lane_kernel(const double* __restrict
     const double kd = (double)k;
     double tol = 1.0;
     int it = 0;
-    const double* Gs = Gpad;
+    int gofs = 0;
     while (true) {
         const bool go = valid && it < 100 && (tol / kd) > 1e-8;
         if (!__any(go)) break;
         if (go) tol = 0.0;
-        // launder the (wave-uniform) Gram pointer once per sweep: the k*k scalar loads must be
-        // re-issued every sweep instead of being hoisted out of the loop and spilled.
-        asm volatile("" : "+s"(Gs));
+        // launder a (wave-uniform, always zero) offset once per sweep: the k*k scalar loads of the
+        // Gram must be re-issued every sweep instead of being hoisted out of the loop and spilled.
+        // The pointer itself keeps its provenance (global, read-only) so the loads stay s_load.
+        asm volatile("" : "+s"(gofs));
+        const double* __restrict__ Gs = Gpad + gofs;
         static_for<KP>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             if (i < k) {
@@ -91,14 +93,20 @@ __global__ __launch_bounds__(256) void nnls_lane_kernel(const double* __restrict
         });
     }
     if (sweep_counter != nullptr) {
-        int s = it;
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-        if ((threadIdx.x & 63) == 0 && s != 0) atomicAdd(sweep_counter, s);
+        int s = it, mx = it;
+        for (int off = 32; off > 0; off >>= 1) {
+            s += __shfl_down(s, off, 64);
+            mx = max(mx, __shfl_down(mx, off, 64));
+        }
+        if ((threadIdx.x & 63) == 0 && s != 0) {
+            atomicAdd(sweep_counter, (unsigned long long)s);
+            atomicAdd(sweep_counter + 2, (unsigned long long)mx);  // diagnostic: sweeps the wave actually ran
+        }
     }
 }
 
 int k_nnls_lane(hipStream_t s, const double* Gpad, int KP, const double* B, double* X, const int64_t* col_nnz, int k,
-                int64_t ncols, double L1, double L2, int* sweep_counter) {
+                int64_t ncols, double L1, double L2, unsigned long long* sweep_counter) {
     if (ncols <= 0) return SGL_OK;
     dim3 g((unsigned)((ncols + 255) / 256)), b(256);
 #define SGL_NNLS(K_) case K_: nnls_lane_kernel<K_><<<g, b, 0, s>>>(Gpad, B, X, col_nnz, k, ncols, L1, L2, sweep_counter); break
@@ -124,7 +132,7 @@ template <int R>
 __global__ __launch_bounds__(256) void nnls_wave_kernel(const double* __restrict__ G, int64_t gstride,
                                                         const double* __restrict__ B, double* __restrict__ X,
                                                         const int64_t* __restrict__ col_nnz, int k, int64_t ncols,
-                                                        double L1, double L2, int* __restrict__ sweep_counter) {
+                                                        double L1, double L2, unsigned long long* __restrict__ sweep_counter) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -182,11 +190,14 @@ __global__ __launch_bounds__(256) void nnls_wave_kernel(const double* __restrict
             if (j < k) X[col * k + j] = x[r];
         }
     }
-    if (sweep_counter != nullptr && lane == 0 && total_sweeps != 0) atomicAdd(sweep_counter, total_sweeps);
+    if (sweep_counter != nullptr && lane == 0 && total_sweeps != 0) {
+        atomicAdd(sweep_counter, (unsigned long long)total_sweeps);
+        atomicAdd(sweep_counter + 2, (unsigned long long)total_sweeps);
+    }
 }
 
 int k_nnls_wave(hipStream_t s, const double* G, int64_t gstride, const double* B, double* X, const int64_t* col_nnz,
-                int k, int64_t ncols, double L1, double L2, int* sweep_counter) {
+                int k, int64_t ncols, double L1, double L2, unsigned long long* sweep_counter) {
     if (ncols <= 0) return SGL_OK;
     if (k > SGL_MAX_K) { sgl_set_error("k_nnls_wave: k=%d > %d", k, SGL_MAX_K); return SGL_EINVAL; }
     int64_t blocks = (ncols + 3) / 4;

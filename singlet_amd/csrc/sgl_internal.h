@@ -70,8 +70,9 @@ struct sgl_ctx {
     double* ws = nullptr;   // partial-reduction workspace
     size_t ws_bytes = 0;
     double* scalars = nullptr;       // device scratch for cor / mse results
-    int* sweep_counters = nullptr;   // device: [0] H sweeps, [1] W sweeps
+    unsigned long long* sweep_counters = nullptr;   // device: [0] H sweeps, [1] W sweeps
     int64_t sweeps_acc[4] = {0, 0, 0, 0};
+    int64_t wave_sweeps_acc[2] = {0, 0};
     double* pinned = nullptr;        // host pinned scratch (8 doubles)
 
     sgl_allreduce_fn allreduce = nullptr;
@@ -121,9 +122,9 @@ int k_acc(hipStream_t s, const DevCSC& M, const double* F, int k, double* B,
 
 // NNLS
 int k_nnls_lane(hipStream_t s, const double* Gpad, int KP, const double* B, double* X, const int64_t* col_nnz,
-                int k, int64_t ncols, double L1, double L2, int* sweep_counter);
+                int k, int64_t ncols, double L1, double L2, unsigned long long* sweep_counter);
 int k_nnls_wave(hipStream_t s, const double* G, int64_t gstride, const double* B, double* X, const int64_t* col_nnz,
-                int k, int64_t ncols, double L1, double L2, int* sweep_counter);
+                int k, int64_t ncols, double L1, double L2, unsigned long long* sweep_counter);
 
 // masked path
 int k_mask_gram_cols(hipStream_t s, int64_t col0, int64_t ncols, int32_t nrow, const int64_t* col_nnz,

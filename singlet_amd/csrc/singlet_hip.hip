@@ -182,9 +182,9 @@ extern "C" int sgl_create(int device, sgl_ctx** out) {
     HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     int rc = dev_alloc(&c->scalars, 16);
-    if (rc == SGL_OK) rc = dev_alloc(&c->sweep_counters, 4);
+    if (rc == SGL_OK) rc = dev_alloc(&c->sweep_counters, 8);
     if (rc != SGL_OK) { sgl_destroy(c); return rc; }
-    HIPCHK(hipMemsetAsync(c->sweep_counters, 0, 4 * sizeof(int), c->stream));
+    HIPCHK(hipMemsetAsync(c->sweep_counters, 0, 8 * sizeof(unsigned long long), c->stream));
     HIPCHK(hipHostMalloc((void**)&c->pinned, 16 * sizeof(double), hipHostMallocDefault));
     *out = c;
     return SGL_OK;
@@ -434,7 +434,7 @@ extern "C" int sgl_fit_init(sgl_ctx* c, int32_t k, const double* w_init, uint64_
 
 // NNLS dispatch for a Gram shared by all columns.
 static int nnls_shared(sgl_ctx* c, const double* G, const double* B, double* X, const int64_t* col_nnz, int64_t ncols,
-                       double L1, double L2, int* counter) {
+                       double L1, double L2, unsigned long long* counter) {
     const int k = c->k;
     if (k <= SGL_LANE_NNLS_MAX_K) {
         const int KP = lane_kp(k);
@@ -509,12 +509,14 @@ extern "C" int sgl_step_scale_w(sgl_ctx* c, double* tol_out) {
 }
 
 static int fetch_sweeps(sgl_ctx* c) {
-    int h[4] = {0, 0, 0, 0};
+    unsigned long long h[4] = {0, 0, 0, 0};
     HIPCHK(hipMemcpyAsync(h, c->sweep_counters, sizeof(h), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemsetAsync(c->sweep_counters, 0, sizeof(h), c->stream));
     c->sweeps_acc[0] += h[0];
     c->sweeps_acc[1] += h[1];
+    c->wave_sweeps_acc[0] += h[2];
+    c->wave_sweeps_acc[1] += h[3];
     return SGL_OK;
 }
 
@@ -531,8 +533,6 @@ extern "C" int sgl_nmf_run(sgl_ctx* c, double tol, int32_t maxit, double L1_w, d
         if (cb && cb->poll && cb->poll(cb->user)) { sgl_set_error("interrupted"); return SGL_EINTR; }
         SGLCHK(sgl_step_w(c, L1_w, L2_w));
         SGLCHK(sgl_step_scale_w(c, &tol_));
-        c->sweeps_acc[2] += c->A.ncol;
-        c->sweeps_acc[3] += c->A.nrow;
         if (tol_trace) tol_trace[it] = tol_;
         if (cb && cb->log) cb->log(cb->user, it + 1, tol_, NAN);
         if (cb && cb->poll && cb->poll(cb->user)) { sgl_set_error("interrupted"); return SGL_EINTR; }
@@ -575,7 +575,7 @@ extern "C" int sgl_set_factors(sgl_ctx* c, const double* w, const double* d, con
 // chunks so the per-column Grams a_i (k*k doubles each) stay bounded.
 static int predict_mask_dev(sgl_ctx* c, const DevCSC& M, const int64_t* col_nnz, const double* F, double* X,
                             double* Bbuf, uint64_t seed, uint64_t inv_density, double L1, double L2, int mask_t,
-                            int rhs_phase, int nnls_phase, int* counter) {
+                            int rhs_phase, int nnls_phase, unsigned long long* counter) {
     const int k = c->k;
     // hash argument order: A pass draw(cell = col + cell_offset, gene = row); At pass draw(cell = row + cell_offset, gene = col)
     const int64_t col_off = mask_t ? 0 : c->cell_offset;
@@ -842,21 +842,21 @@ extern "C" int sgl_op_nnls(sgl_ctx* c, const double* G, const double* B, double*
     HIPCHK(hipMemcpyAsync(dG, G, sizeof(double) * (size_t)k * k, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(dB, B, sizeof(double) * (size_t)k * ncols, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(dX, X, sizeof(double) * (size_t)k * ncols, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemsetAsync(c->sweep_counters + 2, 0, sizeof(int), c->stream));
+    HIPCHK(hipMemsetAsync(c->sweep_counters + 4, 0, 4 * sizeof(unsigned long long), c->stream));
     int rc;
     if (k <= SGL_LANE_NNLS_MAX_K) {
         const int KP = lane_kp(k);
         rc = dev_alloc(&dGp, (size_t)KP * KP);
         if (rc == SGL_OK) rc = k_pad_gram(c->stream, dG, k, KP, dGp);
-        if (rc == SGL_OK) rc = k_nnls_lane(c->stream, dGp, KP, dB, dX, nullptr, k, ncols, L1, L2, c->sweep_counters + 2);
+        if (rc == SGL_OK) rc = k_nnls_lane(c->stream, dGp, KP, dB, dX, nullptr, k, ncols, L1, L2, c->sweep_counters + 4);
     } else {
-        rc = k_nnls_wave(c->stream, dG, 0, dB, dX, nullptr, k, ncols, L1, L2, c->sweep_counters + 2);
+        rc = k_nnls_wave(c->stream, dG, 0, dB, dX, nullptr, k, ncols, L1, L2, c->sweep_counters + 4);
     }
-    int sw = 0;
+    unsigned long long sw = 0;
     HIPCHK(hipMemcpyAsync(X, dX, sizeof(double) * (size_t)k * ncols, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(&sw, c->sweep_counters + 2, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(&sw, c->sweep_counters + 4, sizeof(sw), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    if (sweeps_out) *sweeps_out = sw;
+    if (sweeps_out) *sweeps_out = (int32_t)sw;
     dev_free(dG); dev_free(dB); dev_free(dX); dev_free(dGp);
     return rc;
 }
@@ -918,5 +918,8 @@ extern "C" int sgl_sweeps_get(sgl_ctx* c, int64_t* out4, int reset) {
         if (out4) out4[q] = c->sweeps_acc[q];
         if (reset) c->sweeps_acc[q] = 0;
     }
+    // [2], [3]: sweeps executed per wave (max over its 64 columns), H / W solves
+    if (out4) { out4[2] = c->wave_sweeps_acc[0]; out4[3] = c->wave_sweeps_acc[1]; }
+    if (reset) c->wave_sweeps_acc[0] = c->wave_sweeps_acc[1] = 0;
     return SGL_OK;
 }
