@@ -45,6 +45,17 @@ struct DevCSC {
     int32_t tile_rows = 0, ntiles = 0;
 };
 
+// Re-blocked non-zero stream for the LDS-tiled accumulate (kernels_tiled.hip).
+struct DevTiled {
+    uint32_t* roff = nullptr;   // byte offset of the row inside the LDS tile, per entry
+    double* x = nullptr;        // value per entry (0 for pads)
+    int64_t* cstart = nullptr;  // [nwb * T + 1] first entry of chunk (wb, t)
+    uint8_t* cnt = nullptr;     // [nwb * T * CW] 4-entry groups of slot s in chunk (wb, t)
+    double* part = nullptr;     // [R][k * ncol] partial slabs when the tile range is split
+    int32_t TR = 0, T = 0, CW = 0, k = 0, R = 1, tiles_per_range = 0;
+    int64_t nwb = 0, E = 0, ncol = 0, nrow = 0;
+};
+
 struct PhaseEvent {
     int phase;
     hipEvent_t e0, e1;
@@ -56,6 +67,8 @@ struct sgl_ctx {
     hipStream_t stream = nullptr;
 
     DevCSC A, At;  // A: genes x local cells; At: local cells x genes
+    DevTiled TA, TAt;  // re-blocked streams of A / At for the current k (k <= 64)
+    bool use_tiled = false;
     int64_t cell_offset = 0, ncells_total = 0;
     int64_t* col_nnz_A = nullptr;   // n_local: nnz per cell (skip rule of predict, l.340)
     int64_t* col_nnz_At = nullptr;  // m: GLOBAL nnz per gene (after all-reduce when sharded)
@@ -119,6 +132,11 @@ int k_transpose_dense(hipStream_t s, const double* in, int rows, int cols, doubl
 // sparse accumulate: B[:, c] (+)= sum_{nz in tile t of column c} x * F[:, row]
 int k_acc(hipStream_t s, const DevCSC& M, const double* F, int k, double* B,
           uint64_t mask_seed, uint64_t inv_density, int mask_mode, int64_t mask_col_offset, int64_t mask_row_offset);
+
+// LDS-tiled accumulate
+void sgl_tiled_free(DevTiled& S);
+int sgl_tiled_build(sgl_ctx* c, const DevCSC& M, int k, DevTiled& S);
+int k_acc_tiled(hipStream_t s, const DevTiled& S, const double* F, double* B);
 
 // NNLS
 int k_nnls_lane(hipStream_t s, const double* Gpad, int KP, const double* B, double* X, const int64_t* col_nnz,

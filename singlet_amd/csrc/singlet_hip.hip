@@ -9,6 +9,7 @@
 #include <string.h>
 #include <algorithm>
 #include <string>
+#include <stdlib.h>
 
 // ------------------------------------------------------------------ errors --
 static thread_local char g_err[1024] = "";
@@ -143,6 +144,9 @@ static void free_fit(sgl_ctx* c) {
     dev_free(c->Gpad);
     dev_free(c->A.seg);
     dev_free(c->At.seg);
+    sgl_tiled_free(c->TA);
+    sgl_tiled_free(c->TAt);
+    c->use_tiled = false;
     c->k = 0;
 }
 
@@ -384,9 +388,9 @@ extern "C" int sgl_fit_init(sgl_ctx* c, int32_t k, const double* w_init, uint64_
     free_fit(c);
     const int64_t m = c->A.nrow, n = c->A.ncol;
     c->k = k;
-    SGLCHK(dev_alloc(&c->W, (size_t)k * m));
+    SGLCHK(dev_alloc(&c->W, (size_t)k * m + 2));
     SGLCHK(dev_alloc(&c->Wprev, (size_t)k * m));
-    SGLCHK(dev_alloc(&c->H, (size_t)k * n));
+    SGLCHK(dev_alloc(&c->H, (size_t)k * n + 2));
     SGLCHK(dev_alloc(&c->d, (size_t)k));
     SGLCHK(dev_alloc(&c->B, (size_t)k * n));
     SGLCHK(dev_alloc(&c->red, (size_t)k * m + (size_t)k * k + (size_t)k));
@@ -400,6 +404,13 @@ extern "C" int sgl_fit_init(sgl_ctx* c, int32_t k, const double* w_init, uint64_
     HIPCHK(hipMemcpyAsync(c->d, ones.data(), sizeof(double) * k, hipMemcpyHostToDevice, c->stream));
     SGLCHK(build_tiles(c, c->A, k));
     SGLCHK(build_tiles(c, c->At, k));
+    // LDS-tiled accumulate (lanes over the k factor rows): k <= 64
+    c->use_tiled = false;
+    if (k <= 64 && !getenv("SGL_NO_TILED")) {
+        SGLCHK(sgl_tiled_build(c, c->A, k, c->TA));
+        if (c->At.nnz > 0) SGLCHK(sgl_tiled_build(c, c->At, k, c->TAt));
+        c->use_tiled = true;
+    }
     // global per-gene non-zero counts decide which W columns predict() skips (l.340)
     if (c->allreduce && !c->gene_nnz_global) {
         double* tmp = nullptr;  // counts as doubles through the f64 all-reduce hook (exact below 2^53)
@@ -456,7 +467,9 @@ extern "C" int sgl_step_h(sgl_ctx* c, double L1, double L2) {
     FIT_GUARD(c);
     const int k = c->k;
     { Phase ph(c, SGL_PH_GRAM); SGLCHK(k_gram(c, c->W, k, c->A.nrow, c->G, 1e-15)); }
-    { Phase ph(c, SGL_PH_RHS_H); SGLCHK(k_acc(c->stream, c->A, c->W, k, c->B, 0, 1, 0, 0, 0)); }
+    { Phase ph(c, SGL_PH_RHS_H);
+      if (c->use_tiled) SGLCHK(k_acc_tiled(c->stream, c->TA, c->W, c->B));
+      else SGLCHK(k_acc(c->stream, c->A, c->W, k, c->B, 0, 1, 0, 0, 0)); }
     { Phase ph(c, SGL_PH_NNLS_H);
       SGLCHK(nnls_shared(c, c->G, c->B, c->H, c->col_nnz_A, c->A.ncol, L1, L2, c->sweep_counters + 0)); }
     return SGL_OK;
@@ -479,7 +492,9 @@ extern "C" int sgl_step_w(sgl_ctx* c, double L1, double L2) {
     const int64_t m = c->A.nrow;
     double* Bw = c->red;
     double* Gh = c->red + (size_t)k * m;
-    { Phase ph(c, SGL_PH_RHS_W); SGLCHK(k_acc(c->stream, c->At, c->H, k, Bw, 0, 1, 0, 0, 0)); }
+    { Phase ph(c, SGL_PH_RHS_W);
+      if (c->use_tiled && c->TAt.roff) SGLCHK(k_acc_tiled(c->stream, c->TAt, c->H, Bw));
+      else SGLCHK(k_acc(c->stream, c->At, c->H, k, Bw, 0, 1, 0, 0, 0)); }
     { Phase ph(c, SGL_PH_GRAM); SGLCHK(k_gram(c, c->H, k, c->A.ncol, Gh, 0.0)); }
     SGLCHK(do_allreduce(c, c->red, (int64_t)k * m + (int64_t)k * k));
     { Phase ph(c, SGL_PH_GRAM);
