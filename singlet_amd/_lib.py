@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsinglet_hip.so")
+LIB_PATH = os.environ.get("SGL_LIB_PATH", os.path.join(_HERE, "libsinglet_hip.so"))  # override: kernel ablation builds only
 
 SGL_PH_NAMES = ("gram", "rhs_h", "nnls_h", "rhs_w", "nnls_w", "scale", "comm", "mask")
 SGL_PH_COUNT = len(SGL_PH_NAMES)

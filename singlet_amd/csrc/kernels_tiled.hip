@@ -5,21 +5,31 @@
 // Why: every non-zero needs k doubles of F (400 B at k = 50) against 12 B of
 // matrix data, so the accumulate is bound by operand delivery, not by the HBM
 // stream.  L2 delivers ~34 TB/s chip-wide, LDS ~150 TB/s.
+// Measured on MI355X (scripts/ubench/lds_rate.hip): the LDS retires one wave
+// instruction per ~1.7 ns per CU whether it is ds_read_b64 or ds_read_b128, so
+// the kernel is built around ds_read_b128: a lane reads TWO consecutive factor
+// rows of F, 32 lanes cover k <= 64, and the two half-waves work on two
+// different non-zeros at once (two non-zeros per LDS instruction).
 //
 // Layout ("re-blocked stream", built once per (matrix, k) by sgl_tiled_build):
-//   * rows are cut into tiles of TR rows, TR * k * 8 B <= 128 KiB (one LDS tile);
-//   * columns are cut into wave blocks of CW = 64 columns; a workgroup of 8 waves
-//     owns 8 * CW columns and keeps their k-vectors in VGPRs (lane = factor
-//     row, one f64 accumulator per column slot) across all row tiles;
-//   * the non-zeros of (wave block wb, tile t) form one chunk, stored slot by
-//     slot, each slot's run padded to a multiple of 4 entries and the chunk to
-//     a multiple of 64 (x = 0 pads), as two coalesced arrays: roff (byte offset
-//     of the row inside the LDS tile) and x.  Chunks are ordered (wb, t), so
-//     one wave reads ONE linear stream;
-//   * cnt[(wb * T + t) * CW + s] = number of 4-entry groups of slot s (the
-//     chunk padding is booked on the last slot).
-// Order of summation inside a column is the stored (ascending row) order, as in
-// the reference; pads add x = 0 times a finite F entry.
+//   * rows are cut into tiles of TR rows, TR * KS * 8 B <= 128 KiB (one LDS
+//     tile; KS = k rounded up to even so every row starts 16-byte aligned);
+//   * columns are cut into wave blocks of 64 columns; a workgroup of 8 waves
+//     owns 512 columns and keeps their k-vectors in VGPRs across all row tiles.
+//     Lanes 0-31 of a wave accumulate column p of the block, lanes 32-63 column
+//     32 + p ("column pair" p = 0..31), lane l holding factors 2(l&31), +1;
+//   * per (wave block wb, tile t) -- a chunk -- the entries of the pair's two
+//     columns are stored as two half-streams that advance in lockstep: the runs
+//     of both columns are padded (x = 0 entries) to the same multiple of 4, the
+//     chunk to a multiple of 32 entries per half.  64 consecutive stream slots
+//     hold 32 entries of the A half then 32 of the B half, so one coalesced
+//     64-lane load fetches a "set".  Two arrays: roff (byte offset of the row
+//     inside the LDS tile) and x.  Chunks are ordered (wb, t): one wave reads
+//     ONE linear stream;
+//   * cnt[(wb * T + t) * 32 + p] = number of 4-entry groups of pair p (chunk
+//     padding is booked on the last pair).
+// Inside a column the products are added in stored (ascending row) order, as
+// in the reference; pads add x = 0 times a finite F entry.
 //
 // When the column count is too small to fill the chip (W-update: 30 k genes)
 // the tile range is split over blockIdx.y; each split writes a partial k x ncol
@@ -29,52 +39,41 @@
 #include <type_traits>
 
 #define TILED_NW 8           // waves per workgroup (512 threads -> 256 VGPRs per lane)
-#define TILED_CW 64          // column slots (FP64 accumulators) per wave
+#define TILED_CW 64          // columns per wave
+#define TILED_NP 32          // column pairs per wave
 #define TILED_LDS_BYTES (128 * 1024)
 
-template <typename F, int... Is>
-__device__ __forceinline__ void t_static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
-    (f(std::integral_constant<int, Is>{}), ...);
-}
-template <int N, typename F>
-__device__ __forceinline__ void t_static_for(F&& f) {
-    t_static_for_impl(f, std::make_integer_sequence<int, N>{});
-}
-
-__device__ __forceinline__ double t_readlane_f64(double v, int lane) {
-    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
-    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u & 0xffffffffull), lane);
-    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), lane);
-    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-}
-
 // ---------------------------------------------------------------- build -----
-// groups per (wb, t, slot) and entries per chunk
-__global__ void tiled_count_kernel(const int64_t* __restrict__ seg, int64_t ncol, int T, int CW, int64_t nwb,
+// groups per (wb, t, pair) and entries per chunk
+__global__ void tiled_count_kernel(const int64_t* __restrict__ seg, int64_t ncol, int T, int64_t nwb,
                                    uint8_t* __restrict__ cnt, int64_t* __restrict__ chunk_entries) {
     const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // u = wb * T + t
     if (u >= nwb * T) return;
     const int64_t wb = u / T;
     const int t = (int)(u - wb * T);
     int64_t tot = 0;
-    for (int s = 0; s < CW; ++s) {
-        const int64_t col = wb * CW + s;
-        int g = 0;
-        if (col < ncol) {
-            const int64_t c = seg[(int64_t)(t + 1) * ncol + col] - seg[(int64_t)t * ncol + col];
-            g = (int)((c + 3) >> 2);
+    for (int p = 0; p < TILED_NP; ++p) {
+        int64_t n = 0;
+        for (int h = 0; h < 2; ++h) {
+            const int64_t col = wb * TILED_CW + h * TILED_NP + p;
+            if (col < ncol) {
+                const int64_t c = seg[(int64_t)(t + 1) * ncol + col] - seg[(int64_t)t * ncol + col];
+                n = c > n ? c : n;
+            }
         }
-        if (s == CW - 1) g += (int)((16 - ((tot + g) & 15)) & 15);  // chunk = whole 64-entry steps
-        cnt[u * CW + s] = (uint8_t)g;
+        int g = (int)((n + 3) >> 2);
+        if (p == TILED_NP - 1) g += (int)((8 - ((tot + g) & 7)) & 7);  // half-stream = whole 32-entry steps
+        cnt[u * TILED_NP + p] = (uint8_t)g;
         tot += g;
     }
-    chunk_entries[u] = tot * 4;
+    chunk_entries[u] = tot * 8;  // both halves
 }
 
-// one wave per chunk (wb, t): copy / pad the CW segments
+// one wave per chunk (wb, t): copy / pad the runs of the 32 column pairs
 __global__ __launch_bounds__(256) void tiled_fill_kernel(const double* __restrict__ x, const int32_t* __restrict__ idx,
-                                                         const int64_t* __restrict__ seg, int64_t ncol, int T, int CW,
-                                                         int64_t nwb, int TR, int k, const uint8_t* __restrict__ cnt,
+                                                         const int64_t* __restrict__ seg, int64_t ncol, int T,
+                                                         int64_t nwb, int TR, int row_bytes,
+                                                         const uint8_t* __restrict__ cnt,
                                                          const int64_t* __restrict__ cstart,
                                                          uint32_t* __restrict__ sroff, double* __restrict__ sx) {
     const int lane = threadIdx.x & 63;
@@ -83,23 +82,29 @@ __global__ __launch_bounds__(256) void tiled_fill_kernel(const double* __restric
     for (int64_t u = gw; u < nwb * T; u += nw) {
         const int64_t wb = u / T;
         const int t = (int)(u - wb * T);
-        int64_t dst = cstart[u];
-        for (int s = 0; s < CW; ++s) {
-            const int n4 = 4 * (int)cnt[u * CW + s];
+        const int64_t c0 = cstart[u];
+        int P = 0;  // position in the half-streams
+        for (int p = 0; p < TILED_NP; ++p) {
+            const int n4 = 4 * (int)cnt[u * TILED_NP + p];
             if (n4 == 0) continue;
-            const int64_t col = wb * CW + s;
-            const int64_t a = seg[(int64_t)t * ncol + col], b = seg[(int64_t)(t + 1) * ncol + col];
-            for (int q = lane; q < n4; q += 64) {
-                uint32_t ro = 0;
-                double xv = 0.0;
-                if (a + q < b) {
-                    ro = (uint32_t)(idx[a + q] - t * TR) * (uint32_t)(k * 8);
-                    xv = x[a + q];
+            for (int h = 0; h < 2; ++h) {
+                const int64_t col = wb * TILED_CW + h * TILED_NP + p;
+                int64_t a = 0, b = 0;
+                if (col < ncol) { a = seg[(int64_t)t * ncol + col]; b = seg[(int64_t)(t + 1) * ncol + col]; }
+                for (int q = lane; q < n4; q += 64) {
+                    uint32_t ro = 0;
+                    double xv = 0.0;
+                    if (a + q < b) {
+                        ro = (uint32_t)(idx[a + q] - t * TR) * (uint32_t)row_bytes;
+                        xv = x[a + q];
+                    }
+                    const int pos = P + q;
+                    const int64_t dst = c0 + (int64_t)(pos >> 5) * 64 + h * 32 + (pos & 31);
+                    sroff[dst] = ro;
+                    sx[dst] = xv;
                 }
-                sroff[dst + q] = ro;
-                sx[dst + q] = xv;
             }
-            dst += n4;
+            P += n4;
         }
     }
 }
@@ -131,10 +136,11 @@ int sgl_tiled_build(sgl_ctx* c, const DevCSC& M, int k, DevTiled& S) {
     hipStream_t s = c->stream;
     S.k = k;
     S.CW = TILED_CW;
-    int TR = TILED_LDS_BYTES / (k * 8);
+    const int KS = (k + 1) & ~1;  // LDS row stride in doubles: rows start 16-byte aligned
+    int TR = TILED_LDS_BYTES / (KS * 8);
     TR = TR / 8 * 8;
-    if (TR > 952) TR = 952;  // groups per slot (+ <= 15 chunk-padding groups) must fit a byte
-    if (TR < 8) { sgl_set_error("tiled accumulate: k=%d too large", k); return SGL_EINVAL; }
+    if (TR > 984) TR = 984;  // groups per pair (+ <= 7 chunk-padding groups) must fit a byte
+    if (TR < 8 || k > 64) { sgl_set_error("tiled accumulate: k=%d unsupported", k); return SGL_EINVAL; }
     S.TR = TR;
     S.T = (int)((M.nrow + TR - 1) / TR);
     S.nwb = ((int64_t)M.ncol + S.CW - 1) / S.CW;
@@ -151,11 +157,11 @@ int sgl_tiled_build(sgl_ctx* c, const DevCSC& M, int k, DevTiled& S) {
     int rc = k_build_segments(s, tmp);
     int64_t* chunk_entries = nullptr;
     if (rc == SGL_OK) rc = t_alloc(&chunk_entries, (size_t)nchunks);
-    if (rc == SGL_OK) rc = t_alloc(&S.cnt, (size_t)nchunks * S.CW);
+    if (rc == SGL_OK) rc = t_alloc(&S.cnt, (size_t)nchunks * TILED_NP);
     if (rc == SGL_OK) rc = t_alloc(&S.cstart, (size_t)nchunks + 1);
     if (rc == SGL_OK) {
-        tiled_count_kernel<<<dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, s>>>(tmp.seg, M.ncol, S.T, S.CW, S.nwb,
-                                                                                         S.cnt, chunk_entries);
+        tiled_count_kernel<<<dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, s>>>(tmp.seg, M.ncol, S.T, S.nwb, S.cnt,
+                                                                                         chunk_entries);
         if (hipGetLastError() != hipSuccess) rc = SGL_EHIP;
     }
     if (rc == SGL_OK) rc = k_exclusive_scan(c, chunk_entries, S.cstart, nchunks);
@@ -166,17 +172,17 @@ int sgl_tiled_build(sgl_ctx* c, const DevCSC& M, int k, DevTiled& S) {
             hipStreamSynchronize(s) != hipSuccess) rc = SGL_EHIP;
     }
     S.E = E;
-    // + 256 entries of slack: the kernel prefetches a 64-entry batch past the end
-    if (rc == SGL_OK) rc = t_alloc(&S.roff, (size_t)E + 256);
-    if (rc == SGL_OK) rc = t_alloc(&S.x, (size_t)E + 256);
+    // + 512 entries of slack: the kernel prefetches four 64-entry sets past the end
+    if (rc == SGL_OK) rc = t_alloc(&S.roff, (size_t)E + 512);
+    if (rc == SGL_OK) rc = t_alloc(&S.x, (size_t)E + 512);
     if (rc == SGL_OK) {
-        if (hipMemsetAsync(S.roff + E, 0, 256 * sizeof(uint32_t), s) != hipSuccess ||
-            hipMemsetAsync(S.x + E, 0, 256 * sizeof(double), s) != hipSuccess) rc = SGL_EHIP;
+        if (hipMemsetAsync(S.roff + E, 0, 512 * sizeof(uint32_t), s) != hipSuccess ||
+            hipMemsetAsync(S.x + E, 0, 512 * sizeof(double), s) != hipSuccess) rc = SGL_EHIP;
     }
     if (rc == SGL_OK && nchunks > 0) {
         int64_t blocks = (nchunks + 3) / 4;
         if (blocks > 256 * 64) blocks = 256 * 64;
-        tiled_fill_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(M.x, M.i, tmp.seg, M.ncol, S.T, S.CW, S.nwb, TR, k,
+        tiled_fill_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(M.x, M.i, tmp.seg, M.ncol, S.T, S.nwb, TR, KS * 8,
                                                                        S.cnt, S.cstart, S.roff, S.x);
         if (hipGetLastError() != hipSuccess) rc = SGL_EHIP;
     }
@@ -206,30 +212,46 @@ int sgl_tiled_build(sgl_ctx* c, const DevCSC& M, int k, DevTiled& S) {
 }
 
 // ---------------------------------------------------------------- kernel ----
-// Broadcasting the wave-uniform (roff, x) of each non-zero is the VALU cost
-// that decides this kernel: three v_readlane per non-zero cost ~30 cycles
-// (measured on MI355X: VALU-bound at 35 cyc/nz/SIMD).  Instead every 16-lane
-// ROW of the wave holds the same 16 entries (lane l loads entry l & 15), and
-// DPP row_newbcast:j -- the only DPP mode gfx950 allows on FP64 ALU ops --
-// feeds entry j to all lanes inside the consuming instruction itself:
-//     v_add_u32_dpp  addr, roff, lane*8   row_newbcast:j     (LDS address)
-//     ds_read_b64    w, addr                                (F[lane, row])
-//     v_fmac_f64_dpp acc, x, w            row_newbcast:j     (acc += x_j * w)
-// Two VALU instructions per non-zero; the kernel is then bound by the
-// ds_read_b64 rate (2 cycles per wave instruction per CU).
+// Broadcasting the (roff, x) of each entry to the 32 lanes that work on it is
+// the VALU cost that decides this kernel: three v_readlane per non-zero cost
+// ~30 cycles (measured: VALU-bound at 35 cyc/nz/SIMD).  Instead the 16-lane
+// ROWS of the wave hold 16 entries each -- rows 0,1 the same 16 entries of the A
+// half, rows 2,3 sixteen of the B half -- and DPP row_newbcast:j (the only DPP
+// mode gfx950 allows on FP64 ALU ops) feeds entry j to all lanes of its rows
+// inside the consuming instruction itself:
+//     v_add_u32_dpp  addr, roff, lane16        row_newbcast:j   (LDS address)
+//     ds_read_b128   w, addr                                   (F[2l, 2l+1 ; row])
+//     v_fmac_f64_dpp acc0, x, w.x              row_newbcast:j   (acc += x_j * w)
+//     v_fmac_f64_dpp acc1, x, w.y              row_newbcast:j
+// A 64-entry set (one coalesced load per array) becomes two such 16-pair
+// batches with ONE v_permlane16_swap per dword: rows [A0 A1 B0 B1] ->
+// [A0 A0 B0 B0] and [A1 A1 B1 B1].
 //
-// The wave walks its stream in 16-entry batches, four statically named batch
-// register sets in flight (loaded by inline asm right after a set is consumed,
-// waited with a counted vmcnt: loads return in order).  The column slot of a
-// 4-entry group is dynamic, so the running accumulator `a` is swapped with the
-// slot's home register (a uniform-indexed VGPR array, s_set_gpr_idx) only
-// when the slot changes.  The loop body is a few hundred instructions.
-typedef double d16 __attribute__((ext_vector_type(16)));
+// Register plan.  The 32 pairs x 2 FP64 accumulators of a wave live in
+// v[128:255], OUTSIDE the compiler's register allocation: the kernel is
+// compiled with amdgpu_num_vgpr(128) and an asm clobber of v255 makes the
+// kernel descriptor allocate all 256.  The running pair's accumulators are
+// swapped with their home registers through VGPR index mode
+// (s_set_gpr_idx_on: M0 = 4 * pair is added to the register number) only when
+// the pair changes.  Letting hipcc index a register array dynamically was tried
+// first: it either moved the array to scratch memory or copied whole
+// 32-register vectors around every slot change.
+//
+// Four statically named stream sets are in flight per wave (3 KiB), loaded by
+// inline asm right after a set is consumed and waited with a counted vmcnt
+// (loads return in order); which set is next is the wave-uniform `phase`.
+typedef double d2_t __attribute__((ext_vector_type(2)));
+
+#ifdef TILED_ABL_NOSTREAM  // ablation build: never refill the stream registers (wrong results, timing only)
+#define TILED_ABL_LOAD(...) do { if (pos < 256) asm volatile(__VA_ARGS__); } while (0)
+#else
+#define TILED_ABL_LOAD(...) asm volatile(__VA_ARGS__)
+#endif
 
 template <int J>
-__device__ __forceinline__ int dpp_addr(uint32_t roff, int lane8) {
+__device__ __forceinline__ int dpp_addr(uint32_t roff, int lane_off) {
     int a;
-    asm("v_add_u32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(a) : "v"(roff), "v"(lane8), "n"(J));
+    asm("v_add_u32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(a) : "v"(roff), "v"(lane_off), "n"(J));
     return a;
 }
 template <int J>
@@ -237,67 +259,62 @@ __device__ __forceinline__ void dpp_fmac(double& acc, double x, double w) {
     asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(w), "n"(J));
 }
 
-// Accumulator home registers.  The 64 FP64 accumulators of a wave live in v[128:255], OUTSIDE the
-// compiler's register allocation: the kernel is compiled with amdgpu_num_vgpr(128) (hipcc may only
-// use v0..v127) and an asm clobber of v255 makes the kernel descriptor allocate all 256.  They are
-// reached with VGPR index mode (s_set_gpr_idx_on: M0 = 2 * slot is added to the register number), the
-// one form of dynamic register addressing the ISA has.  Letting hipcc index a register array
-// dynamically was tried first: it either moved the array to scratch memory or copied whole
-// 32-register vectors around every slot change.
-__device__ __forceinline__ void acc_store(int slot2, double v) {
-    asm volatile("s_set_gpr_idx_on %0, gpr_idx(DST)\n\tv_mov_b32 v128, %1\n\tv_mov_b32 v129, %2\n\ts_set_gpr_idx_off"
-                 :: "s"(slot2), "v"(__double2loint(v)), "v"(__double2hiint(v)) : "memory");
+__device__ __forceinline__ void acc_store(int idx4, double v0, double v1) {
+    asm volatile(
+        "s_set_gpr_idx_on %0, gpr_idx(DST)\n\tv_mov_b32 v128, %1\n\tv_mov_b32 v129, %2\n\tv_mov_b32 v130, %3\n\t"
+        "v_mov_b32 v131, %4\n\ts_set_gpr_idx_off"
+        :: "s"(idx4), "v"(__double2loint(v0)), "v"(__double2hiint(v0)), "v"(__double2loint(v1)), "v"(__double2hiint(v1))
+        : "memory");
 }
-__device__ __forceinline__ double acc_load(int slot2) {
-    int lo, hi;
-    asm volatile("s_set_gpr_idx_on %2, gpr_idx(SRC0)\n\tv_mov_b32 %0, v128\n\tv_mov_b32 %1, v129\n\ts_set_gpr_idx_off"
-                 : "=v"(lo), "=v"(hi) : "s"(slot2) : "memory");
-    return __hiloint2double(hi, lo);
+__device__ __forceinline__ void acc_load(int idx4, double& v0, double& v1) {
+    int a, b, c, d;
+    asm volatile(
+        "s_set_gpr_idx_on %4, gpr_idx(SRC0)\n\tv_mov_b32 %0, v128\n\tv_mov_b32 %1, v129\n\tv_mov_b32 %2, v130\n\t"
+        "v_mov_b32 %3, v131\n\ts_set_gpr_idx_off"
+        : "=v"(a), "=v"(b), "=v"(c), "=v"(d) : "s"(idx4) : "memory");
+    v0 = __hiloint2double(b, a);
+    v1 = __hiloint2double(d, c);
 }
-template <int CW>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(128))) void acc_tiled_kernel(const uint32_t* __restrict__ sroff, const double* __restrict__ sx,
-                                                        const int64_t* __restrict__ cstart,
-                                                        const uint8_t* __restrict__ cnt, int T, int64_t nwb,
-                                                        const double* __restrict__ F, int k, int TR, int64_t nrow,
-                                                        int tiles_per_range, double* __restrict__ Bout, int64_t ncol) {
-    static_assert(CW == 64, "accumulators are v[128:255]");
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(128))) void acc_tiled_kernel(
+    const uint32_t* __restrict__ sroff, const double* __restrict__ sx, const int64_t* __restrict__ cstart,
+    const uint8_t* __restrict__ cnt, int T, int64_t nwb, const double* __restrict__ F, int k, int TR, int64_t nrow,
+    int tiles_per_range, double* __restrict__ Bout, int64_t ncol) {
     asm volatile("" ::: "v255");  // make the kernel descriptor allocate 256 VGPRs
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* tile = reinterpret_cast<double*>(smem);
     const int lane = threadIdx.x & 63;
-    const int l16 = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t wb = (int64_t)blockIdx.x * TILED_NW + wave;
     const int t0 = blockIdx.y * tiles_per_range;
     const int t1 = (t0 + tiles_per_range < T) ? (t0 + tiles_per_range) : T;
     const bool wact = wb < nwb;
-    // LDS byte address of this lane's factor row inside the tile (raw 32-bit LDS addresses are used
-    // below so that no per-entry base add is emitted)
+    const int KS = (k + 1) & ~1;
+    // LDS byte address of this lane's pair of factor rows inside a tile row (raw 32-bit LDS addresses
+    // are used below so that no per-entry base add is emitted)
     typedef __attribute__((address_space(3))) char lds_char;
-    typedef __attribute__((address_space(3))) const double lds_cdouble;
-    const int lane8 = (int)(uint32_t)(uintptr_t)(lds_char*)smem + lane * 8;
+    typedef __attribute__((address_space(3))) const d2_t lds_cd2;
+    const int lane16 = (int)(uint32_t)(uintptr_t)(lds_char*)smem + (lane & 31) * 16;
 
-    for (int q = 0; q < CW; ++q) acc_store(2 * q, 0.0);
+    for (int p = 0; p < TILED_NP; ++p) acc_store(4 * p, 0.0, 0.0);
 
-    int64_t pos = 0;   // stream position (entries) of the next batch to LOAD
+    int64_t pos = 0;   // stream position (entries) of the next set to LOAD
     int cnt_next = 0;
     if (wact) {
         pos = cstart[wb * T + t0];
-        cnt_next = (int)cnt[(wb * T + t0) * CW + lane];
+        if (lane < TILED_NP) cnt_next = (int)cnt[(wb * T + t0) * TILED_NP + lane];
     }
-    // four batch register sets; set q always holds batch (4*i + q) of the stream.  (Plain named
-    // variables and macros, no lambdas: a by-reference capture of the accumulator vectors makes
-    // them escape and land in scratch memory.)
     uint32_t er0 = 0, er1 = 0, er2 = 0, er3 = 0;
     double ex0 = 0.0, ex1 = 0.0, ex2 = 0.0, ex3 = 0.0;
 #define TILED_ISSUE(ER, EX)                                                                       \
     do {                                                                                          \
-        const uint32_t* pr_ = sroff + (pos + l16);                                                \
-        const double* px_ = sx + (pos + l16);                                                     \
-        asm volatile("global_load_dword %0, %1, off" : "=v"(ER) : "v"(pr_) : "memory");          \
-        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(EX) : "v"(px_) : "memory");        \
-        pos += 16;                                                                                \
+        const uint32_t* pr_ = sroff + (pos + lane);                                               \
+        const double* px_ = sx + (pos + lane);                                                    \
+        TILED_ABL_LOAD("global_load_dword %0, %1, off" : "=v"(ER) : "v"(pr_) : "memory");        \
+        TILED_ABL_LOAD("global_load_dwordx2 %0, %1, off" : "=v"(EX) : "v"(px_) : "memory");      \
+        pos += 64;                                                                                \
     } while (0)
+    int phase = 0;
     if (wact) {
         TILED_ISSUE(er0, ex0);
         TILED_ISSUE(er1, ex1);
@@ -306,107 +323,137 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(128))) void acc
     }
 
     for (int t = t0; t < t1; ++t) {
-        const int cntv = cnt_next;  // lane s: 4-entry groups of slot s in this tile
-        if (wact && t + 1 < t1) cnt_next = (int)cnt[(wb * T + t + 1) * CW + lane];
-        int tot = cntv;             // total groups of the chunk (a multiple of 16)
+        const int cntv = cnt_next;  // lane p < 32: 4-entry groups of pair p in this tile
+        if (wact && t + 1 < t1 && lane < TILED_NP) cnt_next = (int)cnt[(wb * T + t + 1) * TILED_NP + lane];
+        int tot = cntv;             // total groups of the chunk (a multiple of 8)
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off, 64);
-        const int nb = __builtin_amdgcn_readfirstlane(tot) >> 2;  // 16-entry batches, a multiple of 4
+        int nsets = __builtin_amdgcn_readfirstlane(tot) >> 3;  // 64-entry sets (32 per half) of this chunk
 
-        // stage rows [t*TR, ...) of F (contiguous k*rows doubles) into LDS
+        // stage rows [t*TR, ...) of F into LDS, row stride KS doubles
         const int64_t row0 = (int64_t)t * TR;
         const int rows = (int)((nrow - row0 < TR) ? (nrow - row0) : TR);
         const int n = rows * k;
         const double* __restrict__ src = F + row0 * k;
-        // Each thread moves up to NST 16-byte pieces of the tile, in two rounds of NST/2.  Round 1
-        // loads are issued before the barrier (they overlap the tail of the previous tile's work of
-        // other waves).  Reading one double past an odd-sized tile is harmless: factor buffers carry
-        // 2 doubles of slack, the LDS tile 512 B.
-        constexpr int NST = TILED_LDS_BYTES / 16 / (64 * TILED_NW);
-        constexpr int HST = NST / 2;
-        double2 stg[HST];
+        if (KS == k) {
+            // Each thread moves up to NST 16-byte pieces of the (contiguous) tile, in two rounds of
+            // NST/2.  Round 1 loads are issued before the barrier (they overlap the tail of the previous
+            // tile's work of other waves).
+            constexpr int NST = TILED_LDS_BYTES / 16 / (64 * TILED_NW);
+            constexpr int HST = NST / 2;
+            double2 stg[HST];
 #pragma unroll
-        for (int j = 0; j < HST; ++j) {
-            const int e = ((int)threadIdx.x + j * 64 * TILED_NW) * 2;
-            stg[j] = double2{0.0, 0.0};
-            if (e < n) stg[j] = *reinterpret_cast<const double2*>(src + e);
-        }
-        __syncthreads();  // everyone is done reading the previous tile
+            for (int j = 0; j < HST; ++j) {
+                const int e = ((int)threadIdx.x + j * 64 * TILED_NW) * 2;
+                stg[j] = double2{0.0, 0.0};
+                if (e < n) stg[j] = *reinterpret_cast<const double2*>(src + e);
+            }
+#ifdef TILED_ABL_NOSTAGE  // ablation build: stage only the first tile (wrong results, timing only)
+            if (t > t0) goto staged;
+#endif
+            __syncthreads();  // everyone is done reading the previous tile
 #pragma unroll
-        for (int j = 0; j < HST; ++j) {
-            const int e = ((int)threadIdx.x + j * 64 * TILED_NW) * 2;
-            if (e < n) *reinterpret_cast<double2*>(tile + e) = stg[j];
-        }
+            for (int j = 0; j < HST; ++j) {
+                const int e = ((int)threadIdx.x + j * 64 * TILED_NW) * 2;
+                if (e < n) *reinterpret_cast<double2*>(tile + e) = stg[j];
+            }
 #pragma unroll
-        for (int j = 0; j < HST; ++j) {
-            const int e = ((int)threadIdx.x + (j + HST) * 64 * TILED_NW) * 2;
-            stg[j] = double2{0.0, 0.0};
-            if (e < n) stg[j] = *reinterpret_cast<const double2*>(src + e);
-        }
+            for (int j = 0; j < HST; ++j) {
+                const int e = ((int)threadIdx.x + (j + HST) * 64 * TILED_NW) * 2;
+                stg[j] = double2{0.0, 0.0};
+                if (e < n) stg[j] = *reinterpret_cast<const double2*>(src + e);
+            }
 #pragma unroll
-        for (int j = 0; j < HST; ++j) {
-            const int e = ((int)threadIdx.x + (j + HST) * 64 * TILED_NW) * 2;
-            if (e < n) *reinterpret_cast<double2*>(tile + e) = stg[j];
+            for (int j = 0; j < HST; ++j) {
+                const int e = ((int)threadIdx.x + (j + HST) * 64 * TILED_NW) * 2;
+                if (e < n) *reinterpret_cast<double2*>(tile + e) = stg[j];
+            }
+        } else {
+            // odd k: rows are re-pitched to KS = k + 1 doubles (the pad column is never summed into a
+            // stored factor row: lane 2l+1 == k is not written out)
+            __syncthreads();
+            for (int e = (int)threadIdx.x; e < n; e += 64 * TILED_NW) {
+                const int r = e / k, f = e - r * k;
+                tile[r * KS + f] = src[e];
+            }
+            for (int r = (int)threadIdx.x; r < rows; r += 64 * TILED_NW) tile[r * KS + k] = 0.0;
         }
         __syncthreads();
+#ifdef TILED_ABL_NOSTAGE
+    staged:
+#endif
         if (!wact) continue;
 
         int s = -1, rem = 0;
-        double a = 0.0;
-        // One 16-entry batch: all 16 LDS addresses and ds_reads are issued first (16 reads in flight
-        // per wave keep the LDS pipe busy; with only 2 waves per SIMD a 4-deep group at a time is
-        // latency-bound: measured 8 cyc/nz/CU against the 2 cyc/nz/CU the LDS can do), the batch
-        // registers are refilled for four batches ahead, then the 16 FMAs follow in stored order with
-        // the (wave-uniform) column-slot bookkeeping in front of every 4-entry group.
-#define TILED_AW(J) \
-        const int a##J##_ = dpp_addr<J>(rr_, lane8); \
-        const double w##J##_ = *(lds_cdouble*)(uintptr_t)(uint32_t)a##J##_;
+        // running accumulators of pair s: factors 2(l&31), 2(l&31)+1.  (Splitting the run over two
+        // accumulator pairs to shorten the FMA dependency chain was measured: no gain.)
+        double a0 = 0.0, a1 = 0.0;
+        // pair bookkeeping in front of every 4-entry group (wave-uniform)
 #define TILED_SLOT()                                                                              \
     do {                                                                                          \
-        if (rem == 0) { /* next column slot (uniform) */                                          \
-            if (s >= 0) acc_store(2 * s, a);                                                      \
+        if (rem == 0) {                                                                           \
+            if (s >= 0) acc_store(4 * s, a0, a1);                                                 \
             do {                                                                                  \
                 ++s;                                                                              \
                 rem = __builtin_amdgcn_readlane(cntv, s);                                         \
             } while (rem == 0);                                                                   \
-            a = acc_load(2 * s);                                                                  \
+            acc_load(4 * s, a0, a1);                                                              \
         }                                                                                         \
         --rem;                                                                                    \
     } while (0)
-        // set q's two loads are complete once at most the six younger ones (the three other sets)
-        // remain; s_nop: keep any VALU write of a batch register two wait states from the DPP reads
+#define TILED_AW(J, RR) \
+        const int ad##J##_ = dpp_addr<J>(RR, lane16); \
+        const d2_t w##J##_ = *(lds_cd2*)(uintptr_t)(uint32_t)ad##J##_;
+#define TILED_FM(J, XX) dpp_fmac<J>(a0, XX, w##J##_.x); dpp_fmac<J>(a1, XX, w##J##_.y);
+        // eight entry pairs (row_newbcast lanes J0 .. J0+7): all eight LDS reads are issued before
+        // their FMAs
+#define TILED_OCT(J0, J1, J2, J3, J4, J5, J6, J7, RR, XX)                                         \
+    do {                                                                                          \
+        TILED_AW(J0, RR) TILED_AW(J1, RR) TILED_AW(J2, RR) TILED_AW(J3, RR)                       \
+        TILED_AW(J4, RR) TILED_AW(J5, RR) TILED_AW(J6, RR) TILED_AW(J7, RR)                       \
+        TILED_SLOT();                                                                             \
+        TILED_FM(J0, XX) TILED_FM(J1, XX) TILED_FM(J2, XX) TILED_FM(J3, XX)                       \
+        TILED_SLOT();                                                                             \
+        TILED_FM(J4, XX) TILED_FM(J5, XX) TILED_FM(J6, XX) TILED_FM(J7, XX)                       \
+    } while (0)
+        // the set's two loads are complete once at most the six younger ones (the three other sets)
+        // remain; the set registers pass THROUGH the wait so that no consumer can be scheduled above it
 #define TILED_SET(ER, EX)                                                                         \
     do {                                                                                          \
-        /* the batch registers pass THROUGH the wait, so no consumer can be scheduled above it */   \
-        asm volatile("s_waitcnt vmcnt(6)\n\ts_nop 1" : "+v"(ER), "+v"(EX) : : "memory");          \
-        const uint32_t rr_ = ER;                                                                  \
-        const double xx_ = EX;                                                                    \
-        TILED_AW(0) TILED_AW(1) TILED_AW(2) TILED_AW(3) TILED_AW(4) TILED_AW(5) TILED_AW(6) TILED_AW(7)       \
-        TILED_AW(8) TILED_AW(9) TILED_AW(10) TILED_AW(11) TILED_AW(12) TILED_AW(13) TILED_AW(14) TILED_AW(15) \
-        TILED_SLOT();                                                                             \
-        dpp_fmac<0>(a, xx_, w0_); dpp_fmac<1>(a, xx_, w1_); dpp_fmac<2>(a, xx_, w2_); dpp_fmac<3>(a, xx_, w3_);         \
-        TILED_SLOT();                                                                             \
-        dpp_fmac<4>(a, xx_, w4_); dpp_fmac<5>(a, xx_, w5_); dpp_fmac<6>(a, xx_, w6_); dpp_fmac<7>(a, xx_, w7_);         \
-        TILED_SLOT();                                                                             \
-        dpp_fmac<8>(a, xx_, w8_); dpp_fmac<9>(a, xx_, w9_); dpp_fmac<10>(a, xx_, w10_); dpp_fmac<11>(a, xx_, w11_);     \
-        TILED_SLOT();                                                                             \
-        dpp_fmac<12>(a, xx_, w12_); dpp_fmac<13>(a, xx_, w13_); dpp_fmac<14>(a, xx_, w14_); dpp_fmac<15>(a, xx_, w15_); \
-        TILED_ISSUE(ER, EX); /* refill this set with the batch four ahead */                      \
+        asm volatile("s_waitcnt vmcnt(6)" : "+v"(ER), "+v"(EX) : : "memory");                      \
+        const unsigned rv_ = ER;                                                                  \
+        const unsigned xl_ = (unsigned)__double2loint(EX), xh_ = (unsigned)__double2hiint(EX);    \
+        const auto pr2_ = __builtin_amdgcn_permlane16_swap(rv_, rv_, false, false);               \
+        const auto pl2_ = __builtin_amdgcn_permlane16_swap(xl_, xl_, false, false);               \
+        const auto ph2_ = __builtin_amdgcn_permlane16_swap(xh_, xh_, false, false);               \
+        TILED_ISSUE(ER, EX); /* refill this set with the 64 entries four sets ahead */            \
+        const unsigned ra_ = pr2_[0], rb_ = pr2_[1];                                              \
+        const double xa_ = __hiloint2double((int)ph2_[0], (int)pl2_[0]);                          \
+        const double xb_ = __hiloint2double((int)ph2_[1], (int)pl2_[1]);                          \
+        TILED_OCT(0, 1, 2, 3, 4, 5, 6, 7, ra_, xa_);                                              \
+        TILED_OCT(8, 9, 10, 11, 12, 13, 14, 15, ra_, xa_);                                        \
+        TILED_OCT(0, 1, 2, 3, 4, 5, 6, 7, rb_, xb_);                                              \
+        TILED_OCT(8, 9, 10, 11, 12, 13, 14, 15, rb_, xb_);                                        \
     } while (0)
-        for (int b = 0; b < nb; b += 4) {
-            TILED_SET(er0, ex0);
-            TILED_SET(er1, ex1);
-            TILED_SET(er2, ex2);
-            TILED_SET(er3, ex3);
+        while (nsets > 0) {
+            if (phase == 0) { TILED_SET(er0, ex0); phase = 1; if (--nsets == 0) break; }
+            if (phase == 1) { TILED_SET(er1, ex1); phase = 2; if (--nsets == 0) break; }
+            if (phase == 2) { TILED_SET(er2, ex2); phase = 3; if (--nsets == 0) break; }
+            if (phase == 3) { TILED_SET(er3, ex3); phase = 0; --nsets; }
         }
-        if (s >= 0) acc_store(2 * s, a);
+        if (s >= 0) acc_store(4 * s, a0, a1);
     }
     if (wact) {
         double* out = Bout + (size_t)blockIdx.y * (size_t)k * (size_t)ncol;
-        for (int q = 0; q < CW; ++q) {
-            const double v = acc_load(2 * q);
-            const int64_t col = wb * CW + q;
-            if (col < ncol && lane < k) out[col * k + lane] = v;
+        const int f = 2 * (lane & 31);
+        for (int p = 0; p < TILED_NP; ++p) {
+            double v0, v1;
+            acc_load(4 * p, v0, v1);
+            const int64_t col = wb * TILED_CW + p + ((lane >> 5) ? TILED_NP : 0);
+            if (col < ncol) {
+                if (f < k) out[col * k + f] = v0;
+                if (f + 1 < k) out[col * k + f + 1] = v1;
+            }
         }
     }
 }
@@ -421,16 +468,17 @@ __global__ void acc_tiled_reduce_kernel(const double* __restrict__ part, int R, 
 
 int k_acc_tiled(hipStream_t s, const DevTiled& S, const double* F, double* B) {
     if (S.ncol <= 0) return SGL_OK;
-    const size_t lds = (size_t)S.TR * S.k * 8 + 512;
+    const int KS = (S.k + 1) & ~1;
+    const size_t lds = (size_t)S.TR * KS * 8 + 512;
     static bool attr_set = false;
     if (!attr_set) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&acc_tiled_kernel<TILED_CW>),
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&acc_tiled_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, TILED_LDS_BYTES + 512));
         attr_set = true;
     }
     const int64_t nwg_x = (S.nwb + TILED_NW - 1) / TILED_NW;
     double* out = (S.R > 1) ? S.part : B;
-    acc_tiled_kernel<TILED_CW><<<dim3((unsigned)nwg_x, (unsigned)S.R), dim3(64 * TILED_NW), lds, s>>>(
+    acc_tiled_kernel<<<dim3((unsigned)nwg_x, (unsigned)S.R), dim3(64 * TILED_NW), lds, s>>>(
         S.roff, S.x, S.cstart, S.cnt, S.T, S.nwb, F, S.k, S.TR, S.nrow, S.tiles_per_range, out, S.ncol);
     HIPCHK(hipGetLastError());
     if (S.R > 1) {
