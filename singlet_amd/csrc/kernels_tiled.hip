@@ -276,7 +276,7 @@ __device__ __forceinline__ void acc_load(int idx4, double& v0, double& v1) {
     v1 = __hiloint2double(d, c);
 }
 
-__global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(128))) void acc_tiled_kernel(
+__global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(128), amdgpu_waves_per_eu(4, 4))) void acc_tiled_kernel(
     const uint32_t* __restrict__ sroff, const double* __restrict__ sx, const int64_t* __restrict__ cstart,
     const uint8_t* __restrict__ cnt, int T, int64_t nwb, const double* __restrict__ F, int k, int TR, int64_t nrow,
     int tiles_per_range, double* __restrict__ Bout, int64_t ncol) {
@@ -401,23 +401,25 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(128))) void acc
         }                                                                                         \
         --rem;                                                                                    \
     } while (0)
-#define TILED_AW(J, RR) \
-        const int ad##J##_ = dpp_addr<J>(RR, lane16); \
-        const d2_t w##J##_ = *(lds_cd2*)(uintptr_t)(uint32_t)ad##J##_;
-#define TILED_FM(J, XX) dpp_fmac<J>(a0, XX, w##J##_.x); dpp_fmac<J>(a1, XX, w##J##_.y);
-        // eight entry pairs (row_newbcast lanes J0 .. J0+7): all eight LDS reads are issued before
-        // their FMAs
-#define TILED_OCT(J0, J1, J2, J3, J4, J5, J6, J7, RR, XX)                                         \
-    do {                                                                                          \
-        TILED_AW(J0, RR) TILED_AW(J1, RR) TILED_AW(J2, RR) TILED_AW(J3, RR)                       \
-        TILED_AW(J4, RR) TILED_AW(J5, RR) TILED_AW(J6, RR) TILED_AW(J7, RR)                       \
+#define TILED_AW(T, J, RR) \
+        const int ad##T##J##_ = dpp_addr<J>(RR, lane16); \
+        const d2_t w##T##J##_ = *(lds_cd2*)(uintptr_t)(uint32_t)ad##T##J##_;
+#define TILED_FM(T, J, XX) dpp_fmac<J>(a0, XX, w##T##J##_.x); dpp_fmac<J>(a1, XX, w##T##J##_.y);
+        // eight entry pairs (row_newbcast lanes J0 .. J7): the eight ds_read_b128 of an octet ...
+#define TILED_RD(T, J0, J1, J2, J3, J4, J5, J6, J7, RR)                                           \
+        TILED_AW(T, J0, RR) TILED_AW(T, J1, RR) TILED_AW(T, J2, RR) TILED_AW(T, J3, RR)           \
+        TILED_AW(T, J4, RR) TILED_AW(T, J5, RR) TILED_AW(T, J6, RR) TILED_AW(T, J7, RR)
+        // ... and its sixteen FMAs, with the pair bookkeeping in front of each 4-entry group
+#define TILED_FMS(T, J0, J1, J2, J3, J4, J5, J6, J7, XX)                                          \
         TILED_SLOT();                                                                             \
-        TILED_FM(J0, XX) TILED_FM(J1, XX) TILED_FM(J2, XX) TILED_FM(J3, XX)                       \
+        TILED_FM(T, J0, XX) TILED_FM(T, J1, XX) TILED_FM(T, J2, XX) TILED_FM(T, J3, XX)           \
         TILED_SLOT();                                                                             \
-        TILED_FM(J4, XX) TILED_FM(J5, XX) TILED_FM(J6, XX) TILED_FM(J7, XX)                       \
-    } while (0)
-        // the set's two loads are complete once at most the six younger ones (the three other sets)
-        // remain; the set registers pass THROUGH the wait so that no consumer can be scheduled above it
+        TILED_FM(T, J4, XX) TILED_FM(T, J5, XX) TILED_FM(T, J6, XX) TILED_FM(T, J7, XX)
+        // The set's two loads are complete once at most the six younger ones (the three other sets)
+        // remain; the set registers pass THROUGH the wait so that no consumer can be scheduled above it.
+        // The four octets of a set are software-pipelined: the LDS reads of octet i+1 are issued before
+        // the FMAs of octet i (with 2 waves per SIMD, un-pipelined reads and FMAs were measured at 51 %
+        // LDS / 50 % VALU busy, i.e. running one after the other).
 #define TILED_SET(ER, EX)                                                                         \
     do {                                                                                          \
         asm volatile("s_waitcnt vmcnt(6)" : "+v"(ER), "+v"(EX) : : "memory");                      \
@@ -427,13 +429,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(128))) void acc
         const auto pl2_ = __builtin_amdgcn_permlane16_swap(xl_, xl_, false, false);               \
         const auto ph2_ = __builtin_amdgcn_permlane16_swap(xh_, xh_, false, false);               \
         TILED_ISSUE(ER, EX); /* refill this set with the 64 entries four sets ahead */            \
-        const unsigned ra_ = pr2_[0], rb_ = pr2_[1];                                              \
-        const double xa_ = __hiloint2double((int)ph2_[0], (int)pl2_[0]);                          \
-        const double xb_ = __hiloint2double((int)ph2_[1], (int)pl2_[1]);                          \
-        TILED_OCT(0, 1, 2, 3, 4, 5, 6, 7, ra_, xa_);                                              \
-        TILED_OCT(8, 9, 10, 11, 12, 13, 14, 15, ra_, xa_);                                        \
-        TILED_OCT(0, 1, 2, 3, 4, 5, 6, 7, rb_, xb_);                                              \
-        TILED_OCT(8, 9, 10, 11, 12, 13, 14, 15, rb_, xb_);                                        \
+        unsigned ra_ = pr2_[0], rb_ = pr2_[1];                                                    \
+        double xa_ = __hiloint2double((int)ph2_[0], (int)pl2_[0]);                                \
+        double xb_ = __hiloint2double((int)ph2_[1], (int)pl2_[1]);                                \
+        /* DPP hazard: a VALU write of a register (the swaps / pair-forming moves above) must be two  \
+           wait states ahead of a DPP read of it, and hipcc pads nothing around inline asm */      \
+        asm volatile("s_nop 1" : "+v"(ra_), "+v"(rb_), "+v"(xa_), "+v"(xb_));                      \
+        TILED_RD(p, 0, 1, 2, 3, 4, 5, 6, 7, ra_)                                                  \
+        TILED_RD(q, 8, 9, 10, 11, 12, 13, 14, 15, ra_)                                            \
+        TILED_FMS(p, 0, 1, 2, 3, 4, 5, 6, 7, xa_)                                                 \
+        TILED_RD(r, 0, 1, 2, 3, 4, 5, 6, 7, rb_)                                                  \
+        TILED_FMS(q, 8, 9, 10, 11, 12, 13, 14, 15, xa_)                                           \
+        TILED_RD(u, 8, 9, 10, 11, 12, 13, 14, 15, rb_)                                            \
+        TILED_FMS(r, 0, 1, 2, 3, 4, 5, 6, 7, xb_)                                                 \
+        TILED_FMS(u, 8, 9, 10, 11, 12, 13, 14, 15, xb_)                                           \
     } while (0)
         while (nsets > 0) {
             if (phase == 0) { TILED_SET(er0, ex0); phase = 1; if (--nsets == 0) break; }
