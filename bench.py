@@ -40,21 +40,6 @@ def parse():
     return ap.parse_args()
 
 
-class _DevView:
-    """__cuda_array_interface__ view of `count` doubles at a raw device pointer."""
-
-    def __init__(self, ptr, count):
-        self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr, False), "version": 2}
-
-
-def shard_range(ncells, world, rank):
-    """Contiguous, equal-count cell blocks (the synthetic columns are i.i.d., so equal counts
-    are equal non-zeros to within 0.1 %)."""
-    base, rem = divmod(ncells, world)
-    lo = rank * base + min(rank, rem)
-    return lo, base + (1 if rank < rem else 0)
-
-
 def cpu_baseline(args):
     """The oracle (restatement of singlet's OpenMP path) timed on this host's cores on a
     bounded sample: the first `cpu_sample_cells` cells of the same synthetic matrix, all genes,
@@ -124,19 +109,13 @@ def main():
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)
 
-    views = {}
-
-    def allreduce(ptr, count):
-        t = views.get((ptr, count))
-        if t is None:
-            t = torch.as_tensor(_DevView(ptr, count), device=torch.device("cuda", local_rank))
-            views[(ptr, count)] = t
-        dist.all_reduce(t)
-
+    from singlet_amd.sharded import shard_by_count, torch_allreduce_hook
     if world > 1:
-        ctx.set_allreduce(allreduce)
+        ctx.set_allreduce(torch_allreduce_hook(dist, torch.device("cuda", local_rank)))
 
-    lo, n_local = shard_range(args.cells, world, rank)
+    # contiguous equal-count cell blocks: the synthetic columns are i.i.d., so equal counts are equal
+    # non-zeros to within 0.1 %
+    lo, n_local = shard_by_count(args.cells, world, rank)
     t0 = time.perf_counter()
     ctx.synth(args.genes, n_local, args.inv_density, cell_offset=lo, ncells_total=args.cells)
     torch.cuda.synchronize()

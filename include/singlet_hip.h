@@ -202,7 +202,9 @@ SGL_API int sgl_op_mask(sgl_ctx* ctx, uint64_t state, uint64_t inv_density, int6
 /* AAt (src/singlet.cpp:200-206): G = F F^T (+1e-15 on the diagonal), F k x cols. */
 SGL_API int sgl_op_gram(sgl_ctx* ctx, const double* F, int32_t k, int64_t cols, double* G);
 /* Right-hand sides of predict (src/singlet.cpp:341-343) for the resident
- * shard: which = 0: B = F * A (F k x nrow, B k x ncol); which = 1: B = F * At. */
+ * shard: which = 0: B = F * A (F k x nrow, B k x ncol); which = 1: B = F * At;
+ * which = 2 / 3: the same two products through the LDS-tiled kernel (k <= 64) that the
+ * fit uses, instead of the plain CSC kernel. */
 SGL_API int sgl_op_rhs(sgl_ctx* ctx, int which, const double* F, int32_t k, double* B);
 /* nnls (src/singlet.cpp:229-250) on ncols independent columns sharing G:
  * B k x ncols (destroyed on the device, not written back), X k x ncols in/out. */

@@ -203,7 +203,10 @@ class Context:
         F = _f(F)
         nr, nc, _ = self.dims()
         k = F.shape[1]
-        ncol = nr if which else nc
+        ncol = nr if (which & 1) else nc   # which & 2 selects the LDS-tiled kernel
+        nrow = nc if (which & 1) else nr
+        if F.shape[0] != nrow:
+            raise ValueError("F must have %d rows" % nrow)
         B = np.empty((ncol, k))
         check(self._L.sgl_op_rhs(self._h, int(which), ptr(F, f64p), k, ptr(B, f64p)))
         return B

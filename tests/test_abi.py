@@ -1,0 +1,65 @@
+"""The drop-in boundary on the CPU: libsinglet_hip.so loads, exports every symbol
+include/singlet_hip.h declares, and fails loudly without a GPU (no compute calls here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    h = open(os.path.join(ROOT, "include", "singlet_hip.h")).read()
+    return sorted(set(re.findall(r"SGL_API\s+[\w\s\*]+?\b(sgl_[a-z0-9_]+)\s*\(", h)))
+
+
+def test_header_declares_the_three_reference_entry_points():
+    names = _declared()
+    for n in ("sgl_c_nmf", "sgl_c_ard_nmf", "sgl_c_project_model", "sgl_last_error"):
+        assert n in names
+    assert len(names) >= 30
+
+
+def test_library_exports_every_declared_symbol(sa):
+    from singlet_amd import _lib
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    for n in _declared():
+        assert hasattr(L, n), "libsinglet_hip.so does not export %s" % n
+    assert sorted(_lib.SIGNATURES) == _declared(), "python binding and header disagree"
+    assert _lib.load().sgl_abi_version() == 1
+
+
+def test_no_cpu_fallback(sa):
+    from singlet_amd import _lib
+    if _lib.load().sgl_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(sa.SingletHipError) as e:
+        sa.Context(0)
+    assert e.value.code == -2 and "no CPU path" in str(e.value)
+    import numpy as np
+    A = sa.dgCMatrix([1.0, 2.0], [0, 1], [0, 1, 2], (2, 2))
+    with pytest.raises(sa.SingletHipError):
+        sa.c_nmf(A, None, 0.0, 1, False, 0, 0, 0, 0, 0, np.ones((1, 2)))
+    with pytest.raises(sa.SingletHipError):
+        sa.c_project_model(A, np.ones((2, 1)), 0, 0, 0)
+
+
+def test_product_package_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "singlet_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".c", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                for pat in (r"^\s*(from|import)\s+oracle", r"libsinglet_oracle", r"\bora_[a-z]", r"oracle[./]oracle",
+                            r"np_transcription"):
+                    assert not re.search(pat, src, flags=re.M), (os.path.join(dirpath, f), pat)
+
+
+def test_dgCMatrix_validation(sa):
+    with pytest.raises(ValueError):
+        sa.dgCMatrix([1.0], [0], [0, 1, 1], (2, 3))
+    with pytest.raises(ValueError):
+        sa.dgCMatrix([1.0, 2.0], [0], [0, 1], (2, 1))
+    M = sa.dgCMatrix.from_dense([[0, 1.5], [2.0, 0]])
+    assert M.nnz == 2 and M.Dim == (2, 2) and list(M.i) == [1, 0]
+    assert M.col_slice(1, 2).nnz == 1

@@ -116,3 +116,81 @@ def test_step_api_matches_run(sa, ora, ctx):
     W, d, H = ctx.get_factors()
     assert rel_fro(W, ref["w"]) < TOL and rel_fro(H, ref["h"]) < TOL and rel_fro(d, ref["d"]) < TOL
     assert np.allclose(tols, ref["tol"], rtol=1e-8)
+
+
+# ---- committed golden vectors (tests/golden/, generated by make_golden.py) ------------------
+import os  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("name", ["nmf_k8_l1_0", "nmf_k8_l1_01", "nmf_k8_l1_01_l2_01", "nmf_k30"])
+def test_golden_c_nmf_hip(sa, name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    m, n = int(g["dim"][0]), int(g["dim"][1])
+    A = sa.dgCMatrix(g["Ax"], g["Ai"], g["Ap"], (m, n))
+    At = sa.dgCMatrix(g["Atx"], g["Ati"], g["Atp"], (n, m))
+    L1, L2 = float(g["L1"]), float(g["L2"])
+    got = sa.c_nmf(A, At, 0.0, int(g["maxit"]), False, L1, L1, L2, L2, 0, g["w0"].T)
+    _check(got, g)
+    assert np.allclose(got["tol"], g["tol"], rtol=1e-8, atol=0)
+
+
+def test_golden_ard_and_project_hip(sa):
+    g = np.load(os.path.join(GOLD, "ard_k6.npz"))
+    m, n = int(g["dim"][0]), int(g["dim"][1])
+    A = sa.dgCMatrix(g["Ax"], g["Ai"], g["Ap"], (m, n))
+    got = sa.c_ard_nmf(A, None, 0.0, int(g["maxit"]), False, float(g["L1"]), float(g["L2"]), 0, g["w0"].T,
+                       int(g["seed"]), int(g["inv_density"]), float(g["overfit_threshold"]), int(g["trace_test_mse"]))
+    _check(got, g)
+    assert np.array_equal(got["iter"], g["iter"])
+    assert np.allclose(got["test_mse"], g["test_mse"], rtol=1e-9, atol=0)
+    g = np.load(os.path.join(GOLD, "project_k5.npz"))
+    A = sa.dgCMatrix(g["Ax"], g["Ai"], g["Ap"], (m, n))
+    got = sa.c_project_model(A, g["w"], float(g["L1"]), float(g["L2"]), 0)
+    _check(got, g, ("h", "d"))
+
+
+def test_pbmc3k_config1(sa, ora):
+    """BASELINE config 1: pbmc3k 13714 x 2700 (the reference's bundled data), LogNormalize, k = 10,
+    L1 = 0.01, through run_nmf's entry point; HIP == oracle at equal iteration count, and the
+    RunNMF-level post-processing (factors sorted by d) applied on top."""
+    g = np.load(os.path.join(GOLD, "pbmc3k_counts.npz"))
+    p, dim = g["p"], g["dim"]
+    i = g["di"].astype(np.int64)
+    for c in range(dim[1]):
+        s, e = p[c], p[c + 1]
+        i[s:e] = np.cumsum(i[s:e])
+    x = g["x"].astype(np.float64)
+    per_cell = np.diff(p)
+    xn = np.log1p(x / np.repeat(np.add.reduceat(x, p[:-1]), per_cell) * 1e4)
+    A = ora.CSC(xn, i.astype(np.int32), p, dim[0], dim[1])
+    w0 = ora.synth_winit(10, dim[0])
+    ref = ora.c_nmf(A, A.t(), 0.0, 6, 0.01, 0.01, 0.0, 0.0, 0, w0)
+    got = sa.c_nmf(to_dgc(sa, A), None, 0.0, 6, False, 0.01, 0.01, 0.0, 0.0, 0, w0.T)
+    _check(got, ref)
+    order = np.argsort(-got["d"], kind="stable")
+    assert np.array_equal(order, np.argsort(-ref["d"], kind="stable"))
+
+
+def test_large_shape_properties(sa, ctx):
+    """A size the oracle does not finish in seconds (config-2 shape scaled: 20000 genes x 30000
+    cells, k = 30): size-independent properties instead of a reference run."""
+    ctx.synth(20000, 30000, 20)
+    ctx.fit_init(30, None)
+    it, tols = ctx.nmf_run(0.0, 3, 0.01, 0.01, 0.0, 0.0)
+    W, d, H = ctx.get_factors()
+    assert it == 3 and np.all(np.isfinite(tols)) and tols[2] < tols[0]
+    assert np.all(W >= 0) and np.all(H >= 0) and np.all(np.isfinite(W)) and np.all(np.isfinite(H))
+    assert np.abs(W.sum(axis=0) - 1).max() < 1e-9          # scale(): rows of w sum to 1
+    assert np.abs(H.sum(axis=0) - 1).max() < 1e-6          # ... and of h (scaled before the W-update)
+    # idempotence of the deterministic pipeline: same inputs -> bit-identical outputs
+    ctx.fit_init(30, None)
+    ctx.nmf_run(0.0, 3, 0.01, 0.01, 0.0, 0.0)
+    W2, d2, H2 = ctx.get_factors()
+    assert np.array_equal(W, W2) and np.array_equal(H, H2) and np.array_equal(d, d2)
+    # linearity of the right-hand sides: B(F1 + F2) = B(F1) + B(F2) on the resident matrix
+    rng = np.random.default_rng(0)
+    F1, F2 = rng.random((20000, 30)), rng.random((20000, 30))
+    B12 = ctx.op_rhs(0, F1 + F2)
+    assert rel_fro(B12, ctx.op_rhs(0, F1) + ctx.op_rhs(0, F2)) < 1e-13

@@ -1,0 +1,145 @@
+"""The oracle pinned on the CPU: hash KATs, C restatement == independent numpy transcription
+(bit for bit), both == the committed golden vectors, generator statistics, pbmc3k fixture."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import np_transcription as npt
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+# derived by literal transcription of src/singlet.cpp:30-64 with 64-bit wrap
+KATS = [((123, 0, 0), 0x692656729eb6707c), ((123, 1, 2), 0xd1c4f6746e22623f), ((123, 2, 1), 0xa171855b28d239a7),
+        ((123, 999999, 29999), 0x3ffec3e4f2d21eea), ((2147483647, 5, 7), 0x3b72606ab1a2d601),
+        ((1, 0, 1), 0x000112648b36e912)]
+
+
+def _csc(ora, g):
+    m, n = int(g["dim"][0]), int(g["dim"][1])
+    return ora.CSC(g["Ax"], g["Ai"], g["Ap"], m, n), ora.CSC(g["Atx"], g["Ati"], g["Atp"], n, m)
+
+
+def test_hash_kats(ora):
+    for (s, i, j), v in KATS:
+        assert ora.rng_rand(s, i, j) == v
+        assert npt.rand_py(s, i, j) == v
+        assert int(npt.rand_np(s, np.uint64(i), np.uint64(j))) == v
+    assert [v % 20 for _, v in KATS] == [4, 7, 7, 6, 9, 18]
+    g = np.load(os.path.join(GOLD, "rng_kat.npz"))
+    for (s, i, j), v in zip(g["args"].tolist(), g["out"].tolist()):
+        assert ora.rng_rand(s, i, j) == v
+
+
+def test_draw_rate_and_mask_agree(ora):
+    m = ora.rng_mask(123, 0, 500, 2000, 20)
+    assert abs(m.mean() - 0.05) < 0.002
+    cells = np.arange(500, dtype=np.uint64)[:, None]
+    genes = np.arange(2000, dtype=np.uint64)[None, :]
+    assert np.array_equal(m.astype(bool), npt.draw_np(123, cells, genes, 20))
+
+
+def test_generator_density_and_transpose(ora):
+    A = ora.synth_csc(700, 900, 20)
+    assert abs(A.nnz / (700 * 900) - 0.05) < 0.002
+    assert A.x.min() > 0 and len(np.unique(A.x)) == 16
+    for c in range(0, 900, 97):                       # rows ascending inside every column
+        r = A.i[A.p[c]:A.p[c + 1]]
+        assert np.all(np.diff(r) > 0)
+    At = A.t()
+    assert np.array_equal(At.to_dense(), A.to_dense().T)
+    w = ora.synth_winit(5, 700)
+    assert w.min() > 0 and w.max() < 1 and abs(w.mean() - 0.5) < 0.02
+
+
+@pytest.mark.parametrize("L1,L2", [(0.0, 0.0), (0.01, 0.0), (0.01, 0.02)])
+def test_c_oracle_equals_numpy_transcription(ora, L1, L2):
+    A = ora.synth_csc(150, 190, 12)
+    At = A.t()
+    w0 = ora.synth_winit(6, 150)
+    a = ora.c_nmf(A, At, 0.0, 4, L1, L1, L2, L2, 0, w0)
+    b = npt.c_nmf(A, At, 0.0, 4, L1, L1, L2, L2, w0)
+    for key in ("w", "h", "d", "tol"):
+        assert np.array_equal(a[key], b[key]), key
+
+
+def test_c_oracle_masked_path_equals_numpy_transcription(ora):
+    A = ora.synth_csc(110, 140, 10)
+    At = A.t()
+    w0 = ora.synth_winit(5, 110)
+    a = ora.c_ard_nmf(A, At, 0.0, 5, 0.01, 0.0, 0, w0, 31, 10, 1e-3, 2)
+    b = npt.c_ard_nmf(A, At, 0.0, 5, 0.01, 0.0, w0, 31, 10, 1e-3, 2)
+    for key in ("w", "h", "d", "test_mse", "iter", "tol", "score_overfit"):
+        assert np.array_equal(a[key], b[key]), key
+
+
+@pytest.mark.parametrize("name", ["nmf_k8_l1_0", "nmf_k8_l1_01", "nmf_k8_l1_01_l2_01", "nmf_k30"])
+def test_golden_c_nmf(ora, name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    A, At = _csc(ora, g)
+    L1, L2 = float(g["L1"]), float(g["L2"])
+    r = ora.c_nmf(A, At, 0.0, int(g["maxit"]), L1, L1, L2, L2, 0, g["w0"])
+    for key in ("w", "h", "d", "tol"):
+        assert np.array_equal(r[key], g[key]), key
+
+
+def test_golden_inputs_come_from_the_generator(ora):
+    g = np.load(os.path.join(GOLD, "nmf_k8_l1_0.npz"))
+    A = ora.synth_csc(300, 400, 20)
+    assert np.array_equal(A.x, g["Ax"]) and np.array_equal(A.i, g["Ai"]) and np.array_equal(A.p, g["Ap"])
+    assert np.array_equal(ora.synth_winit(8, 300), g["w0"])
+
+
+def test_golden_ard_and_project(ora):
+    g = np.load(os.path.join(GOLD, "ard_k6.npz"))
+    A, At = _csc(ora, g)
+    r = ora.c_ard_nmf(A, At, 0.0, int(g["maxit"]), float(g["L1"]), float(g["L2"]), 0, g["w0"], int(g["seed"]),
+                      int(g["inv_density"]), float(g["overfit_threshold"]), int(g["trace_test_mse"]))
+    for key in ("w", "h", "d", "test_mse", "iter", "tol", "score_overfit"):
+        assert np.array_equal(r[key], g[key]), key
+    g = np.load(os.path.join(GOLD, "project_k5.npz"))
+    A, _ = _csc(ora, g)
+    r = ora.c_project_model(A, g["w"], float(g["L1"]), float(g["L2"]))
+    assert np.array_equal(r["h"], g["h"]) and np.array_equal(r["d"], g["d"])
+    r2 = ora.c_project_model(A, np.ascontiguousarray(g["w"].T), float(g["L1"]), float(g["L2"]))
+    assert np.array_equal(r2["h"], g["h"])
+
+
+def test_nnls_quirks(ora):
+    """SURVEY.md 8a quirks 2-5 on hand-made cases."""
+    G = np.array([[2.0, 0.5], [0.5, 1.0]])
+    # (4) a negative step on x == 0 does nothing; (5) first sweep always runs
+    x, b, it = ora.nnls(G, np.array([-1.0, -1.0]), np.zeros(2))
+    assert np.all(x == 0) and it == 1
+    # (2) L1 is subtracted from every step of every sweep
+    x0, _, _ = ora.nnls(G, np.array([1.0, 1.0]), np.zeros(2), 0.0, 0.0)
+    x1, _, _ = ora.nnls(G, np.array([1.0, 1.0]), np.zeros(2), 0.01, 0.0)
+    assert np.all(x1 < x0)
+    # (3) a clamp overwrites the sweep's tol with 1, forcing another sweep
+    x, _, it = ora.nnls(G, np.array([-5.0, 3.0]), np.array([1.0, 0.0]))
+    assert x[0] == 0 and it >= 2
+    # cap of 100 sweeps (uint8 counter, src/singlet.cpp:231)
+    Gb = np.array([[1.0, 0.999999], [0.999999, 1.0]])
+    _, _, it = ora.nnls(Gb, np.array([1.0, 1.0000001]), np.zeros(2))
+    assert it == 100
+
+
+def test_pbmc3k_fixture_and_config1(ora):
+    """BASELINE config 1: pbmc3k 13714 x 2700, LogNormalize, k = 10, on the CPU path (plumbing)."""
+    g = np.load(os.path.join(GOLD, "pbmc3k_counts.npz"))
+    p, dim = g["p"], g["dim"]
+    i = g["di"].astype(np.int64)
+    for c in range(dim[1]):                      # undo the per-column delta coding
+        s, e = p[c], p[c + 1]
+        i[s:e] = np.cumsum(i[s:e])
+    assert tuple(dim) == (13714, 2700) and p[-1] == 2282976
+    per_cell = np.diff(p)
+    assert (per_cell.min(), int(np.median(per_cell)), per_cell.max()) == (212, 816, 3400)   # SURVEY.md 8 [probe]
+    x = g["x"].astype(np.float64)
+    colsum = np.add.reduceat(x, p[:-1])
+    xn = np.log1p(x / np.repeat(colsum, per_cell) * 1e4)   # Seurat::LogNormalize (R/PreprocessData.R:35)
+    A = ora.CSC(xn, i.astype(np.int32), p, dim[0], dim[1])
+    w0 = ora.synth_winit(10, dim[0])
+    r = ora.c_nmf(A, A.t(), 1e-5, 3, 0.01, 0.01, 0.0, 0.0, 0, w0)
+    assert r["iter"] == 3 and np.all(np.isfinite(r["w"])) and np.all(r["h"] >= 0)
+    assert np.all(np.diff(r["tol"]) < 0)         # converging
+    assert abs(r["w"].sum(axis=0) - 1).max() < 1e-9   # rows of W sum to 1 after scale()
