@@ -1,9 +1,26 @@
+#!/bin/bash
+# Round-1 profile set (run on the GPU box through gpurun): the default bench command under
+# rocprofv3 --kernel-trace --stats, then separate PMC passes (FETCH_SIZE / WRITE_SIZE / SQ).
+# Summaries land in gpurun_out/r1_*.csv; copy the ones to keep into profiles/.
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-mkdir -p gpurun_out/prof1 gpurun_out/pmc1 gpurun_out/pmc2
-rocprofv3 --kernel-trace --stats -d gpurun_out/prof1 -- python3 bench.py --cells 200000 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/prof1/bench.json 2> gpurun_out/prof1/err.txt
-find gpurun_out/prof1 -name "*stats*" | head
-rocprofv3 -L > gpurun_out/counters_list.txt 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS --kernel-trace -d gpurun_out/pmc1 -- python3 bench.py --cells 200000 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/pmc1/bench.json 2> gpurun_out/pmc1/err.txt
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA --kernel-trace -d gpurun_out/pmc2 -- python3 bench.py --cells 200000 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/pmc2/bench.json 2> gpurun_out/pmc2/err.txt
-ls -R gpurun_out/pmc1 | head -20
+O=gpurun_out
+mkdir -p $O
+rm -rf $O/r1_trace
+timeout 900 rocprofv3 --kernel-trace --stats -d $O/r1_trace -- python3 bench.py > $O/r1_trace_bench.json 2> $O/r1_trace.err
+db=$(find $O/r1_trace -name "*.db" | head -1)
+python3 scripts/pmc_summary.py $db > $O/r1_kernel_stats.csv 2>&1
+rm -rf $O/r1_trace
+i=0
+for set in "FETCH_SIZE" "WRITE_SIZE" \
+           "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" \
+           "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM" ; do
+  i=$((i+1))
+  rm -rf $O/r1_pmc_$i
+  timeout 600 rocprofv3 --pmc $set --kernel-trace -d $O/r1_pmc_$i -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/r1_pmc_$i.json 2> $O/r1_pmc_$i.err
+  db=$(find $O/r1_pmc_$i -name "*.db" | head -1)
+  python3 scripts/pmc_summary.py $db > $O/r1_pmc_$i.csv 2>&1
+  rm -rf $O/r1_pmc_$i
+done
+tail -n 40 $O/r1_kernel_stats.csv
+cat $O/r1_pmc_1.csv $O/r1_pmc_2.csv

@@ -35,6 +35,7 @@
 // the tile range is split over blockIdx.y; each split writes a partial k x ncol
 // slab and acc_tiled_reduce sums the slabs in a fixed order.
 #include "sgl_internal.h"
+#include <stdlib.h>
 #include <utility>
 #include <type_traits>
 
@@ -241,6 +242,7 @@ int sgl_tiled_build(sgl_ctx* c, const DevCSC& M, int k, DevTiled& S) {
 // inline asm right after a set is consumed and waited with a counted vmcnt
 // (loads return in order); which set is next is the wave-uniform `phase`.
 typedef double d2_t __attribute__((ext_vector_type(2)));
+#define TILED_SET_WAIT "s_waitcnt vmcnt(6)"
 
 #ifdef TILED_ABL_NOSTREAM  // ablation build: never refill the stream registers (wrong results, timing only)
 #define TILED_ABL_LOAD(...) do { if (pos < 256) asm volatile(__VA_ARGS__); } while (0)
@@ -422,7 +424,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(128), amdgpu_wa
         // LDS / 50 % VALU busy, i.e. running one after the other).
 #define TILED_SET(ER, EX)                                                                         \
     do {                                                                                          \
-        asm volatile("s_waitcnt vmcnt(6)" : "+v"(ER), "+v"(EX) : : "memory");                      \
+        asm volatile(TILED_SET_WAIT : "+v"(ER), "+v"(EX) : : "memory");                               \
         const unsigned rv_ = ER;                                                                  \
         const unsigned xl_ = (unsigned)__double2loint(EX), xh_ = (unsigned)__double2hiint(EX);    \
         const auto pr2_ = __builtin_amdgcn_permlane16_swap(rv_, rv_, false, false);               \
@@ -452,6 +454,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(128), amdgpu_wa
         }
         if (s >= 0) acc_store(4 * s, a0, a1);
     }
+    // Up to four refills (issued past the end of this wave's range, into the stream's slack) are
+    // still in flight and WILL write the set registers when they land.  Drain them with the registers
+    // passed through the wait: otherwise hipcc, which knows nothing of the pending writes, reuses
+    // v1 / v68.. for the output addressing below and a late (HBM-latency) return overwrites them.
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(er0), "+v"(er1), "+v"(er2), "+v"(er3), "+v"(ex0), "+v"(ex1), "+v"(ex2), "+v"(ex3)
+                 :
+                 : "memory");
     if (wact) {
         double* out = Bout + (size_t)blockIdx.y * (size_t)k * (size_t)ncol;
         const int f = 2 * (lane & 31);

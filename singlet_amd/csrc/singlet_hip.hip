@@ -826,22 +826,33 @@ extern "C" int sgl_op_gram(sgl_ctx* c, const double* F, int32_t k, int64_t cols,
 
 extern "C" int sgl_op_rhs(sgl_ctx* c, int which, const double* F, int32_t k, double* B) {
     CTX_GUARD(c);
-    DevCSC& M = which ? c->At : c->A;
+    const bool tiled = (which & 2) != 0;  // which = 2 / 3: same right-hand sides through the LDS-tiled kernel
+    DevCSC& M = (which & 1) ? c->At : c->A;
     if (!M.p) { sgl_set_error("no matrix resident"); return SGL_ESTATE; }
-    if (!F || !B || k <= 0 || k > SGL_MAX_K) { sgl_set_error("sgl_op_rhs: bad arguments"); return SGL_EINVAL; }
+    if (!F || !B || k <= 0 || k > SGL_MAX_K || (tiled && k > 64)) { sgl_set_error("sgl_op_rhs: bad arguments"); return SGL_EINVAL; }
     double *dF = nullptr, *dB = nullptr;
-    SGLCHK(dev_alloc(&dF, (size_t)k * M.nrow));
+    SGLCHK(dev_alloc(&dF, (size_t)k * M.nrow + 2));
     SGLCHK(dev_alloc(&dB, (size_t)k * M.ncol));
     HIPCHK(hipMemcpyAsync(dF, F, sizeof(double) * (size_t)k * M.nrow, hipMemcpyHostToDevice, c->stream));
-    // tiles depend on k: build a temporary table unless a fit with the same k owns one
-    int64_t* saved = M.seg; int32_t str = M.tile_rows, snt = M.ntiles;
-    M.seg = nullptr;
-    int rc = build_tiles(c, M, k);
-    if (rc == SGL_OK) rc = k_acc(c->stream, M, dF, k, dB, 0, 1, 0, 0, 0);
-    HIPCHK(hipMemcpyAsync(B, dB, sizeof(double) * (size_t)k * M.ncol, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    dev_free(M.seg);
-    M.seg = saved; M.tile_rows = str; M.ntiles = snt;
+    int rc;
+    if (tiled) {
+        DevTiled S;
+        rc = sgl_tiled_build(c, M, k, S);
+        if (rc == SGL_OK) rc = k_acc_tiled(c->stream, S, dF, dB);
+        HIPCHK(hipMemcpyAsync(B, dB, sizeof(double) * (size_t)k * M.ncol, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        sgl_tiled_free(S);
+    } else {
+        // tiles depend on k: build a temporary table unless a fit with the same k owns one
+        int64_t* saved = M.seg; int32_t str = M.tile_rows, snt = M.ntiles;
+        M.seg = nullptr;
+        rc = build_tiles(c, M, k);
+        if (rc == SGL_OK) rc = k_acc(c->stream, M, dF, k, dB, 0, 1, 0, 0, 0);
+        HIPCHK(hipMemcpyAsync(B, dB, sizeof(double) * (size_t)k * M.ncol, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        dev_free(M.seg);
+        M.seg = saved; M.tile_rows = str; M.ntiles = snt;
+    }
     dev_free(dF); dev_free(dB);
     return rc;
 }

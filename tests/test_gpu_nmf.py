@@ -194,3 +194,37 @@ def test_large_shape_properties(sa, ctx):
     F1, F2 = rng.random((20000, 30)), rng.random((20000, 30))
     B12 = ctx.op_rhs(0, F1 + F2)
     assert rel_fro(B12, ctx.op_rhs(0, F1) + ctx.op_rhs(0, F2)) < 1e-13
+
+
+@pytest.mark.parametrize("genes,cells,k", [(600, 150000, 30), (20000, 30000, 30), (3000, 40000, 50), (900, 50000, 31)])
+def test_tiled_first_step_cold_streams(sa, genes, cells, k):
+    """The first H-update after fit_init reads its entry streams from HBM (they were evicted from the
+    last-level cache while the transposed streams were built), the slowest the refill loads ever are.
+    Regression test of a late-landing prefetch that overwrote registers reused by the kernel's output
+    addressing: the LDS-tiled path (fit default, and op_rhs which=2/3) must equal the plain
+    wave-per-column kernel on several fresh builds."""
+    import os
+    c = sa.Context(0)
+    try:
+        c.synth(genes, cells, 20)
+        os.environ["SGL_NO_TILED"] = "1"
+        try:
+            c.fit_init(k, None)
+            c.step_begin(); c.step_h(0.01, 0.0)
+            _, _, Hp = c.get_factors()
+        finally:
+            del os.environ["SGL_NO_TILED"]
+        W0 = None
+        for rep in range(3):
+            c.fit_init(k, None)
+            if W0 is None:
+                W0 = c.get_factors()[0]
+            c.step_begin(); c.step_h(0.01, 0.0)
+            _, _, H = c.get_factors()
+            assert rel_fro(H, Hp) < 1e-12, rep
+            assert same_zero_pattern(H, Hp), rep
+        for which in (0, 1):
+            F = W0 if which == 0 else Hp
+            assert rel_fro(c.op_rhs(which | 2, F), c.op_rhs(which, F)) < 1e-13, which
+    finally:
+        c.close()
