@@ -80,6 +80,22 @@ def cpu_baseline(args):
     }
 
 
+def measured_traffic(args, world, dom):
+    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (FETCH_SIZE and
+    WRITE_SIZE, separate runs, corrected as MI355X_MICROARCH.md prescribes): counters cannot be read
+    from inside this process, so the figure measured by scripts/prof_r1.sh on this exact workload is
+    kept in profiles/traffic.json and reported only when the workload matches; otherwise null."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            t = json.load(f)
+        w = t["workload"]
+        if world == 1 and all(w[key] == getattr(args, key) for key in ("genes", "cells", "k", "inv_density")):
+            return t["bytes_per_launch"][dom]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -143,6 +159,7 @@ def main():
     phases = ctx.timing_get(reset=True)
     ctx.timing_enable(False)
     sweeps = ctx.sweeps_get(reset=True)
+    layout = ctx.layout_get()
 
     nnz_total = nnz_local
     if world > 1:
@@ -169,6 +186,15 @@ def main():
         dom_ms = max(rhs_h_ms, rhs_w_ms)
         dom_bytes = bytes_h if dom == "rhs_h" else bytes_w
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        # what the kernel really has to move: the padded entry stream (12 B per stored entry), one byte per
+        # (column pair, tile), the output, and the factor tiles every workgroup stages (mostly L2 / MALL hits)
+        lay = layout["A" if dom == "rhs_h" else "At"]
+        ncols_dom = n_loc if dom == "rhs_h" else m
+        nrows_dom = m if dom == "rhs_h" else n_loc
+        stream_bytes = lay["entries"] * 12 + lay["col_blocks"] * lay["tiles"] * (32 + 8)
+        out_bytes = 8 * k * ncols_dom * (lay["tile_ranges"] + (2 if lay["tile_ranges"] > 1 else 0))
+        staged_bytes = 8 * k * nrows_dom * ((lay["col_blocks"] + 7) // 8)
+        traffic = measured_traffic(args, world, dom)
         out = {
             "metric": "ALS iterations/sec (1M cells x 30k genes, 5% nnz, k=50)",
             "value": args.steps / elapsed, "unit": "iter/s", "n_gpus": world, "steps": args.steps,
@@ -180,7 +206,9 @@ def main():
                        "genes": m, "cells": n, "k": k, "nnz": nnz_total, "parallelism": "cells/%d" % world},
             "roofline": {"bound": "hbm", "kernel": "acc_kernel (%s: sparse accumulate of predict, one pass = all row tiles)" % dom,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "frac_of_measured_copy": achieved / HBM_MEASURED_GBS, "traffic": None,
+                         "frac_of_measured_copy": achieved / HBM_MEASURED_GBS, "traffic": traffic,
+                         "stream_layout": dict(lay, stream_bytes=stream_bytes, output_bytes=out_bytes,
+                                               factor_tile_bytes_staged_from_l2=staged_bytes),
                          "algorithmic_bytes_per_pass": dom_bytes, "ms_per_pass": dom_ms,
                          "whole_iteration": {"algorithmic_bytes": bytes_iter, "achieved": bytes_iter / (ms_step * 1e-3) / 1e9 / world,
                                              "frac": bytes_iter / (ms_step * 1e-3) / 1e9 / world / HBM_PEAK_GBS}},

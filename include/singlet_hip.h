@@ -232,9 +232,17 @@ SGL_API int sgl_op_mse_test(sgl_ctx* ctx, uint64_t seed, uint64_t inv_density, d
 SGL_API int sgl_timing_enable(sgl_ctx* ctx, int on);
 /* ms[SGL_PH_COUNT] accumulated since the last reset, calls[SGL_PH_COUNT] launches. */
 SGL_API int sgl_timing_get(sgl_ctx* ctx, double* ms, int64_t* calls, int reset);
-/* NNLS sweep totals since the last reset: [0] H solves, [1] W solves; and
- * number of columns solved [2], [3]. */
+/* NNLS sweep totals since the last reset: [0] sweeps summed over the columns of
+ * the H solves, [1] same for the W solves; [2], [3] sweeps each 64-column wave
+ * actually executed (the maximum over its columns), summed over the waves of
+ * the H / W solves -- the number that drives the kernel's run time. */
 SGL_API int sgl_sweeps_get(sgl_ctx* ctx, int64_t* out4, int reset);
+/* HBM layout of the current fit's entry streams (DESIGN.md "Data layout"), for
+ * the roofline report: per orientation (A then At) five numbers --
+ * entries stored (non-zeros + padding), row tiles T, rows per tile TR, tile
+ * ranges R (blockIdx.y slabs), column blocks of 64.  out10 all zero when the
+ * fit runs on the plain CSC kernel (k > 64). */
+SGL_API int sgl_layout_get(sgl_ctx* ctx, int64_t* out10);
 
 #ifdef __cplusplus
 }

@@ -82,6 +82,7 @@ SIGNATURES = {
     "sgl_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "sgl_timing_get": (C.c_int, [C.c_void_p, f64p, i64p, C.c_int]),
     "sgl_sweeps_get": (C.c_int, [C.c_void_p, i64p, C.c_int]),
+    "sgl_layout_get": (C.c_int, [C.c_void_p, i64p]),
 }
 
 _lib = None

@@ -251,3 +251,10 @@ class Context:
         out = np.zeros(4, dtype=np.int64)
         check(self._L.sgl_sweeps_get(self._h, ptr(out, i64p), int(reset)))
         return dict(h_sweeps=int(out[0]), w_sweeps=int(out[1]), h_wave_sweeps=int(out[2]), w_wave_sweeps=int(out[3]))
+
+    def layout_get(self):
+        """Entry-stream layout of the current fit: {'A': {...}, 'At': {...}} (all zero on the plain CSC path)."""
+        out = np.zeros(10, dtype=np.int64)
+        check(self._L.sgl_layout_get(self._h, ptr(out, i64p)))
+        keys = ("entries", "tiles", "tile_rows", "tile_ranges", "col_blocks")
+        return {name: dict(zip(keys, (int(v) for v in out[5 * o:5 * o + 5]))) for o, name in enumerate(("A", "At"))}

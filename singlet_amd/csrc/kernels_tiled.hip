@@ -380,6 +380,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(128), amdgpu_wa
             }
             for (int r = (int)threadIdx.x; r < rows; r += 64 * TILED_NW) tile[r * KS + k] = 0.0;
         }
+        // hipcc's wait-count pass cannot see that the conditional staging loads above are complete on
+        // every path, and it does not see the asm stream loads at all: without this explicit wait (which
+        // it does model) it drops an s_waitcnt vmcnt(0) in front of every set of the loop below, which
+        // drains the four-set prefetch queue each time.
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
         __syncthreads();
 #ifdef TILED_ABL_NOSTAGE
     staged:

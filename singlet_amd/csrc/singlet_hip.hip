@@ -949,3 +949,19 @@ extern "C" int sgl_sweeps_get(sgl_ctx* c, int64_t* out4, int reset) {
     if (reset) c->wave_sweeps_acc[0] = c->wave_sweeps_acc[1] = 0;
     return SGL_OK;
 }
+
+extern "C" int sgl_layout_get(sgl_ctx* c, int64_t* out10) {
+    CTX_GUARD(c);
+    if (!out10) { sgl_set_error("sgl_layout_get: NULL buffer"); return SGL_EINVAL; }
+    for (int q = 0; q < 10; ++q) out10[q] = 0;
+    if (!c->use_tiled) return SGL_OK;
+    const DevTiled* S[2] = {&c->TA, &c->TAt};
+    for (int o = 0; o < 2; ++o) {
+        out10[5 * o + 0] = S[o]->E;
+        out10[5 * o + 1] = S[o]->T;
+        out10[5 * o + 2] = S[o]->TR;
+        out10[5 * o + 3] = S[o]->R;
+        out10[5 * o + 4] = S[o]->nwb;
+    }
+    return SGL_OK;
+}
