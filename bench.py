@@ -204,7 +204,7 @@ def main():
                                    "(no early stop), cells sharded over %d GPU(s)"
                                    % (m, n, args.inv_density, nnz_total, k, args.L1, world),
                        "genes": m, "cells": n, "k": k, "nnz": nnz_total, "parallelism": "cells/%d" % world},
-            "roofline": {"bound": "hbm", "kernel": "acc_kernel (%s: sparse accumulate of predict, one pass = all row tiles)" % dom,
+            "roofline": {"bound": "hbm", "kernel": "acc_tiled_kernel (%s: sparse accumulate of predict, one launch = one pass over the matrix)" % dom,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "frac_of_measured_copy": achieved / HBM_MEASURED_GBS, "traffic": traffic,
                          "stream_layout": dict(lay, stream_bytes=stream_bytes, output_bytes=out_bytes,

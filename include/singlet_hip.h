@@ -112,6 +112,15 @@ SGL_API int sgl_c_project_model(const double* Ax, const int32_t* Ai, const int32
                         double L1, double L2, uint16_t threads,
                         double* h_out, double* d_out);
 
+/* Rcpp_predict (src/singlet.cpp:350-367): the projection without the two
+ * scale() calls.  Replaces _singlet_Rcpp_predict (src/RcppExports.cpp, 5 args,
+ * registered at :462).  w is transposed iff w_rows == nrow && w_cols != nrow
+ * (l.351 -- not the same rule as c_project_model's).  h_out: k x ncol. */
+SGL_API int sgl_rcpp_predict(const double* Ax, const int32_t* Ai, const int32_t* Ap,
+                             int32_t nrow, int32_t ncol,
+                             const double* w, int32_t w_rows, int32_t w_cols,
+                             double L1, double L2, uint16_t threads, double* h_out);
+
 /* ------------------------------------------------------------------------
  * 2. Context API: the same path with the matrix kept resident in HBM, for
  *    rank sweeps (R/ard_nmf.R:95-160 calls c_ard_nmf many times on one A),

@@ -241,6 +241,15 @@ def c_project_model(A, w, L1, L2, threads=0):
     return dict(h=h, d=d)
 
 
+def rcpp_predict(A, w, L1, L2, threads=0):
+    """Rcpp_predict (src/singlet.cpp:350-367): c_project_model without the two scale() calls.
+    w in R orientation; transposed iff w.rows() == A.rows() && w.cols() != A.rows() (l.351).
+    Returns h as an (n, k) array (== k x n column-major)."""
+    w = np.asarray(w, dtype=np.float64)
+    F = np.ascontiguousarray(w) if (w.shape[0] == A.nrow and w.shape[1] != A.nrow) else np.ascontiguousarray(w.T)
+    return predict(A, F, np.zeros((A.ncol, F.shape[1])), L1, L2, threads)
+
+
 def c_ard_nmf(A, At, tol, maxit, L1, L2, threads, w, seed, inv_density, overfit_threshold, trace_test_mse):
     ka, pa = _csc(A.x, A.i, A.p)
     kt, pt = _csc(At.x, At.i, At.p)

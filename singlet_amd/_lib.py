@@ -50,6 +50,8 @@ SIGNATURES = {
                                               _CB]),
     "sgl_c_project_model": (C.c_int, _CSC + [C.c_int32, C.c_int32, f64p, C.c_int32, C.c_int32, C.c_double, C.c_double,
                                              C.c_uint16, f64p, f64p]),
+    "sgl_rcpp_predict": (C.c_int, _CSC + [C.c_int32, C.c_int32, f64p, C.c_int32, C.c_int32, C.c_double, C.c_double,
+                                          C.c_uint16, f64p]),
     "sgl_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "sgl_destroy": (C.c_int, [C.c_void_p]),
     "sgl_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),

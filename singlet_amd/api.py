@@ -114,6 +114,22 @@ def c_project_model(A, w, L1, L2, threads):
     return {"h": h_out.T, "d": d_out}
 
 
+def Rcpp_predict(A, w, L1, L2, threads):
+    """.Call(`_singlet_Rcpp_predict`, ...) -> h (k x n)  (src/singlet.cpp:350-367)."""
+    L = _lib.load()
+    A = as_dgCMatrix(A)
+    w = np.asarray(w, dtype=np.float64)
+    if w.ndim != 2:
+        raise ValueError("w must be a matrix")
+    w_rows, w_cols = w.shape
+    wf = np.ascontiguousarray(w.T)
+    k = w_cols if (w_rows == A.nrow and w_cols != A.nrow) else w_rows
+    h_out = np.empty((A.ncol, k))
+    check(L.sgl_rcpp_predict(ptr(A.x, f64p), ptr(A.i, i32p), ptr(A.p, i32p), A.nrow, A.ncol, ptr(wf, f64p), w_rows, w_cols,
+                             L1, L2, int(threads), ptr(h_out, f64p)))
+    return h_out.T
+
+
 # ---------------------------------------------------------------------------
 # R drivers
 # ---------------------------------------------------------------------------

@@ -746,13 +746,10 @@ extern "C" int sgl_c_ard_nmf(const double* Ax, const int32_t* Ai, const int32_t*
     return sgl_get_factors(hd.c, w_out, d_out, h_out);
 }
 
-extern "C" int sgl_c_project_model(const double* Ax, const int32_t* Ai, const int32_t* Ap, int32_t nrow, int32_t ncol,
-                                   const double* w, int32_t w_rows, int32_t w_cols, double L1, double L2,
-                                   uint16_t threads, double* h_out, double* d_out) {
-    (void)threads;
-    if (!w || !h_out || !d_out) { sgl_set_error("sgl_c_project_model: NULL buffer"); return SGL_EINVAL; }
-    // if (w.rows() == A.rows()) w = w.transpose();   src/singlet.cpp:406
-    const bool tr = (w_rows == nrow);
+// c_project_model (scale_w = true) and Rcpp_predict (scale_w = false) share everything but the scaling
+static int project_common(const double* Ax, const int32_t* Ai, const int32_t* Ap, int32_t nrow, int32_t ncol, const double* w,
+                          int32_t w_rows, int32_t w_cols, bool tr, double L1, double L2, bool scaled, double* h_out,
+                          double* d_out) {
     const int k = tr ? w_cols : w_rows;
     const int64_t cols = tr ? w_rows : w_cols;
     if (cols != nrow) { sgl_set_error("'w' must share a common edge with the rows of 'A' (w is %d x %d, A has %d rows)", w_rows, w_cols, nrow); return SGL_EINVAL; }
@@ -770,11 +767,36 @@ extern "C" int sgl_c_project_model(const double* Ax, const int32_t* Ai, const in
         wsrc = wk.data();
     }
     SGLCHK(sgl_fit_init(c, k, wsrc, 0));
-    // scale(w, d) (l.408) then one predict + scale(h, d) (l.410-411)
-    SGLCHK(k_rowsum(c, c->W, k, nrow, c->d));
-    SGLCHK(k_scale_apply(c->stream, c->W, k, nrow, c->d, 1));
-    SGLCHK(sgl_project_run(c, L1, L2));
+    if (scaled) {
+        // scale(w, d) (l.408) then one predict + scale(h, d) (l.410-411)
+        SGLCHK(k_rowsum(c, c->W, k, nrow, c->d));
+        SGLCHK(k_scale_apply(c->stream, c->W, k, nrow, c->d, 1));
+        SGLCHK(sgl_project_run(c, L1, L2));
+    } else {
+        // h = 0; a = AAt(w); per column b, nnls (l.352-364)
+        HIPCHK(hipMemsetAsync(c->H, 0, sizeof(double) * (size_t)k * ncol, c->stream));
+        SGLCHK(sgl_step_h(c, L1, L2));
+    }
     return sgl_get_factors(c, nullptr, d_out, h_out);
+}
+
+extern "C" int sgl_c_project_model(const double* Ax, const int32_t* Ai, const int32_t* Ap, int32_t nrow, int32_t ncol,
+                                   const double* w, int32_t w_rows, int32_t w_cols, double L1, double L2,
+                                   uint16_t threads, double* h_out, double* d_out) {
+    (void)threads;
+    if (!w || !h_out || !d_out) { sgl_set_error("sgl_c_project_model: NULL buffer"); return SGL_EINVAL; }
+    // if (w.rows() == A.rows()) w = w.transpose();   src/singlet.cpp:406
+    return project_common(Ax, Ai, Ap, nrow, ncol, w, w_rows, w_cols, w_rows == nrow, L1, L2, true, h_out, d_out);
+}
+
+extern "C" int sgl_rcpp_predict(const double* Ax, const int32_t* Ai, const int32_t* Ap, int32_t nrow, int32_t ncol,
+                                const double* w, int32_t w_rows, int32_t w_cols, double L1, double L2, uint16_t threads,
+                                double* h_out) {
+    (void)threads;
+    if (!w || !h_out) { sgl_set_error("sgl_rcpp_predict: NULL buffer"); return SGL_EINVAL; }
+    // if (w.rows() == A.rows() && w.cols() != A.rows()) w = w.transpose();   src/singlet.cpp:351
+    return project_common(Ax, Ai, Ap, nrow, ncol, w, w_rows, w_cols, w_rows == nrow && w_cols != nrow, L1, L2, false, h_out,
+                          nullptr);
 }
 
 // ------------------------------------------------------------ operators -----

@@ -1,0 +1,31 @@
+# backend.R -- opt-in switch for the HIP back end (source()d or added to the package's R/).
+#
+# With options(singlet.backend = "hip") (or SINGLET_BACKEND=hip in the environment) the four
+# wrappers of R/RcppExports.R:20-30, 78-80 are rebound to the shim's .Call symbols; with the option
+# unset nothing changes and the package's own OpenMP code runs.  run_nmf / ard_nmf /
+# cross_validate_nmf / RunNMF / project_model call these wrappers by name, so they need no edit.
+
+singlet_hip_enable <- function(shim = Sys.getenv("SINGLET_HIP_SHIM", "singlet_hip_shim.so")) {
+  dll <- dyn.load(shim)
+  ns <- asNamespace("singlet")
+  rebind <- function(name, fn) {
+    unlockBinding(name, ns)
+    assign(name, fn, envir = ns)
+    lockBinding(name, ns)
+  }
+  rebind("c_nmf", function(A, At, tol, maxit, verbose, L1_w, L1_h, L2_w, L2_h, threads, w)
+    .Call(dll[["_singlet_c_nmf"]], A, At, tol, maxit, verbose, L1_w, L1_h, L2_w, L2_h, threads, w))
+  rebind("c_ard_nmf", function(A, At, tol, maxit, verbose, L1, L2, threads, w, seed, inv_density, overfit_threshold, trace_test_mse)
+    .Call(dll[["_singlet_c_ard_nmf"]], A, At, tol, maxit, verbose, L1, L2, threads, w, seed, inv_density,
+          overfit_threshold, trace_test_mse))
+  rebind("c_project_model", function(A, w, L1, L2, threads)
+    .Call(dll[["_singlet_c_project_model"]], A, w, L1, L2, threads))
+  rebind("Rcpp_predict", function(A, w, L1, L2, threads)
+    .Call(dll[["_singlet_Rcpp_predict"]], A, w, L1, L2, threads))
+  invisible(TRUE)
+}
+
+.singlet_hip_onload <- function() {
+  want <- getOption("singlet.backend", Sys.getenv("SINGLET_BACKEND", ""))
+  if (identical(want, "hip")) singlet_hip_enable()
+}

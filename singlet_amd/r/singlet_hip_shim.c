@@ -1,0 +1,199 @@
+/*
+ * singlet_hip_shim.c -- the only R-aware C file of the HIP back end.
+ *
+ * It provides .Call entry points with the SAME names and arity as the Rcpp glue
+ * of the reference (src/RcppExports.cpp:98-116 _singlet_c_nmf,
+ * :284-304 _singlet_c_ard_nmf, _singlet_c_project_model, _singlet_Rcpp_predict;
+ * registration table :449-477), so that R/RcppExports.R:20-30, 78-80 and
+ * everything above it (run_nmf, ard_nmf, cross_validate_nmf, RunNMF,
+ * project_model) work unchanged.  Each entry point pulls raw pointers out of
+ * the dgCMatrix slots (what inst/include/singlet.h:108-127 does through Rcpp),
+ * allocates the result objects, and forwards to libsinglet_hip.so
+ * (include/singlet_hip.h).  It uses the plain R C API only: no Rcpp, no Eigen.
+ *
+ * NOT COMPILED IN THIS REPOSITORY'S CI: the build image has neither R nor its
+ * headers.  Build where R exists with
+ *     R CMD SHLIB singlet_hip_shim.c -I<repo>/include -L<repo>/singlet_amd -lsinglet_hip
+ * (or add the file to the package's src/ and the two flags to src/Makevars;
+ * see INTEGRATION.md).  All numerical testing of the library goes through the
+ * same C ABI from Python (tests/).
+ */
+#include <R.h>
+#include <Rinternals.h>
+#include <R_ext/Rdynload.h>
+#include <R_ext/Utils.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "singlet_hip.h"
+
+/* ---- argument helpers -------------------------------------------------- */
+typedef struct {
+    const double* x;
+    const int* i;
+    const int* p;
+    int nrow, ncol;
+} dgc_view;
+
+/* Zero-copy view of a Matrix::dgCMatrix; errors like the reference's Exporter
+ * (inst/include/singlet.h:116-117) when a slot is missing. */
+static dgc_view view_dgc(SEXP s, const char* what) {
+    dgc_view v;
+    SEXP names[4] = {Rf_install("x"), Rf_install("i"), Rf_install("p"), Rf_install("Dim")};
+    for (int q = 0; q < 4; ++q)
+        if (!R_has_slot(s, names[q])) Rf_error("%s: not a dgCMatrix (missing slot)", what);
+    SEXP x = R_do_slot(s, names[0]), i = R_do_slot(s, names[1]), p = R_do_slot(s, names[2]), dim = R_do_slot(s, names[3]);
+    if (TYPEOF(x) != REALSXP || TYPEOF(i) != INTSXP || TYPEOF(p) != INTSXP || TYPEOF(dim) != INTSXP || XLENGTH(dim) != 2)
+        Rf_error("%s: not a dgCMatrix (slot types)", what);
+    v.x = REAL(x);
+    v.i = INTEGER(i);
+    v.p = INTEGER(p);
+    v.nrow = INTEGER(dim)[0];
+    v.ncol = INTEGER(dim)[1];
+    return v;
+}
+
+static void fail_if(int rc) {
+    if (rc != SGL_OK) Rf_error("singlet HIP back end: %s", sgl_last_error());
+}
+
+/* Interrupts: R_CheckUserInterrupt() long-jumps, which must not unwind through
+ * the library while kernels are in flight; test for a pending interrupt inside
+ * R_ToplevelExec and report it as a return value instead.  The library stops
+ * at the next polling point, frees its device memory and returns SGL_EINTR. */
+static void check_interrupt_fn(void* dummy) { (void)dummy; R_CheckUserInterrupt(); }
+static int poll_cb(void* user) { (void)user; return R_ToplevelExec(check_interrupt_fn, NULL) == FALSE; }
+
+/* Trace lines exactly as the reference prints them (src/singlet.cpp:661-662, 1115-1127). */
+static void log_nmf(void* user, int iter, double tol, double overfit) {
+    (void)user; (void)overfit;
+    Rprintf("%4d | %8.2e\n", iter, tol);
+}
+static void log_ard(void* user, int iter, double tol, double overfit) {
+    (void)user;
+    if (ISNAN(overfit)) Rprintf("%4d | %8.2e | %8s\n", iter, tol, "-");
+    else Rprintf("%4d | %8.2e | %8.2e\n", iter, tol, overfit);
+}
+
+static SEXP named_list(int n, const char** names, SEXP* values) {
+    SEXP out = PROTECT(Rf_allocVector(VECSXP, n)), nm = PROTECT(Rf_allocVector(STRSXP, n));
+    for (int q = 0; q < n; ++q) {
+        SET_VECTOR_ELT(out, q, values[q]);
+        SET_STRING_ELT(nm, q, Rf_mkChar(names[q]));
+    }
+    Rf_setAttrib(out, R_NamesSymbol, nm);
+    UNPROTECT(2);
+    return out;
+}
+
+/* ---- c_nmf(A, At, tol, maxit, verbose, L1_w, L1_h, L2_w, L2_h, threads, w) ---- */
+SEXP _singlet_c_nmf(SEXP A_, SEXP At_, SEXP tol_, SEXP maxit_, SEXP verbose_, SEXP L1w_, SEXP L1h_, SEXP L2w_, SEXP L2h_,
+                    SEXP threads_, SEXP w_) {
+    dgc_view A = view_dgc(A_, "A"), At = view_dgc(At_, "At");
+    if (!Rf_isMatrix(w_) || TYPEOF(w_) != REALSXP) Rf_error("w must be a numeric matrix");
+    const int k = Rf_nrows(w_), m = Rf_ncols(w_);
+    if (m != A.nrow) Rf_error("w must be k x nrow(A)");
+    const int verbose = Rf_asLogical(verbose_);
+    const int maxit = Rf_asInteger(maxit_);
+    SEXP w = PROTECT(Rf_allocMatrix(REALSXP, k, A.nrow)), d = PROTECT(Rf_allocVector(REALSXP, k)),
+         h = PROTECT(Rf_allocMatrix(REALSXP, k, A.ncol));
+    sgl_callbacks cb = {NULL, verbose ? log_nmf : NULL, poll_cb};
+    if (verbose) Rprintf("\n%4s | %8s \n---------------\n", "iter", "tol");
+    int n_iter = 0;
+    int rc = sgl_c_nmf(A.x, A.i, A.p, At.x, At.i, At.p, A.nrow, A.ncol, Rf_asReal(tol_), (uint16_t)maxit, verbose,
+                       Rf_asReal(L1w_), Rf_asReal(L1h_), Rf_asReal(L2w_), Rf_asReal(L2h_), (uint16_t)Rf_asInteger(threads_),
+                       REAL(w_), k, REAL(w), REAL(d), REAL(h), &n_iter, NULL, &cb);
+    if (rc == SGL_EINTR) { UNPROTECT(3); Rf_onintr(); }
+    fail_if(rc);
+    const char* names[3] = {"w", "d", "h"};
+    SEXP vals[3] = {w, d, h};
+    SEXP out = named_list(3, names, vals);
+    UNPROTECT(3);
+    return out;
+}
+
+/* ---- c_ard_nmf(A, At, tol, maxit, verbose, L1, L2, threads, w, seed, inv_density,
+ *                overfit_threshold, trace_test_mse) -------------------------------- */
+SEXP _singlet_c_ard_nmf(SEXP A_, SEXP At_, SEXP tol_, SEXP maxit_, SEXP verbose_, SEXP L1_, SEXP L2_, SEXP threads_, SEXP w_,
+                        SEXP seed_, SEXP invd_, SEXP thr_, SEXP trace_) {
+    dgc_view A = view_dgc(A_, "A"), At = view_dgc(At_, "At");
+    if (!Rf_isMatrix(w_) || TYPEOF(w_) != REALSXP) Rf_error("w must be a numeric matrix");
+    const int k = Rf_nrows(w_);
+    if (Rf_ncols(w_) != A.nrow) Rf_error("w must be k x nrow(A)");
+    const int verbose = Rf_asLogical(verbose_);
+    const int maxit = Rf_asInteger(maxit_);
+    SEXP w = PROTECT(Rf_allocMatrix(REALSXP, k, A.nrow)), d = PROTECT(Rf_allocVector(REALSXP, k)),
+         h = PROTECT(Rf_allocMatrix(REALSXP, k, A.ncol));
+    double* t_mse = (double*)R_alloc(maxit + 1, sizeof(double));
+    double* t_tol = (double*)R_alloc(maxit + 1, sizeof(double));
+    double* t_sco = (double*)R_alloc(maxit + 1, sizeof(double));
+    int* t_it = (int*)R_alloc(maxit + 1, sizeof(int));
+    int n_trace = 0;
+    sgl_callbacks cb = {NULL, verbose ? log_ard : NULL, poll_cb};
+    if (verbose) Rprintf("\n%4s | %8s | %8s \n---------------------------\n", "iter", "tol", "overfit");
+    int rc = sgl_c_ard_nmf(A.x, A.i, A.p, At.x, At.i, At.p, A.nrow, A.ncol, Rf_asReal(tol_), (uint16_t)maxit, verbose,
+                           Rf_asReal(L1_), Rf_asReal(L2_), (uint16_t)Rf_asInteger(threads_), REAL(w_), k,
+                           (uint64_t)Rf_asReal(seed_), (uint64_t)Rf_asReal(invd_), Rf_asReal(thr_),
+                           (uint16_t)Rf_asInteger(trace_), REAL(w), REAL(d), REAL(h), t_mse, t_it, t_tol, t_sco, &n_trace, &cb);
+    if (rc == SGL_EINTR) { UNPROTECT(3); Rf_onintr(); }
+    fail_if(rc);
+    SEXP v_mse = PROTECT(Rf_allocVector(REALSXP, n_trace)), v_it = PROTECT(Rf_allocVector(INTSXP, n_trace)),
+         v_tol = PROTECT(Rf_allocVector(REALSXP, n_trace)), v_sco = PROTECT(Rf_allocVector(REALSXP, n_trace));
+    for (int q = 0; q < n_trace; ++q) {
+        REAL(v_mse)[q] = t_mse[q];
+        INTEGER(v_it)[q] = t_it[q];
+        REAL(v_tol)[q] = t_tol[q];
+        REAL(v_sco)[q] = t_sco[q];
+    }
+    /* element names and order of src/singlet.cpp:1144-1151 */
+    const char* names[7] = {"w", "d", "h", "test_mse", "iter", "tol", "score_overfit"};
+    SEXP vals[7] = {w, d, h, v_mse, v_it, v_tol, v_sco};
+    SEXP out = named_list(7, names, vals);
+    UNPROTECT(7);
+    return out;
+}
+
+/* ---- c_project_model(A, w, L1, L2, threads) -> list(h, d) ---------------- */
+SEXP _singlet_c_project_model(SEXP A_, SEXP w_, SEXP L1_, SEXP L2_, SEXP threads_) {
+    dgc_view A = view_dgc(A_, "A");
+    if (!Rf_isMatrix(w_) || TYPEOF(w_) != REALSXP) Rf_error("w must be a numeric matrix");
+    const int wr = Rf_nrows(w_), wc = Rf_ncols(w_);
+    const int k = (wr == A.nrow) ? wc : wr;
+    SEXP h = PROTECT(Rf_allocMatrix(REALSXP, k, A.ncol)), d = PROTECT(Rf_allocVector(REALSXP, k));
+    fail_if(sgl_c_project_model(A.x, A.i, A.p, A.nrow, A.ncol, REAL(w_), wr, wc, Rf_asReal(L1_), Rf_asReal(L2_),
+                                (uint16_t)Rf_asInteger(threads_), REAL(h), REAL(d)));
+    const char* names[2] = {"h", "d"};
+    SEXP vals[2] = {h, d};
+    SEXP out = named_list(2, names, vals);
+    UNPROTECT(2);
+    return out;
+}
+
+/* ---- Rcpp_predict(A, w, L1, L2, threads) -> h ---------------------------- */
+SEXP _singlet_Rcpp_predict(SEXP A_, SEXP w_, SEXP L1_, SEXP L2_, SEXP threads_) {
+    dgc_view A = view_dgc(A_, "A");
+    if (!Rf_isMatrix(w_) || TYPEOF(w_) != REALSXP) Rf_error("w must be a numeric matrix");
+    const int wr = Rf_nrows(w_), wc = Rf_ncols(w_);
+    const int k = (wr == A.nrow && wc != A.nrow) ? wc : wr;
+    SEXP h = PROTECT(Rf_allocMatrix(REALSXP, k, A.ncol));
+    fail_if(sgl_rcpp_predict(A.x, A.i, A.p, A.nrow, A.ncol, REAL(w_), wr, wc, Rf_asReal(L1_), Rf_asReal(L2_),
+                             (uint16_t)Rf_asInteger(threads_), REAL(h)));
+    UNPROTECT(1);
+    return h;
+}
+
+/* ---- registration (stand-alone build: library(singletHip) style) ---------- *
+ * When the file is compiled INTO the singlet package instead, drop this table
+ * and keep the reference's own CallEntries (src/RcppExports.cpp:449-477): the
+ * four symbols above then simply replace the four Rcpp-generated ones. */
+static const R_CallMethodDef call_entries[] = {
+    {"_singlet_c_nmf", (DL_FUNC)&_singlet_c_nmf, 11},
+    {"_singlet_c_ard_nmf", (DL_FUNC)&_singlet_c_ard_nmf, 13},
+    {"_singlet_c_project_model", (DL_FUNC)&_singlet_c_project_model, 5},
+    {"_singlet_Rcpp_predict", (DL_FUNC)&_singlet_Rcpp_predict, 5},
+    {NULL, NULL, 0}};
+
+void R_init_singlet_hip_shim(DllInfo* dll) {
+    R_registerRoutines(dll, NULL, call_entries, NULL, NULL);
+    R_useDynamicSymbols(dll, FALSE);
+}

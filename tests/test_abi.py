@@ -63,3 +63,14 @@ def test_dgCMatrix_validation(sa):
     M = sa.dgCMatrix.from_dense([[0, 1.5], [2.0, 0]])
     assert M.nnz == 2 and M.Dim == (2, 2) and list(M.i) == [1, 0]
     assert M.col_slice(1, 2).nnz == 1
+
+
+def test_r_shim_matches_the_abi():
+    """singlet_amd/r/singlet_hip_shim.c (the .Call layer an R user loads) cannot be built here (no R);
+    syntax-check its calls into include/singlet_hip.h against prototype-only R API declarations."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["gcc", "-fsyntax-only", "-Wall", "-Wextra", "-Werror", "-Wno-cast-function-type",
+                        "-I" + os.path.join(root, "include"), "-I" + os.path.join(root, "tests", "r_api_stub"),
+                        os.path.join(root, "singlet_amd", "r", "singlet_hip_shim.c")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr

@@ -74,6 +74,17 @@ def test_c_project_model(sa, ora, orient):
     _check(got, ref, ("h", "d"))
 
 
+@pytest.mark.parametrize("shape", [(300, 11), (11, 300), (40, 40)])
+def test_rcpp_predict(sa, ora, shape):
+    """Rcpp_predict transposes w only if w.rows() == A.rows() and w.cols() != A.rows()
+    (src/singlet.cpp:351): the square case is NOT transposed, unlike c_project_model."""
+    A = ora.synth_csc(max(shape), 410, 20)
+    w = np.random.default_rng(2).random(shape)
+    ref = ora.rcpp_predict(A, w, 0.01, 0.0)
+    got = sa.Rcpp_predict(to_dgc(sa, A), w, 0.01, 0.0, 0)
+    assert rel_fro(got.T, ref) < TOL and same_zero_pattern(got.T, ref)
+
+
 @pytest.mark.parametrize("k,trace,maxit", [(6, 1, 4), (8, 2, 5), (5, 3, 4)])
 def test_c_ard_nmf_parity(sa, ora, k, trace, maxit):
     A = ora.synth_csc(220, 260, 20)

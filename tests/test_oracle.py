@@ -104,6 +104,18 @@ def test_golden_ard_and_project(ora):
     assert np.array_equal(r2["h"], g["h"])
 
 
+def test_rcpp_predict_against_transcription(ora):
+    """Rcpp_predict (src/singlet.cpp:350-367): transposition rule and no scaling."""
+    from oracle import np_transcription as npt
+    A = ora.synth_csc(60, 90, 20)
+    rng = np.random.default_rng(3)
+    for shape in ((60, 7), (7, 60), (60, 60)):
+        w = rng.random(shape)
+        F = w if (shape[0] == 60 and shape[1] != 60) else np.ascontiguousarray(w.T)
+        ref = npt.predict(A.x, A.i, A.p, A.nrow, A.ncol, np.ascontiguousarray(F), np.zeros((90, F.shape[1])), 0.01, 0.0)
+        assert np.array_equal(ora.rcpp_predict(A, w, 0.01, 0.0), ref), shape
+
+
 def test_nnls_quirks(ora):
     """SURVEY.md 8a quirks 2-5 on hand-made cases."""
     G = np.array([[2.0, 0.5], [0.5, 1.0]])
