@@ -2,7 +2,7 @@
 // per column, <= 100 sweeps, stop when tol / k <= 1e-8.  FP64 VALU bound.
 //
 // Two mappings:
-//  * nnls_lane_kernel<KP>: ONE LANE PER COLUMN.  b[KP] and x[KP] live in VGPRs,
+//  * nnls_lane_kernel<KP> (nnls_lane.h): ONE LANE PER COLUMN.  b[KP] and x[KP] live in VGPRs,
 //    the sweep is fully unrolled, the shared Gram G is wave-uniform and reaches
 //    the FMAs as scalar (SGPR) operands.  Every VALU lane does useful work; the
 //    wave runs until its slowest column converges.  Used for k <= 64 with a
@@ -17,106 +17,78 @@
 // arithmetic difference to an SSE2 build of the reference is FMA contraction of
 // b - G*delta.
 #include "sgl_internal.h"
+#include <algorithm>
+#include <cstdlib>
 #include <utility>
 #include <type_traits>
 
-// compile-time loop: guarantees that b[] / x[] are only ever indexed by constants
-// (so they live in VGPRs) regardless of the optimiser's unroll thresholds.
-template <typename F, int... Is>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
-    (f(std::integral_constant<int, Is>{}), ...);
-}
-template <int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-    static_for_impl(f, std::make_integer_sequence<int, N>{});
+// ---- host side of the lane-per-column solve (kernels in nnls_lane.h) ----------------------
+int k_nnls_lane_launch1(hipStream_t s, const double* Gpad, int KP, double* B, double* X, const int64_t* col_nnz, int k,
+                        int64_t ncols, double L1, double L2, unsigned long long* sweep_counter, const NnlsPass& ps, dim3 g,
+                        dim3 b);
+int k_nnls_lane_launch2(hipStream_t s, const double* Gpad, int KP, double* B, double* X, const int64_t* col_nnz, int k,
+                        int64_t ncols, double L1, double L2, unsigned long long* sweep_counter, const NnlsPass& ps, dim3 g,
+                        dim3 b);
+
+int64_t nnls_repack_min_cols() {
+    // read on every call (cheap): tests lower it to drive small problems through the multi-pass path
+    const char* e = getenv("SGL_NNLS_REPACK_MIN_COLS");
+    const long long x = e ? atoll(e) : 0;
+    return (int64_t)(x > 0 ? x : (1 << 18));
 }
 
-template <int KP>
-__global__ __launch_bounds__(256) void nnls_lane_kernel(const double* __restrict__ Gpad, const double* __restrict__ B,
-                                                        double* __restrict__ X, const int64_t* __restrict__ col_nnz,
-                                                        int k, int64_t ncols, double L1, double L2,
-                                                        unsigned long long* __restrict__ sweep_counter) {
-    const int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    // empty columns are skipped and keep their stale values (src/singlet.cpp:340)
-    const bool valid = (col < ncols) && (col_nnz == nullptr || col_nnz[col] != 0);
-    double b[KP], x[KP];
-    const double* bp = B + col * k;
-    double* xp = X + col * k;
-    static_for<KP>([&](auto jc) {
-        constexpr int j = decltype(jc)::value;
-        b[j] = (valid && j < k) ? bp[j] : 0.0;
-        x[j] = (valid && j < k) ? xp[j] : 0.0;
-    });
-    const double kd = (double)k;
-    double tol = 1.0;
-    int it = 0;
-    int gofs = 0;
-    while (true) {
-        const bool go = valid && it < 100 && (tol / kd) > 1e-8;
-        if (!__any(go)) break;
-        if (go) tol = 0.0;
-        // launder a (wave-uniform, always zero) offset once per sweep: the k*k scalar loads of the
-        // Gram must be re-issued every sweep instead of being hoisted out of the loop and spilled.
-        // The pointer itself keeps its provenance (global, read-only) so the loads stay s_load.
-        asm volatile("" : "+s"(gofs));
-        const double* __restrict__ Gs = Gpad + gofs;
-        static_for<KP>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            if (i < k) {
-                const double xi = x[i];
-                double diff = b[i] / Gs[i + KP * i];
-                diff -= L1;                 // exact no-op when L1 == 0
-                diff = fma(L2, xi, diff);   // exact no-op when L2 == 0 (x >= 0)
-                const bool clamp = -diff > xi;
-                const bool c2 = clamp && (xi != 0.0);
-                const bool upd = (!clamp) && (diff != 0.0);
-                const double xn = c2 ? 0.0 : (upd ? xi + diff : xi);
-                double delta = c2 ? -xi : (upd ? diff : 0.0);
-                delta = go ? delta : 0.0;
-                x[i] = go ? xn : xi;
-                const double tadd = fabs(diff / (xn + 1e-15));
-                const double tnew = c2 ? 1.0 : (upd ? tol + tadd : tol);
-                tol = go ? tnew : tol;
-                const double nd = -delta;
-                static_for<KP>([&](auto jc) {
-                    constexpr int j = decltype(jc)::value;
-                    b[j] = fma(Gs[j + KP * i], nd, b[j]);
-                });
-            }
-        });
-        it += go ? 1 : 0;
+int nnls_scratch_alloc(NnlsScratch& sc, int64_t cap) {
+    nnls_scratch_free(sc);
+    if (cap <= 0) return SGL_OK;
+    if (hipMalloc(&sc.list[0], sizeof(int32_t) * cap) != hipSuccess || hipMalloc(&sc.list[1], sizeof(int32_t) * cap) != hipSuccess ||
+        hipMalloc(&sc.counts, sizeof(uint32_t) * (SGL_NNLS_MAX_PASSES + 1)) != hipSuccess ||
+        hipMalloc(&sc.it_state, (size_t)cap) != hipSuccess || hipMalloc(&sc.tol_state, sizeof(double) * cap) != hipSuccess) {
+        nnls_scratch_free(sc);
+        sgl_set_error("NNLS scratch: out of device memory");
+        return SGL_ENOMEM;
     }
-    if (valid) {
-        static_for<KP>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            if (j < k) xp[j] = x[j];
-        });
-    }
-    if (sweep_counter != nullptr) {
-        int s = it, mx = it;
-        for (int off = 32; off > 0; off >>= 1) {
-            s += __shfl_down(s, off, 64);
-            mx = max(mx, __shfl_down(mx, off, 64));
-        }
-        if ((threadIdx.x & 63) == 0 && s != 0) {
-            atomicAdd(sweep_counter, (unsigned long long)s);
-            atomicAdd(sweep_counter + 2, (unsigned long long)mx);  // diagnostic: sweeps the wave actually ran
-        }
-    }
+    sc.cap = cap;
+    return SGL_OK;
 }
 
-int k_nnls_lane(hipStream_t s, const double* Gpad, int KP, const double* B, double* X, const int64_t* col_nnz, int k,
-                int64_t ncols, double L1, double L2, unsigned long long* sweep_counter) {
+void nnls_scratch_free(NnlsScratch& sc) {
+    if (sc.list[0]) hipFree(sc.list[0]);
+    if (sc.list[1]) hipFree(sc.list[1]);
+    if (sc.counts) hipFree(sc.counts);
+    if (sc.it_state) hipFree(sc.it_state);
+    if (sc.tol_state) hipFree(sc.tol_state);
+    sc = NnlsScratch();
+}
+
+int k_nnls_lane(hipStream_t s, const double* Gpad, int KP, double* B, double* X, const int64_t* col_nnz, int k,
+                int64_t ncols, double L1, double L2, unsigned long long* sweep_counter, const NnlsScratch* scr) {
     if (ncols <= 0) return SGL_OK;
-    dim3 g((unsigned)((ncols + 255) / 256)), b(256);
-#define SGL_NNLS(K_) case K_: nnls_lane_kernel<K_><<<g, b, 0, s>>>(Gpad, B, X, col_nnz, k, ncols, L1, L2, sweep_counter); break
-    switch (KP) {
-        SGL_NNLS(4); SGL_NNLS(8); SGL_NNLS(12); SGL_NNLS(16); SGL_NNLS(20); SGL_NNLS(24); SGL_NNLS(28); SGL_NNLS(32);
-        SGL_NNLS(36); SGL_NNLS(40); SGL_NNLS(44); SGL_NNLS(48); SGL_NNLS(52); SGL_NNLS(56); SGL_NNLS(60); SGL_NNLS(64);
-        default: sgl_set_error("k_nnls_lane: unsupported KP=%d", KP); return SGL_EINVAL;
+    auto launch = (KP <= 40) ? k_nnls_lane_launch1 : k_nnls_lane_launch2;
+    const dim3 g((unsigned)((ncols + 255) / 256)), b(256);
+    const bool repack = scr != nullptr && scr->cap >= ncols && ncols >= nnls_repack_min_cols();
+    if (!repack) {
+        const NnlsPass one = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+        SGLCHK(launch(s, Gpad, KP, B, X, col_nnz, k, ncols, L1, L2, sweep_counter, one, g, b));
+        HIPCHK(hipGetLastError());
+        return SGL_OK;
     }
-#undef SGL_NNLS
-    HIPCHK(hipGetLastError());
+    // Passes over ever shorter lists; how many columns survive a pass is only known on the device, so
+    // every pass is launched for the worst case and workgroups beyond the list return at once.  The
+    // last pass, and any pass over a list too short to fill the GPU, runs its columns to the end.
+    HIPCHK(hipMemsetAsync(scr->counts, 0, sizeof(uint32_t) * (SGL_NNLS_MAX_PASSES + 1), s));
+    for (int p = 0; p < SGL_NNLS_MAX_PASSES; ++p) {
+        const bool last = (p == SGL_NNLS_MAX_PASSES - 1);
+        NnlsPass ps;
+        ps.list = p ? scr->list[(p - 1) & 1] : nullptr;
+        ps.count = p ? scr->counts + p : nullptr;
+        ps.next_list = last ? nullptr : scr->list[p & 1];
+        ps.next_count = last ? nullptr : scr->counts + p + 1;
+        ps.it_state = scr->it_state;
+        ps.tol_state = scr->tol_state;
+        ps.final_below = (int32_t)std::min<int64_t>(64 * 1024, nnls_repack_min_cols() / 4);
+        SGLCHK(launch(s, Gpad, KP, B, X, col_nnz, k, ncols, L1, L2, sweep_counter, ps, g, b));
+        HIPCHK(hipGetLastError());
+    }
     return SGL_OK;
 }
 

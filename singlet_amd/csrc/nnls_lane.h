@@ -1,0 +1,132 @@
+// nnls_lane_kernel<KP>: nnls (src/singlet.cpp:229-250) with ONE LANE PER COLUMN (see kernels_nnls.hip
+// for the two mappings).  Included by kernels_nnls_lane{1,2}.hip, which instantiate disjoint sets of
+// KP so that the (long) compiles run in parallel.
+//
+// Re-packing.  Lanes of a wave run in lock-step, so a wave is busy until its slowest column stops:
+// at config 3 the columns need 31 sweeps on average but a wave runs 46.  The solve is therefore
+// done in PASSES: a wave leaves a pass as soon as fewer than 3/8 of the lanes it started with are
+// still iterating, writes the state of the unfinished columns back (b in place in B, x, the sweep
+// count and the running tol) and appends them to a list; the next pass runs the listed columns
+// densely packed.  A column's own sequence of sweeps is unchanged (same order, same arithmetic, same
+// stop test after every sweep), so results are bit-identical to the one-pass kernel whatever the
+// packing; only the order in which columns land in the list varies from run to run.
+#pragma once
+#include "sgl_internal.h"
+#include <utility>
+#include <type_traits>
+
+// compile-time loop: guarantees that b[] / x[] are only ever indexed by constants
+// (so they live in VGPRs) regardless of the optimiser's unroll thresholds.
+template <typename F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+template <int KP>
+__global__ __launch_bounds__(256) void nnls_lane_kernel(const double* __restrict__ Gpad, double* __restrict__ B,
+                                                        double* __restrict__ X, const int64_t* __restrict__ col_nnz,
+                                                        int k, int64_t ncols, double L1, double L2,
+                                                        unsigned long long* __restrict__ sweep_counter, NnlsPass ps) {
+    // columns of this pass: all of them (first pass) or the list written by the previous pass
+    const int64_t n_in = ps.list ? (int64_t)*ps.count : ncols;
+    if ((int64_t)blockIdx.x * blockDim.x >= n_in) return;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in_range = gid < n_in;
+    const int64_t col = in_range ? (ps.list ? (int64_t)ps.list[gid] : gid) : 0;
+    // empty columns are skipped and keep their stale values (src/singlet.cpp:340)
+    const bool valid = in_range && (ps.list != nullptr || col_nnz == nullptr || col_nnz[col] != 0);
+    const bool to_end = (ps.next_list == nullptr) || n_in <= (int64_t)ps.final_below;
+    double b[KP], x[KP];
+    double* bp = B + col * k;
+    double* xp = X + col * k;
+    static_for<KP>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        b[j] = (valid && j < k) ? bp[j] : 0.0;
+        x[j] = (valid && j < k) ? xp[j] : 0.0;
+    });
+    const double kd = (double)k;
+    double tol = 1.0;
+    int it = 0;
+    if (valid && ps.list != nullptr) {
+        tol = ps.tol_state[col];
+        it = (int)ps.it_state[col];
+    }
+    int gofs = 0, ran = 0;
+    const int n_act0 = __popcll(__ballot(valid && it < 100 && (tol / kd) > 1e-8));
+    while (true) {
+        const bool go = valid && it < 100 && (tol / kd) > 1e-8;
+        const int n_act = __popcll(__ballot(go));
+        if (n_act == 0) break;
+        if (!to_end && n_act * 8 < n_act0 * 3) break;  // re-pack the stragglers
+        ++ran;
+        if (go) tol = 0.0;
+        // launder a (wave-uniform, always zero) offset once per sweep: the k*k scalar loads of the
+        // Gram must be re-issued every sweep instead of being hoisted out of the loop and spilled.
+        // The pointer itself keeps its provenance (global, read-only) so the loads stay s_load.
+        asm volatile("" : "+s"(gofs));
+        const double* __restrict__ Gs = Gpad + gofs;
+        static_for<KP>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            if (i < k) {
+                const double xi = x[i];
+                double diff = b[i] / Gs[i + KP * i];
+                diff -= L1;                 // exact no-op when L1 == 0
+                diff = fma(L2, xi, diff);   // exact no-op when L2 == 0 (x >= 0)
+                const bool clamp = -diff > xi;
+                const bool c2 = clamp && (xi != 0.0);
+                const bool upd = (!clamp) && (diff != 0.0);
+                const double xn = c2 ? 0.0 : (upd ? xi + diff : xi);
+                double delta = c2 ? -xi : (upd ? diff : 0.0);
+                delta = go ? delta : 0.0;
+                x[i] = go ? xn : xi;
+                const double tadd = fabs(diff / (xn + 1e-15));
+                const double tnew = c2 ? 1.0 : (upd ? tol + tadd : tol);
+                tol = go ? tnew : tol;
+                const double nd = -delta;
+                static_for<KP>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    b[j] = fma(Gs[j + KP * i], nd, b[j]);
+                });
+            }
+        });
+        it += go ? 1 : 0;
+    }
+    const bool unfinished = valid && it < 100 && (tol / kd) > 1e-8;  // only possible when !to_end
+    if (valid) {
+        static_for<KP>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if (j < k) xp[j] = x[j];
+        });
+    }
+    if (unfinished) {
+        static_for<KP>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if (j < k) bp[j] = b[j];
+        });
+        ps.tol_state[col] = tol;
+        ps.it_state[col] = (uint8_t)it;
+    }
+    const unsigned long long um = __ballot(unfinished);
+    if (um != 0ull) {  // wave-aggregated append
+        const int lane = threadIdx.x & 63;
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(ps.next_count, (unsigned)__popcll(um));
+        base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+        if (unfinished) ps.next_list[base + (unsigned)__popcll(um & ((1ull << lane) - 1ull))] = (int32_t)col;
+    }
+    if (sweep_counter != nullptr) {
+        int s = (valid && !unfinished) ? it : 0;  // a column's sweeps are booked once, when it stops
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        if ((threadIdx.x & 63) == 0 && (s != 0 || ran != 0)) {
+            atomicAdd(sweep_counter, (unsigned long long)s);
+            atomicAdd(sweep_counter + 2, (unsigned long long)ran);  // sweeps this wave actually executed
+        }
+    }
+}
+
+#define SGL_NNLS_CASE(K_) \
+    case K_: nnls_lane_kernel<K_><<<g, b, 0, s>>>(Gpad, B, X, col_nnz, k, ncols, L1, L2, sweep_counter, ps); break

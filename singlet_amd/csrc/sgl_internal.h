@@ -61,6 +61,26 @@ struct PhaseEvent {
     hipEvent_t e0, e1;
 };
 
+// one pass of the lane-per-column kernel (nnls_lane.h): columns come from `list` (count at *count)
+// or are 0..ncols-1 when list == nullptr; unfinished columns go to next_list (nullptr: run to the end)
+struct NnlsPass {
+    const int32_t* list;
+    const uint32_t* count;
+    int32_t* next_list;
+    uint32_t* next_count;
+    uint8_t* it_state;    // sweeps done so far, per column
+    double* tol_state;    // running tol, per column
+    int32_t final_below;  // a pass over at most this many columns runs them to the end
+};
+// device scratch of the multi-pass solve, sized for `cap` columns (owned by the caller)
+struct NnlsScratch {
+    int32_t* list[2] = {nullptr, nullptr};
+    uint32_t* counts = nullptr;   // SGL_NNLS_MAX_PASSES + 1
+    uint8_t* it_state = nullptr;
+    double* tol_state = nullptr;
+    int64_t cap = 0;
+};
+
 struct sgl_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -80,6 +100,7 @@ struct sgl_ctx {
     double* red = nullptr;  // [k*m right-hand sides of the W-update | k*k Gram of H | k row sums]
     double* G = nullptr;    // k x k Gram (+1e-15 diagonal)
     double* Gpad = nullptr; // KP x KP zero-padded copy for the lane NNLS kernel
+    NnlsScratch nnls_scr;   // lists / per-column state of the multi-pass lane NNLS
     double* ws = nullptr;   // partial-reduction workspace
     size_t ws_bytes = 0;
     double* scalars = nullptr;       // device scratch for cor / mse results
@@ -139,8 +160,14 @@ int sgl_tiled_build(sgl_ctx* c, const DevCSC& M, int k, DevTiled& S);
 int k_acc_tiled(hipStream_t s, const DevTiled& S, const double* F, double* B);
 
 // NNLS
-int k_nnls_lane(hipStream_t s, const double* Gpad, int KP, const double* B, double* X, const int64_t* col_nnz,
-                int k, int64_t ncols, double L1, double L2, unsigned long long* sweep_counter);
+#define SGL_NNLS_MAX_PASSES 10
+// below this many columns the GPU is not full anyway: one pass (env SGL_NNLS_REPACK_MIN_COLS overrides, tests)
+int64_t nnls_repack_min_cols();
+int nnls_scratch_alloc(NnlsScratch& sc, int64_t cap);
+void nnls_scratch_free(NnlsScratch& sc);
+// B is destroyed (and used as the spill space of b between passes).  scr == nullptr: one pass.
+int k_nnls_lane(hipStream_t s, const double* Gpad, int KP, double* B, double* X, const int64_t* col_nnz,
+                int k, int64_t ncols, double L1, double L2, unsigned long long* sweep_counter, const NnlsScratch* scr);
 int k_nnls_wave(hipStream_t s, const double* G, int64_t gstride, const double* B, double* X, const int64_t* col_nnz,
                 int k, int64_t ncols, double L1, double L2, unsigned long long* sweep_counter);
 

@@ -142,6 +142,7 @@ static void free_fit(sgl_ctx* c) {
     dev_free(c->red);
     dev_free(c->G);
     dev_free(c->Gpad);
+    nnls_scratch_free(c->nnls_scr);
     dev_free(c->A.seg);
     dev_free(c->At.seg);
     sgl_tiled_free(c->TA);
@@ -378,7 +379,7 @@ static int build_tiles(sgl_ctx* c, DevCSC& M, int k) {
     return k_build_segments(c->stream, M);
 }
 
-static int lane_kp(int k) { return (k + 3) / 4 * 4; }
+static int lane_kp(int k) { return (k + 1) / 2 * 2; }
 
 extern "C" int sgl_fit_init(sgl_ctx* c, int32_t k, const double* w_init, uint64_t synth_seed) {
     CTX_GUARD(c);
@@ -397,6 +398,10 @@ extern "C" int sgl_fit_init(sgl_ctx* c, int32_t k, const double* w_init, uint64_
     SGLCHK(dev_alloc(&c->G, (size_t)k * k));
     const int KP = lane_kp(k);
     SGLCHK(dev_alloc(&c->Gpad, (size_t)KP * KP));
+    {
+        const int64_t cap = std::max<int64_t>(c->A.ncol, c->A.nrow);
+        if (k <= SGL_LANE_NNLS_MAX_K && cap >= nnls_repack_min_cols()) SGLCHK(nnls_scratch_alloc(c->nnls_scr, cap));
+    }
     if (w_init) HIPCHK(hipMemcpyAsync(c->W, w_init, sizeof(double) * (size_t)k * m, hipMemcpyHostToDevice, c->stream));
     else SGLCHK(k_synth_winit(c->stream, synth_seed, k, (int32_t)m, c->W));
     HIPCHK(hipMemsetAsync(c->H, 0, sizeof(double) * (size_t)k * n, c->stream));
@@ -444,13 +449,13 @@ extern "C" int sgl_fit_init(sgl_ctx* c, int32_t k, const double* w_init, uint64_
     } while (0)
 
 // NNLS dispatch for a Gram shared by all columns.
-static int nnls_shared(sgl_ctx* c, const double* G, const double* B, double* X, const int64_t* col_nnz, int64_t ncols,
+static int nnls_shared(sgl_ctx* c, const double* G, double* B, double* X, const int64_t* col_nnz, int64_t ncols,
                        double L1, double L2, unsigned long long* counter) {
     const int k = c->k;
     if (k <= SGL_LANE_NNLS_MAX_K) {
         const int KP = lane_kp(k);
         SGLCHK(k_pad_gram(c->stream, G, k, KP, c->Gpad));
-        return k_nnls_lane(c->stream, c->Gpad, KP, B, X, col_nnz, k, ncols, L1, L2, counter);
+        return k_nnls_lane(c->stream, c->Gpad, KP, B, X, col_nnz, k, ncols, L1, L2, counter, &c->nnls_scr);
     }
     return k_nnls_wave(c->stream, G, 0, B, X, col_nnz, k, ncols, L1, L2, counter);
 }
@@ -896,7 +901,11 @@ extern "C" int sgl_op_nnls(sgl_ctx* c, const double* G, const double* B, double*
         const int KP = lane_kp(k);
         rc = dev_alloc(&dGp, (size_t)KP * KP);
         if (rc == SGL_OK) rc = k_pad_gram(c->stream, dG, k, KP, dGp);
-        if (rc == SGL_OK) rc = k_nnls_lane(c->stream, dGp, KP, dB, dX, nullptr, k, ncols, L1, L2, c->sweep_counters + 4);
+        NnlsScratch scr;  // re-pack passes only pay off (and are only used) for many columns
+        if (rc == SGL_OK && ncols >= nnls_repack_min_cols()) rc = nnls_scratch_alloc(scr, ncols);
+        if (rc == SGL_OK) rc = k_nnls_lane(c->stream, dGp, KP, dB, dX, nullptr, k, ncols, L1, L2, c->sweep_counters + 4, &scr);
+        if (rc == SGL_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = SGL_EHIP;
+        nnls_scratch_free(scr);
     } else {
         rc = k_nnls_wave(c->stream, dG, 0, dB, dX, nullptr, k, ncols, L1, L2, c->sweep_counters + 4);
     }

@@ -239,3 +239,14 @@ def test_tiled_first_step_cold_streams(sa, genes, cells, k):
             assert rel_fro(c.op_rhs(which | 2, F), c.op_rhs(which, F)) < 1e-13, which
     finally:
         c.close()
+
+
+def test_c_nmf_with_nnls_repack(sa, ora, monkeypatch):
+    """Whole fit with the NNLS re-pack passes forced on at a small size: same parity bar."""
+    monkeypatch.setenv("SGL_NNLS_REPACK_MIN_COLS", "256")
+    A = ora.synth_csc(400, 3000, 20)
+    At = A.t()
+    w0 = ora.synth_winit(10, 400)
+    ref = ora.c_nmf(A, At, 0.0, 4, 0.01, 0.01, 0.0, 0.0, 0, w0)
+    got = sa.c_nmf(to_dgc(sa, A), to_dgc(sa, At), 0.0, 4, False, 0.01, 0.01, 0.0, 0.0, 0, w0.T)
+    _check(got, ref)

@@ -113,6 +113,25 @@ def test_nnls(ctx, ora, k, L1, L2):
     assert sweeps == esw
 
 
+@pytest.mark.parametrize("k", [7, 12, 50])
+def test_nnls_repack_passes_are_bit_identical(ctx, k, monkeypatch):
+    """The multi-pass lane kernel (stragglers re-packed between passes, nnls_lane.h) must give
+    bit-identical solutions and the same sweep total as the one-pass kernel.  Columns with very
+    different difficulty (scaled right-hand sides, some warm starts) make the passes uneven."""
+    rng = np.random.default_rng(100 + k)
+    ncols = 6000
+    F = rng.random((4 * k + 5, k))
+    G = F.T @ F + 1e-15 * np.eye(k)
+    B = rng.normal(size=(ncols, k)) * 3 + 1.0
+    B *= np.exp(rng.normal(size=(ncols, 1)) * 2)
+    X0 = np.abs(rng.normal(size=(ncols, k))) * (rng.random((ncols, k)) < 0.6) * 1e-3
+    monkeypatch.delenv("SGL_NNLS_REPACK_MIN_COLS", raising=False)
+    X1, s1 = ctx.op_nnls(G, B, X0, 0.01, 0.0)
+    monkeypatch.setenv("SGL_NNLS_REPACK_MIN_COLS", "512")
+    X2, s2 = ctx.op_nnls(G, B, X0, 0.01, 0.0)
+    assert np.array_equal(X1, X2) and s1 == s2
+
+
 def test_scale_and_cor(ctx, ora):
     rng = np.random.default_rng(11)
     F = rng.random((1234, 17))
