@@ -37,6 +37,9 @@ def parse():
     ap.add_argument("--L1", type=float, default=0.01)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-cells", type=int, default=16000)
+    ap.add_argument("--force-allreduce", action="store_true",
+                    help="with one rank: still create the RCCL process group and route the two per-iteration sums through "
+                         "the all-reduce hook (plumbing check of the multi-GPU path on a 1-GPU box)")
     return ap.parse_args()
 
 
@@ -111,9 +114,12 @@ def main():
 
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_allreduce:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     def barrier():
@@ -122,11 +128,14 @@ def main():
         torch.cuda.synchronize()
 
     ctx = sa.Context(local_rank)
-    stream = torch.cuda.current_stream()
+    # one explicit (non-default) stream shared by the kernels and torch: RCCL orders its collective against
+    # torch's CURRENT stream, so the library must launch on exactly that one
+    stream = torch.cuda.Stream(device=local_rank)
+    torch.cuda.set_stream(stream)
     ctx.set_stream(stream.cuda_stream)
 
     from singlet_amd.sharded import shard_by_count, torch_allreduce_hook
-    if world > 1:
+    if dist is not None:
         ctx.set_allreduce(torch_allreduce_hook(dist, torch.device("cuda", local_rank)))
 
     # contiguous equal-count cell blocks: the synthetic columns are i.i.d., so equal counts are equal
@@ -162,7 +171,7 @@ def main():
     layout = ctx.layout_get()
 
     nnz_total = nnz_local
-    if world > 1:
+    if dist is not None:
         tt = torch.tensor([elapsed, float(nnz_local)], dtype=torch.float64, device="cuda")
         mx = tt.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -225,11 +234,21 @@ def main():
                 out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
             except Exception as e:  # noqa: BLE001 - the baseline is reported, never required
                 out["cpu_baseline"] = {"error": repr(e)}
-        print(json.dumps(out))
+        line = json.dumps(out)
     ctx.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes a version banner through C stdio; push it out first so that the JSON line is the
+        # last thing on stdout
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        sys.stdout.flush()
+        print(line, flush=True)
 
 
 if __name__ == "__main__":

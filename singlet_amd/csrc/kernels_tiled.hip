@@ -398,7 +398,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(128), amdgpu_wa
         // pair bookkeeping in front of every 4-entry group (wave-uniform)
 #define TILED_SLOT()                                                                              \
     do {                                                                                          \
-        if (rem == 0) {                                                                           \
+        if (__builtin_expect(rem == 0, 0)) {                                                      \
             if (s >= 0) acc_store(4 * s, a0, a1);                                                 \
             do {                                                                                  \
                 ++s;                                                                              \
