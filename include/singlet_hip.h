@@ -162,8 +162,12 @@ SGL_API int sgl_download_csc(sgl_ctx* ctx, int which, double* x, int32_t* i, int
 SGL_API int sgl_fit_init(sgl_ctx* ctx, int32_t k, const double* w_init, uint64_t synth_seed);
 
 /* Collective hook for cell-sharded runs.  Called with a device pointer to
- * `count` doubles that must be summed in place over all shards, on the
- * context's stream semantics described at sgl_set_stream.  NULL = one shard. */
+ * `count` doubles that must be summed in place over all shards.  Ordering:
+ * after sgl_set_stream(ctx, S) the buffer is produced and consumed by kernels
+ * on S, so the hook enqueues its collective on S (or a stream ordered against
+ * S) and returns without a host sync.  Without sgl_set_stream the context runs
+ * on a private stream: the library then synchronises it before the call, and
+ * the hook must have completed its writes when it returns.  NULL = one shard. */
 typedef int (*sgl_allreduce_fn)(void* user, void* dev_ptr, int64_t count);
 SGL_API int sgl_set_allreduce(sgl_ctx* ctx, sgl_allreduce_fn fn, void* user);
 

@@ -42,7 +42,7 @@
 #define TILED_NW 8           // waves per workgroup (512 threads -> 256 VGPRs per lane)
 #define TILED_CW 64          // columns per wave
 #define TILED_NP 32          // column pairs per wave
-#define TILED_LDS_BYTES (128 * 1024)
+#define TILED_LDS_BYTES (160 * 1024 - 512)  // the whole 160 KiB of a CU minus the read-past-the-row slack
 
 // ---------------------------------------------------------------- build -----
 // groups per (wb, t, pair) and entries per chunk
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(128), amdgpu_wa
             // Each thread moves up to NST 16-byte pieces of the (contiguous) tile, in two rounds of
             // NST/2.  Round 1 loads are issued before the barrier (they overlap the tail of the previous
             // tile's work of other waves).
-            constexpr int NST = TILED_LDS_BYTES / 16 / (64 * TILED_NW);
+            constexpr int NST = (TILED_LDS_BYTES / 16 + 64 * TILED_NW - 1) / (64 * TILED_NW) + ((TILED_LDS_BYTES / 16 + 64 * TILED_NW - 1) / (64 * TILED_NW)) % 2;
             constexpr int HST = NST / 2;
             double2 stg[HST];
 #pragma unroll

@@ -230,6 +230,11 @@ extern "C" int sgl_set_allreduce(sgl_ctx* c, sgl_allreduce_fn fn, void* user) {
 static int do_allreduce(sgl_ctx* c, double* dev_ptr, int64_t count) {
     if (!c->allreduce) return SGL_OK;
     Phase ph(c, SGL_PH_COMM);
+    // On a caller-provided stream (sgl_set_stream) the hook enqueues the collective on that same stream
+    // and no host synchronisation is needed.  On the context's private stream the hook cannot order
+    // itself against the kernels, so the buffer is made complete first and the hook must have finished
+    // its writes (synchronised whatever stream it used) when it returns.
+    if (c->stream == c->own_stream) HIPCHK(hipStreamSynchronize(c->stream));
     const int rc = c->allreduce(c->allreduce_user, dev_ptr, count);
     if (rc != 0) { sgl_set_error("all-reduce callback failed with code %d", rc); return SGL_ECOMM; }
     return SGL_OK;
