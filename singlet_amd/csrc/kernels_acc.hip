@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void acc_kernel(const double* __restrict__ x, 
                                                   const int64_t* __restrict__ seg_lo, const int64_t* __restrict__ seg_hi,
                                                   int64_t ncols, const double* __restrict__ F, int k,
                                                   double* __restrict__ B, int accumulate, uint64_t seed,
-                                                  uint64_t inv_density, int64_t col_off, int64_t row_off) {
+                                                  SglDiv inv_density, int64_t col_off, int64_t row_off) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -110,7 +110,7 @@ static int launch_acc(hipStream_t s, const DevCSC& M, int tile, const double* F,
     const int R = (k + 63) / 64;
     const int accumulate = tile > 0;
     dim3 g((unsigned)blocks), b(256);
-#define SGL_ACC(RR) acc_kernel<RR, MASK><<<g, b, 0, s>>>(M.x, M.i, lo, hi, M.ncol, F, k, B, accumulate, seed, inv_density, col_off, row_off)
+#define SGL_ACC(RR) acc_kernel<RR, MASK><<<g, b, 0, s>>>(M.x, M.i, lo, hi, M.ncol, F, k, B, accumulate, seed, sgl_div_make(inv_density), col_off, row_off)
     switch (R) {
         case 1: SGL_ACC(1); break;
         case 2: SGL_ACC(2); break;

@@ -19,12 +19,12 @@ int k_rand(hipStream_t s, uint64_t state, const uint64_t* i, const uint64_t* j, 
 }
 
 // out[c * ngenes + g] = draw(cell0 + c, g): one block row per cell, lanes over genes.
-__global__ void mask_kernel(uint64_t state, uint64_t inv_density, int64_t cell0, int32_t ncells, int32_t ngenes,
+__global__ void mask_kernel(uint64_t state, SglDiv inv_density, int64_t cell0, int32_t ncells, int32_t ngenes,
                             uint8_t* __restrict__ out) {
     const int64_t c = blockIdx.y;
     const uint64_t xi = sgl_rand_i(state, (uint64_t)(cell0 + c));
     for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < ngenes; g += (int64_t)gridDim.x * blockDim.x)
-        out[c * ngenes + g] = (uint8_t)((sgl_rand_j(xi, (uint64_t)g) % inv_density) == 0);
+        out[c * ngenes + g] = (uint8_t)sgl_divides(sgl_rand_j(xi, (uint64_t)g), inv_density);
 }
 
 int k_mask(hipStream_t s, uint64_t state, uint64_t inv_density, int64_t cell0, int32_t ncells, int32_t ngenes,
@@ -32,7 +32,7 @@ int k_mask(hipStream_t s, uint64_t state, uint64_t inv_density, int64_t cell0, i
     if (ncells <= 0 || ngenes <= 0) return SGL_OK;
     unsigned gx = (unsigned)((ngenes + 255) / 256);
     if (gx > 64) gx = 64;
-    mask_kernel<<<dim3(gx, (unsigned)ncells), dim3(256), 0, s>>>(state, inv_density, cell0, ncells, ngenes, out);
+    mask_kernel<<<dim3(gx, (unsigned)ncells), dim3(256), 0, s>>>(state, sgl_div_make(inv_density), cell0, ncells, ngenes, out);
     HIPCHK(hipGetLastError());
     return SGL_OK;
 }
@@ -42,7 +42,7 @@ int k_mask(hipStream_t s, uint64_t state, uint64_t inv_density, int64_t cell0, i
 // transposed = 1: column = gene, rows = local cells.  The hash always takes
 // (global cell, gene) in that order (src/singlet.cpp:450).
 template <bool FILL>
-__global__ __launch_bounds__(256) void synth_kernel(uint64_t S, uint64_t inv_density, const double* __restrict__ levels,
+__global__ __launch_bounds__(256) void synth_kernel(uint64_t S, SglDiv inv_density, const double* __restrict__ levels,
                                                     int transposed, int64_t cell_offset, int32_t ncells, int32_t ngenes,
                                                     int64_t* __restrict__ counts, const int64_t* __restrict__ p,
                                                     int32_t* __restrict__ idx, double* __restrict__ x) {
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void synth_kernel(uint64_t S, uint64_t inv_den
             if (r < nrow) {
                 const uint64_t h = transposed ? sgl_rand2(S, (uint64_t)(cell_offset + r), (uint64_t)col)
                                               : sgl_rand_j(xi, (uint64_t)r);
-                drawn = (h % inv_density) == 0;
+                drawn = sgl_divides(h, inv_density);
             }
             const unsigned long long m = __ballot(drawn);
             if (FILL) {
@@ -95,7 +95,7 @@ int k_synth_count(hipStream_t s, uint64_t S, uint64_t inv_density, int transpose
                   int32_t ncells, int32_t ngenes, int64_t* counts) {
     const int64_t ncol = transposed ? ngenes : ncells;
     if (ncol <= 0) return SGL_OK;
-    synth_kernel<false><<<dim3(wave_grid(ncol)), dim3(256), 0, s>>>(S, inv_density, nullptr, transposed, cell_offset,
+    synth_kernel<false><<<dim3(wave_grid(ncol)), dim3(256), 0, s>>>(S, sgl_div_make(inv_density), nullptr, transposed, cell_offset,
                                                                     ncells, ngenes, counts, nullptr, nullptr, nullptr);
     HIPCHK(hipGetLastError());
     return SGL_OK;
@@ -105,7 +105,7 @@ int k_synth_fill(hipStream_t s, uint64_t S, uint64_t inv_density, const double* 
                  int64_t cell_offset, int32_t ncells, int32_t ngenes, const int64_t* p, int32_t* idx, double* x) {
     const int64_t ncol = transposed ? ngenes : ncells;
     if (ncol <= 0) return SGL_OK;
-    synth_kernel<true><<<dim3(wave_grid(ncol)), dim3(256), 0, s>>>(S, inv_density, levels16_dev, transposed,
+    synth_kernel<true><<<dim3(wave_grid(ncol)), dim3(256), 0, s>>>(S, sgl_div_make(inv_density), levels16_dev, transposed,
                                                                    cell_offset, ncells, ngenes, nullptr, p, idx, x);
     HIPCHK(hipGetLastError());
     return SGL_OK;

@@ -5,6 +5,7 @@
 //  * mse_test (src/singlet.cpp:536-568).
 // The hash is the bit-exact uint64 rng of kernels_hash.hip.
 #include "sgl_internal.h"
+#include <cstdlib>
 
 // lower-triangle pair p -> (i, j), i >= j, p = i*(i+1)/2 + j
 __device__ __forceinline__ void tri_unrank(int p, int& i, int& j) {
@@ -20,7 +21,7 @@ template <int PMAX>
 __global__ __launch_bounds__(256) void mask_gram_kernel(int64_t col0, int64_t ncols, int32_t nrow,
                                                         const int64_t* __restrict__ col_nnz,
                                                         const double* __restrict__ F, const double* __restrict__ G,
-                                                        int k, uint64_t seed, uint64_t inv_density, int mask_t,
+                                                        int k, uint64_t seed, SglDiv inv_density, int mask_t,
                                                         int64_t col_off, int64_t row_off, double* __restrict__ Gout) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     int* list = reinterpret_cast<int*>(smem_raw);                 // [256] drawn rows of the current chunk
@@ -90,15 +91,148 @@ __global__ __launch_bounds__(256) void mask_gram_kernel(int64_t col0, int64_t nc
     }
 }
 
+// Same downdate on the FP64 matrix cores, k <= 64 (NT = ceil(k / 16) <= 4).  AAt(submat(w, idx)) is a
+// k x |idx| by |idx| x k contraction: with v_mfma_f64_16x16x4_f64 (operand layout in kernels_dense.hip)
+// four drawn rows feed all NT (NT + 1) / 2 lower-triangle 16 x 16 tiles from NT loads per lane, where
+// the VALU kernel above reads two LDS operands per FMA.  One workgroup per column: every 256-row chunk
+// is hashed (one row per thread), the drawn rows are compacted into an LDS queue, and each of the 4
+// waves takes 4 queued rows per step; the 4 waves' tiles are summed at the end.
+typedef double mg_d4 __attribute__((ext_vector_type(4)));
+#define MG_QW 1024  // drawn rows a wave queues in LDS before it turns to the matrix cores
+
+template <int NT>
+__global__ __launch_bounds__(256) void mask_gram_mfma_kernel(int64_t col0, int64_t ncols, int32_t nrow,
+                                                             const int64_t* __restrict__ col_nnz,
+                                                             const double* __restrict__ F, const double* __restrict__ G,
+                                                             int k, uint64_t seed, SglDiv inv_density, int mask_t,
+                                                             int64_t col_off, int64_t row_off, double* __restrict__ Gout) {
+    constexpr int NTILES = NT * (NT + 1) / 2;
+    __shared__ int list[4 * MG_QW];
+    __shared__ double sm[4][64 * 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, kk = lane >> 4;
+    const int64_t lc = blockIdx.x;
+    if (lc >= ncols) return;
+    const int64_t col = col0 + lc;
+    double* out = Gout + (size_t)lc * k * k;
+    if (col_nnz != nullptr && col_nnz[col] == 0) return;  // column is skipped by predict_mask (l.444)
+
+    mg_d4 acc[NTILES];
+#pragma unroll
+    for (int t = 0; t < NTILES; ++t) acc[t] = mg_d4{0, 0, 0, 0};
+    // Every wave works on its own: it hashes 64 rows per step (one per lane), compacts the drawn ones
+    // into its own LDS queue (no workgroup barrier), and drains the queue through the matrix cores in
+    // groups of 4 rows.  operands of group g for this lane: row q[4 g + kk], factors b*16 + r16.
+    int* q = list + wave * MG_QW;
+    auto load_group = [&](double (&f)[NT], int g, int pending) {
+        const int idx = 4 * g + kk;
+        const bool valid = idx < pending;
+        const int row = valid ? q[idx] : 0;
+#pragma unroll
+        for (int b = 0; b < NT; ++b) {
+            const int fr = b * 16 + r16;
+            f[b] = (valid && fr < k) ? F[(int64_t)row * k + fr] : 0.0;
+        }
+    };
+    auto mfma_group = [&](const double (&f)[NT]) {
+        int t = 0;
+#pragma unroll
+        for (int bi = 0; bi < NT; ++bi)
+#pragma unroll
+            for (int bj = 0; bj <= bi; ++bj) {
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[bi], f[bj], acc[t], 0, 0, 0);
+                ++t;
+            }
+    };
+    // four groups' gathers (from L2) in flight before their MFMAs; `all` also takes the last, partial
+    // group (missing rows contribute zeros)
+    auto drain = [&](int pending, bool all) -> int {
+        const int ngroups = all ? (pending + 3) / 4 : pending / 4;
+        int g = 0;
+        for (; g + 4 <= ngroups; g += 4) {
+            double f0[NT], f1[NT], f2[NT], f3[NT];
+            load_group(f0, g, pending); load_group(f1, g + 1, pending); load_group(f2, g + 2, pending); load_group(f3, g + 3, pending);
+            mfma_group(f0); mfma_group(f1); mfma_group(f2); mfma_group(f3);
+        }
+        for (; g < ngroups; ++g) {
+            double f0[NT];
+            load_group(f0, g, pending);
+            mfma_group(f0);
+        }
+        return ngroups * 4;
+    };
+
+    const uint64_t gcol = (uint64_t)(col + col_off);
+    int pending = 0;  // rows queued by this wave (wave-uniform)
+    for (int64_t r0 = (int64_t)wave * 64; r0 < nrow; r0 += 256) {
+        const int64_t r = r0 + lane;
+        bool drawn = false;
+        if (r < nrow) {
+            const uint64_t grow = (uint64_t)(r + row_off);
+            drawn = mask_t ? sgl_draw(seed, grow, gcol, inv_density) : sgl_draw(seed, gcol, grow, inv_density);
+        }
+        const unsigned long long m = __ballot(drawn);
+        if (drawn) q[pending + __popcll(m & ((1ull << lane) - 1ull))] = (int)r;
+        pending += __popcll(m);
+        if (pending > MG_QW - 64) {  // another step might not fit
+            const int done = drain(pending, false);
+            const int rem = pending - done;  // < 4 left-over rows move to the front
+            const int v = (lane < rem) ? q[done + lane] : 0;
+            if (lane < rem) q[lane] = v;
+            pending = rem;
+        }
+    }
+    drain(pending, true);
+
+    // sum the 4 waves' tiles in a fixed order; Gout = G - (Gsub + 1e-15 I)  (quirk 8: the two 1e-15 cancel)
+    int t = 0;
+#pragma unroll
+    for (int bi = 0; bi < NT; ++bi)
+#pragma unroll
+        for (int bj = 0; bj <= bi; ++bj) {
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sm[wave][lane * 4 + r] = acc[t][r];
+            __syncthreads();
+            if (wave == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    double sub = ((sm[0][lane * 4 + r] + sm[1][lane * 4 + r]) + sm[2][lane * 4 + r]) + sm[3][lane * 4 + r];
+                    const int row = bi * 16 + kk + 4 * r;  // D row (lane >> 4) + 4 r
+                    const int cc = bj * 16 + r16;          // D col lane & 15
+                    if (row < k && cc < k) {
+                        if (row == cc) sub += 1e-15;
+                        const double v = G[(size_t)cc * k + row] - sub;
+                        out[(size_t)cc * k + row] = v;
+                        if (row != cc) out[(size_t)row * k + cc] = v;
+                    }
+                }
+            }
+            ++t;
+        }
+}
+
 int k_mask_gram_cols(hipStream_t s, int64_t col0, int64_t ncols, int32_t nrow, const int64_t* col_nnz,
                      const double* F, const double* G, int k, uint64_t seed, uint64_t inv_density, int mask_t,
                      int64_t col_offset, int64_t row_offset, double* Gcols) {
     if (ncols <= 0) return SGL_OK;
+    dim3 g((unsigned)ncols), b(256);
+    if (k <= 64 && !getenv("SGL_MASK_GRAM_VALU")) {  // env: keep the VALU kernel reachable for A/B tests
+#define SGL_MGM(NT_) mask_gram_mfma_kernel<NT_><<<g, b, 0, s>>>(col0, ncols, nrow, col_nnz, F, G, k, seed, sgl_div_make(inv_density), mask_t, col_offset, row_offset, Gcols)
+        switch ((k + 15) / 16) {
+            case 1: SGL_MGM(1); break;
+            case 2: SGL_MGM(2); break;
+            case 3: SGL_MGM(3); break;
+            default: SGL_MGM(4); break;
+        }
+#undef SGL_MGM
+        HIPCHK(hipGetLastError());
+        return SGL_OK;
+    }
     const int npairs = k * (k + 1) / 2;
     const int P = (npairs + 255) / 256;
     const size_t smem = 264 * 4 + sizeof(double) * 16 * (size_t)k;
-    dim3 g((unsigned)ncols), b(256);
-#define SGL_MG(PM) mask_gram_kernel<PM><<<g, b, smem, s>>>(col0, ncols, nrow, col_nnz, F, G, k, seed, inv_density, mask_t, col_offset, row_offset, Gcols)
+#define SGL_MG(PM) mask_gram_kernel<PM><<<g, b, smem, s>>>(col0, ncols, nrow, col_nnz, F, G, k, seed, sgl_div_make(inv_density), mask_t, col_offset, row_offset, Gcols)
     if (P <= 4) SGL_MG(4);
     else if (P <= 9) SGL_MG(9);
     else if (P <= 20) SGL_MG(20);
@@ -117,7 +251,7 @@ __global__ __launch_bounds__(256) void mse_test_kernel(const double* __restrict_
                                                        const int64_t* __restrict__ Ap, int32_t m, int64_t n,
                                                        int64_t cell_off, const double* __restrict__ Wd,
                                                        const double* __restrict__ H, int k, uint64_t seed,
-                                                       uint64_t inv_density, double* __restrict__ losses) {
+                                                       SglDiv inv_density, double* __restrict__ losses) {
     __shared__ int queue[4][128];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t gw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -134,7 +268,7 @@ __global__ __launch_bounds__(256) void mse_test_kernel(const double* __restrict_
             const int g = g0 + lane;
             const bool last = g0 >= m;
             bool drawn = false;
-            if (!last && g < m) drawn = (sgl_rand_j(xi, (uint64_t)g) % inv_density) == 0;
+            if (!last && g < m) drawn = sgl_divides(sgl_rand_j(xi, (uint64_t)g), inv_density);
             const unsigned long long mk = __ballot(drawn);
             if (drawn) qv[qn + __popcll(mk & ((1ull << lane) - 1ull))] = g;
             qn += __popcll(mk);
@@ -211,7 +345,7 @@ int k_mse_test(sgl_ctx* c, const double* Wd, const double* H, int k, uint64_t se
     int64_t blocks = (n + 3) / 4;
     if (blocks > 256 * 16) blocks = 256 * 16;
     mse_test_kernel<<<dim3((unsigned)blocks), dim3(256), 0, c->stream>>>(c->A.x, c->A.i, c->A.p, c->A.nrow, n,
-                                                                         c->cell_offset, Wd, H, k, seed, inv_density,
+                                                                         c->cell_offset, Wd, H, k, seed, sgl_div_make(inv_density),
                                                                          losses);
     HIPCHK(hipGetLastError());
     sum_partial_kernel<<<dim3(nblocks), dim3(256), 0, c->stream>>>(losses, n, part);

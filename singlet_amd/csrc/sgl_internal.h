@@ -218,6 +218,21 @@ __device__ __forceinline__ uint64_t sgl_rand_j(uint64_t xi, uint64_t j) {
     x ^= x >> 4;
     return x;
 }
-__device__ __forceinline__ bool sgl_draw(uint64_t state, uint64_t i, uint64_t j, uint64_t inv_density) {
-    return (sgl_rand2(state, i, j) % inv_density) == 0;
+// `x % d == 0` for a kernel-uniform divisor without a 64-bit division per test (hipcc expands a
+// runtime u64 modulo into a long software routine, the bulk of the hashing cost of the masked path).
+// With M = floor((2^64 - 1) / d): q = mulhi(x, M) is floor(x / d) or up to 2 less, so x - q d needs
+// at most two conditional subtractions.  Exact for every x and d >= 1 (d = 0 is rejected on the host).
+struct SglDiv {
+    uint64_t d, M;
+};
+static inline SglDiv sgl_div_make(uint64_t d) { return SglDiv{d, d > 1 ? ~0ull / d : 0ull}; }
+__device__ __forceinline__ bool sgl_divides(uint64_t x, SglDiv dv) {
+    if (dv.d <= 1) return true;
+    uint64_t r = x - __umul64hi(x, dv.M) * dv.d;
+    r -= (r >= dv.d) ? dv.d : 0ull;
+    r -= (r >= dv.d) ? dv.d : 0ull;
+    return r == 0;
+}
+__device__ __forceinline__ bool sgl_draw(uint64_t state, uint64_t i, uint64_t j, SglDiv inv_density) {
+    return sgl_divides(sgl_rand2(state, i, j), inv_density);
 }

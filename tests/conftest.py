@@ -58,3 +58,19 @@ def same_zero_pattern(a, b, eps=1e-12):
     thr = eps * max(np.abs(b).max(), 1e-300)
     diff = (a == 0) != (b == 0)
     return bool(np.all(~diff | (np.abs(a) < thr) & (np.abs(b) < thr)))
+
+
+@pytest.fixture(autouse=True)
+def _no_pending_hip_error(request):
+    """After every GPU test the HIP runtime must be left without a sticky error: a pending error
+    makes the next library that probes the runtime in this process (torch, RCCL) see 'no GPU'."""
+    yield
+    if request.node.get_closest_marker("gpu") is None:
+        return
+    import ctypes
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+    except OSError:
+        return
+    err = hip.hipPeekAtLastError()
+    assert err == 0, "test left HIP error %d pending" % err

@@ -31,10 +31,13 @@ def test_rand_bulk_bit_exact(ctx, ora):
         assert np.array_equal(got, exp)
 
 
-@pytest.mark.parametrize("inv_density", [20, 5, 1])
+@pytest.mark.parametrize("inv_density", [20, 5, 1, 2, 3, 7, 64, 1000, 2 ** 20 + 7])
 def test_mask_bit_exact(ctx, ora, inv_density):
-    got = ctx.op_mask(42, inv_density, 1000, 37, 515)
-    exp = ora.rng_mask(42, 1000, 37, 515, inv_density)
+    """draw = (rand % inv_density == 0): the device replaces the u64 modulo by a multiply-high test
+    (sgl_divides); powers of two, small and large divisors, and d = 1 must all agree bit for bit."""
+    ncells, ngenes = (37, 515) if inv_density < 1000 else (400, 3000)
+    got = ctx.op_mask(42, inv_density, 1000, ncells, ngenes)
+    exp = ora.rng_mask(42, 1000, ncells, ngenes, inv_density)
     assert np.array_equal(got, exp)
 
 

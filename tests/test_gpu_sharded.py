@@ -38,7 +38,9 @@ class TwoShardSum:
 @pytest.mark.timeout(300)
 @pytest.mark.parametrize("m,n,k,split", [(300, 1000, 8, 430), (257, 700, 30, 1), (500, 640, 50, 320)])
 def test_two_shards_one_gpu_match_unsharded(sa, ora, m, n, k, split):
-    pytest.importorskip("torch")
+    torch = pytest.importorskip("torch")
+    torch.cuda.init()                      # in the main thread, before the two shard threads use it
+    assert torch.cuda.device_count() >= 1
     A = ora.synth_csc(m, n, 20)
     At = A.t()
     w0 = ora.synth_winit(k, m)
