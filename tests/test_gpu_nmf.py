@@ -250,3 +250,50 @@ def test_c_nmf_with_nnls_repack(sa, ora, monkeypatch):
     ref = ora.c_nmf(A, At, 0.0, 4, 0.01, 0.01, 0.0, 0.0, 0, w0)
     got = sa.c_nmf(to_dgc(sa, A), to_dgc(sa, At), 0.0, 4, False, 0.01, 0.01, 0.0, 0.0, 0, w0.T)
     _check(got, ref)
+
+
+@pytest.mark.timeout(900)
+def test_config2_full_size_parity(sa, ora):
+    """BASELINE config 2 at full size (20 000 genes x 50 000 cells, 5 % nnz, k = 30): three ALS
+    iterations through the one-shot entry point (host dgCMatrix in, transpose built on the device)
+    against the oracle on the same matrix."""
+    m, n, k = 20000, 50000, 30
+    A = ora.synth_csc(m, n, 20)
+    At = A.t()
+    w0 = ora.synth_winit(k, m)
+    ref = ora.c_nmf(A, At, 0.0, 3, 0.01, 0.01, 0.0, 0.0, 0, w0)
+    got = sa.c_nmf(to_dgc(sa, A), None, 0.0, 3, False, 0.01, 0.01, 0.0, 0.0, 0, w0.T)
+    _check(got, ref)
+    assert got["iter"] == 3 and np.allclose(got["tol"], ref["tol"], rtol=1e-8)
+
+
+@pytest.mark.timeout(900)
+def test_config3_full_size_tiled_equals_plain(sa):
+    """BASELINE config 3 at full size (30 000 genes x 1 000 000 cells, nnz 1.5e9, k = 50), too big
+    for the oracle: the LDS-tiled path the bench runs must agree with the plain CSC kernel (an
+    independent implementation of the same sums) after two full ALS iterations, the factors must be
+    a fixed point of scale(), and a second run must be bit-identical."""
+    import os
+    genes, cells, k = 30000, 1000000, 50
+    c = sa.Context(0)
+    try:
+        c.synth(genes, cells, 20)
+        runs = []
+        for mode in ("tiled", "plain", "tiled"):
+            if mode == "plain":
+                os.environ["SGL_NO_TILED"] = "1"
+            try:
+                c.fit_init(k, None)
+            finally:
+                os.environ.pop("SGL_NO_TILED", None)
+            it, tols = c.nmf_run(0.0, 2, 0.01, 0.01, 0.0, 0.0)
+            W, d, H = c.get_factors()
+            runs.append((W, d, H, tols))
+        (W, d, H, t), (Wp, dp, Hp, tp), (W2, d2, H2, t2) = runs
+        assert np.array_equal(W, W2) and np.array_equal(H, H2) and np.array_equal(d, d2) and np.array_equal(t, t2)
+        assert rel_fro(W, Wp) < 1e-11 and rel_fro(H, Hp) < 1e-11 and rel_fro(d, dp) < 1e-12
+        assert same_zero_pattern(W, Wp) and same_zero_pattern(H, Hp)
+        assert np.all(W >= 0) and np.all(H >= 0) and np.all(np.isfinite(H))
+        assert np.abs(W.sum(axis=0) - 1).max() < 1e-9
+    finally:
+        c.close()
