@@ -156,6 +156,17 @@ SGL_API int sgl_dims(const sgl_ctx* ctx, int32_t* nrow, int32_t* ncol, int64_t* 
  * of the device transpose).  which = 0: A, 1: At.  Buffers sized from sgl_dims. */
 SGL_API int sgl_download_csc(sgl_ctx* ctx, int which, double* x, int32_t* i, int64_t* p);
 
+/* Input staging on the resident shard, applied to A and its transpose in place
+ * (call before sgl_fit_init; a running fit is dropped).
+ * sgl_log_normalize: Seurat::LogNormalize as PreprocessData.dgCMatrix applies
+ *   it (R/PreprocessData.R:34-39): x <- log1p(x / colSums(A)[cell] * scale_factor).
+ * sgl_weight_by_split: weight_by_split (src/singlet.cpp:119-144): split_by[c] in
+ *   [0, n_groups) is the group of local cell c; cells of group g != 0 are divided
+ *   by (sum of group g) / (sum of group 0).  Group sums are global over shards
+ *   (all-reduce hook). */
+SGL_API int sgl_log_normalize(sgl_ctx* ctx, double scale_factor);
+SGL_API int sgl_weight_by_split(sgl_ctx* ctx, const int32_t* split_by, int32_t n_groups);
+
 /* Start a fit at rank k.  w_init: k x nrow host array, or NULL to fill W on
  * the device with the synthetic init ((rand_{S+2}(f,g) >> 11) + 0.5) * 2^-53.
  * h = 0, d = 1 as in src/singlet.cpp:639-641. */

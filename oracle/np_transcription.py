@@ -299,3 +299,29 @@ def c_ard_nmf(A, At, tol, maxit, L1, L2, w, seed, inv_density, overfit_threshold
         score.append((this_err - min_err) / (this_err + min_err))
     return dict(w=w, d=d, h=h, test_mse=np.array(test_mse), iter=np.array(iters, dtype=np.int32),
                 tol=np.array(fit_tol), score_overfit=np.array(score), n_iter=it)
+
+
+def log_normalize(x, p, scale_factor=10000.0):
+    """R/PreprocessData.R:34-39 (Seurat::LogNormalize): per column, x / colsum * scale, log1p."""
+    out = np.array(x, dtype=np.float64)
+    for c in range(len(p) - 1):
+        seg = out[p[c]:p[c + 1]]
+        s = 0.0
+        for v in seg:           # left-to-right, as a scalar loop sums
+            s += v
+        out[p[c]:p[c + 1]] = np.log1p(seg / s * scale_factor)
+    return out
+
+
+def weight_by_split(x, p, split_by, n_groups):
+    """src/singlet.cpp:119-144."""
+    out = np.array(x, dtype=np.float64)
+    sums = np.zeros(n_groups)
+    for j in range(len(p) - 1):
+        for v in out[p[j]:p[j + 1]]:
+            sums[split_by[j]] += v
+    sums[1:] /= sums[0]
+    for i in range(len(p) - 1):
+        if split_by[i] != 0:
+            out[p[i]:p[i + 1]] /= sums[split_by[i]]
+    return out

@@ -70,6 +70,10 @@ def lib():
         L.ora_c_ard_nmf.argtypes = csc + csc + [C.c_int32, C.c_int32, C.c_double, C.c_int, C.c_double, C.c_double,
                                                 C.c_int, C.c_int, _f64p, _f64p, _f64p, C.c_uint64, C.c_uint64,
                                                 C.c_double, C.c_int, _f64p, _i32p, _f64p, _f64p, _i32p]
+        L.ora_log_normalize.restype = None
+        L.ora_log_normalize.argtypes = [_f64p, _i32p, C.c_int32, C.c_double]
+        L.ora_weight_by_split.restype = None
+        L.ora_weight_by_split.argtypes = [_f64p, _i32p, C.c_int32, _i32p, C.c_int32]
         L.ora_synth_count.restype = C.c_int64
         L.ora_synth_count.argtypes = [C.c_uint64, C.c_uint64, C.c_int64, C.c_int64, C.c_int64, _i32p]
         L.ora_synth_fill.restype = None
@@ -270,6 +274,23 @@ def c_ard_nmf(A, At, tol, maxit, L1, L2, threads, w, seed, inv_density, overfit_
     q = nt.value
     return dict(w=w, d=d, h=h, test_mse=tm[:q].copy(), iter=itv[:q].copy(), tol=ft[:q].copy(),
                 score_overfit=so[:q].copy(), n_iter=it)
+
+
+def log_normalize(A, scale_factor=10000.0):
+    """PreprocessData.dgCMatrix (R/PreprocessData.R:34-39): a new CSC with x <- log1p(x / colsum * scale)."""
+    x = np.array(A.x, dtype=np.float64)
+    p = np.ascontiguousarray(A.p, dtype=np.int32)
+    lib().ora_log_normalize(_p(x, _f64p), _p(p, _i32p), A.ncol, float(scale_factor))
+    return CSC(x, A.i, A.p, A.nrow, A.ncol)
+
+
+def weight_by_split(A, split_by, n_groups):
+    """weight_by_split (src/singlet.cpp:119-144): a new CSC."""
+    x = np.array(A.x, dtype=np.float64)
+    p = np.ascontiguousarray(A.p, dtype=np.int32)
+    sb = np.ascontiguousarray(split_by, dtype=np.int32)
+    lib().ora_weight_by_split(_p(x, _f64p), _p(p, _i32p), A.ncol, _p(sb, _i32p), int(n_groups))
+    return CSC(x, A.i, A.p, A.nrow, A.ncol)
 
 
 def transpose(A):

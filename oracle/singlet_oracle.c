@@ -509,6 +509,32 @@ ORA_API void ora_synth_winit(uint64_t S, int k, int64_t ngenes, double* w) {
             w[(size_t)g * k + f] = ((double)(ora_rng_rand(S + 2, (uint64_t)f, (uint64_t)g) >> 11) + 0.5) * 0x1p-53;
 }
 
+/* Seurat::LogNormalize as PreprocessData.dgCMatrix applies it (R/PreprocessData.R:34-39):
+ * x <- log1p(x / colSums(A)[cell] * scale_factor), values updated in place.  (Seurat is a dependency
+ * absent from /root/reference; its LogNorm walks each column, divides by the column total, multiplies
+ * by the scale factor and takes log1p, in that order.) */
+ORA_API void ora_log_normalize(double* Ax, const int32_t* Ap, int32_t ncol, double scale_factor) {
+    for (int32_t c = 0; c < ncol; ++c) {
+        double s = 0.0;
+        for (int32_t q = Ap[c]; q < Ap[c + 1]; ++q) s += Ax[q];
+        for (int32_t q = Ap[c]; q < Ap[c + 1]; ++q) Ax[q] = log1p(Ax[q] / s * scale_factor);
+    }
+}
+
+/* weight_by_split -- src/singlet.cpp:119-144, values updated in place.  split_by: group of every
+ * column, 0-based; sums[g] over all values of group g in column order (l.125-129), sums[j] /= sums[0]
+ * for j >= 1 (l.132-133), columns of group != 0 divided by their group's ratio (l.136-141). */
+ORA_API void ora_weight_by_split(double* Ax, const int32_t* Ap, int32_t ncol, const int32_t* split_by, int32_t n_groups) {
+    double* sums = (double*)calloc((size_t)n_groups, sizeof(double));
+    for (int32_t j = 0; j < ncol; ++j)
+        for (int32_t q = Ap[j]; q < Ap[j + 1]; ++q) sums[split_by[j]] += Ax[q];
+    for (int32_t j = 1; j < n_groups; ++j) sums[j] /= sums[0];
+    for (int32_t i = 0; i < ncol; ++i)
+        if (split_by[i] != 0)
+            for (int32_t q = Ap[i]; q < Ap[i + 1]; ++q) Ax[q] /= sums[split_by[i]];
+    free(sums);
+}
+
 /* CSC -> CSC of the transpose (what Matrix::t(A) gives R, R/run_nmf.R:40):
  * rows ascending within each column by construction. */
 ORA_API void ora_transpose(const double* Ax, const int32_t* Ai, const int32_t* Ap, int32_t nrow, int32_t ncol,

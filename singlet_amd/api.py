@@ -169,6 +169,32 @@ def run_nmf(A, rank, tol=1e-4, maxit=100, verbose=True, L1=0.01, L2=0, threads=0
     return _sort_model(model, A.Dimnames[0], A.Dimnames[1])
 
 
+def _staged(A, op):
+    """Upload A, run a staging operator on the device, return the transformed dgCMatrix."""
+    from .context import Context
+    A = as_dgCMatrix(A)
+    c = Context(0)
+    try:
+        c.upload(A, None)
+        op(c)
+        x, i, p = c.download(0)
+    finally:
+        c.close()
+    return dgCMatrix(x, i, p.astype(np.int32), A.Dim, A.Dimnames)
+
+
+def PreprocessData(A, scale_factor=10000.0):
+    """PreprocessData.dgCMatrix (R/PreprocessData.R:34-39): Seurat::LogNormalize of a counts matrix,
+    log1p(x / colSums * scale_factor), computed on the device; dimnames kept."""
+    return _staged(A, lambda c: c.log_normalize(scale_factor))
+
+
+def weight_by_split(A_, split_by, n_groups):
+    """.Call(`_singlet_weight_by_split`, A_, split_by, n_groups)  (src/singlet.cpp:119-144):
+    returns a rescaled copy; split_by is the 0-based group of every column (R/RunNMF.R:86)."""
+    return _staged(A_, lambda c: c.weight_by_split(split_by, n_groups))
+
+
 def project_model(A, w, L1=0.01, L2=0, threads=0):
     """R/ProjectData.R:11-19."""
     A = as_dgCMatrix(A)

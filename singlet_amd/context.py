@@ -92,6 +92,20 @@ class Context:
         return x, i, p
 
     # -- fit ----------------------------------------------------------------
+    def log_normalize(self, scale_factor=10000.0):
+        """Seurat::LogNormalize on the resident shard (R/PreprocessData.R:34-39)."""
+        check(self._L.sgl_log_normalize(self._h, float(scale_factor)))
+        self.k = 0
+
+    def weight_by_split(self, split_by, n_groups):
+        """weight_by_split (src/singlet.cpp:119-144) on the resident shard; split_by: 0-based group per local cell."""
+        sb = np.ascontiguousarray(split_by, dtype=np.int32)
+        _, nc, _ = self.dims()
+        if sb.shape != (nc,):
+            raise ValueError("split_by must have one entry per cell (column) of A")
+        check(self._L.sgl_weight_by_split(self._h, ptr(sb, i32p), int(n_groups)))
+        self.k = 0
+
     def fit_init(self, k, w_init=None, synth_seed=SYNTH_SEED):
         """w_init: (m, k) C-contiguous (== k x m column-major) or None for the synthetic init."""
         w = None

@@ -159,6 +159,10 @@ void sgl_tiled_free(DevTiled& S);
 int sgl_tiled_build(sgl_ctx* c, const DevCSC& M, int k, DevTiled& S);
 int k_acc_tiled(hipStream_t s, const DevTiled& S, const double* F, double* B);
 
+// input staging (kernels_prep.hip)
+int k_colsum(hipStream_t s, const DevCSC& M, double* sums);
+int k_cell_factor(hipStream_t s, DevCSC& A, DevCSC& At, const double* f, int mode, double scale);
+
 // NNLS
 #define SGL_NNLS_MAX_PASSES 10
 // below this many columns the GPU is not full anyway: one pass (env SGL_NNLS_REPACK_MIN_COLS overrides, tests)

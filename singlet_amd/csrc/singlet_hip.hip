@@ -386,6 +386,60 @@ static int build_tiles(sgl_ctx* c, DevCSC& M, int k) {
 
 static int lane_kp(int k) { return (k + 1) / 2 * 2; }
 
+// ------------------------------------------------------------ input staging --
+extern "C" int sgl_log_normalize(sgl_ctx* c, double scale_factor) {
+    CTX_GUARD(c);
+    if (!c->A.p) { sgl_set_error("no matrix resident"); return SGL_ESTATE; }
+    free_fit(c);
+    c->k = 0;
+    double* sums = nullptr;
+    SGLCHK(dev_alloc(&sums, (size_t)std::max<int64_t>(c->A.ncol, 1)));
+    int rc = k_colsum(c->stream, c->A, sums);
+    if (rc == SGL_OK) rc = k_cell_factor(c->stream, c->A, c->At, sums, 0, scale_factor);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    dev_free(sums);
+    if (rc == SGL_OK && e != hipSuccess) { sgl_set_error("sgl_log_normalize: %s", hipGetErrorString(e)); rc = SGL_EHIP; }
+    return rc;
+}
+
+extern "C" int sgl_weight_by_split(sgl_ctx* c, const int32_t* split_by, int32_t n_groups) {
+    CTX_GUARD(c);
+    if (!c->A.p) { sgl_set_error("no matrix resident"); return SGL_ESTATE; }
+    if (!split_by || n_groups <= 0) { sgl_set_error("sgl_weight_by_split: bad arguments"); return SGL_EINVAL; }
+    const int64_t n = c->A.ncol;
+    for (int64_t j = 0; j < n; ++j)
+        if (split_by[j] < 0 || split_by[j] >= n_groups) { sgl_set_error("sgl_weight_by_split: group id out of range at cell %lld", (long long)j); return SGL_EINVAL; }
+    free_fit(c);
+    c->k = 0;
+    double *dsums = nullptr, *dgrp = nullptr;
+    SGLCHK(dev_alloc(&dsums, (size_t)std::max<int64_t>(n, 1)));
+    int rc = dev_alloc(&dgrp, (size_t)n_groups);
+    std::vector<double> colsum((size_t)n), grp((size_t)n_groups, 0.0);
+    if (rc == SGL_OK) rc = k_colsum(c->stream, c->A, dsums);
+    if (rc == SGL_OK && n > 0 && hipMemcpyAsync(colsum.data(), dsums, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = SGL_EHIP;
+    if (rc == SGL_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = SGL_EHIP;
+    if (rc == SGL_OK) {
+        // group totals in cell order (src/singlet.cpp:125-129 walks the cells in order), global over shards
+        for (int64_t j = 0; j < n; ++j) grp[split_by[j]] += colsum[j];
+        if (hipMemcpyAsync(dgrp, grp.data(), sizeof(double) * n_groups, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = SGL_EHIP;
+        if (rc == SGL_OK) rc = do_allreduce(c, dgrp, n_groups);
+        if (rc == SGL_OK && hipMemcpyAsync(grp.data(), dgrp, sizeof(double) * n_groups, hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = SGL_EHIP;
+        if (rc == SGL_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = SGL_EHIP;
+    }
+    if (rc == SGL_OK) {
+        // sums[j] /= sums[0] for j >= 1 (l.132-133); cells of group 0 are left alone (l.137)
+        for (int32_t g = 1; g < n_groups; ++g) grp[g] /= grp[0];
+        for (int64_t j = 0; j < n; ++j) colsum[j] = split_by[j] != 0 ? grp[split_by[j]] : 1.0;
+        if (n > 0 && hipMemcpyAsync(dsums, colsum.data(), sizeof(double) * n, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = SGL_EHIP;
+        if (rc == SGL_OK) rc = k_cell_factor(c->stream, c->A, c->At, dsums, 1, 0.0);
+        if (rc == SGL_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = SGL_EHIP;
+    }
+    dev_free(dsums);
+    dev_free(dgrp);
+    if (rc == SGL_EHIP) sgl_set_error("sgl_weight_by_split: HIP call failed");
+    return rc;
+}
+
 extern "C" int sgl_fit_init(sgl_ctx* c, int32_t k, const double* w_init, uint64_t synth_seed) {
     CTX_GUARD(c);
     if (!c->A.p || !c->At.p) { sgl_set_error("sgl_fit_init: no matrix resident"); return SGL_ESTATE; }

@@ -173,12 +173,13 @@ def test_pbmc3k_config1(sa, ora):
         s, e = p[c], p[c + 1]
         i[s:e] = np.cumsum(i[s:e])
     x = g["x"].astype(np.float64)
-    per_cell = np.diff(p)
-    xn = np.log1p(x / np.repeat(np.add.reduceat(x, p[:-1]), per_cell) * 1e4)
-    A = ora.CSC(xn, i.astype(np.int32), p, dim[0], dim[1])
+    counts = ora.CSC(x, i.astype(np.int32), p, dim[0], dim[1])
+    A = ora.log_normalize(counts, 1e4)                       # oracle: LogNormalize then the fit
     w0 = ora.synth_winit(10, dim[0])
     ref = ora.c_nmf(A, A.t(), 0.0, 6, 0.01, 0.01, 0.0, 0.0, 0, w0)
-    got = sa.c_nmf(to_dgc(sa, A), None, 0.0, 6, False, 0.01, 0.01, 0.0, 0.0, 0, w0.T)
+    dA = sa.PreprocessData(to_dgc(sa, counts))               # device: PreprocessData.dgCMatrix then c_nmf
+    assert rel_fro(dA.x, A.x) < 1e-14
+    got = sa.c_nmf(dA, None, 0.0, 6, False, 0.01, 0.01, 0.0, 0.0, 0, w0.T)
     _check(got, ref)
     order = np.argsort(-got["d"], kind="stable")
     assert np.array_equal(order, np.argsort(-ref["d"], kind="stable"))

@@ -164,3 +164,43 @@ def test_device_transpose(ctx, ora, sa):
     At = A.t()
     x, i, p = ctx.download(1)
     assert np.array_equal(p, At.p.astype(np.int64)) and np.array_equal(i, At.i) and np.array_equal(x, At.x)
+
+
+def test_log_normalize_and_weight_by_split(sa, ora):
+    """Device staging operators against the oracle, on A and on the resident transpose; the float
+    tolerance (1e-14 relative) covers the device log1p and the tree-order column sums."""
+    A = ora.synth_csc(300, 257, 10)
+    counts = ora.CSC(np.round(np.expm1(A.x)) + 1.0, A.i, A.p, A.nrow, A.ncol)
+    sb = np.random.default_rng(5).integers(0, 4, A.ncol).astype(np.int32)
+    ref_ln = ora.log_normalize(counts, 1e4)
+    ref_ws = ora.weight_by_split(ref_ln, sb, 4)
+    c = sa.Context(0)
+    try:
+        c.upload(to_dgc(sa, counts), None)
+        c.log_normalize(1e4)
+        x, i, p = c.download(0)
+        assert np.array_equal(i, counts.i) and np.array_equal(p, counts.p)
+        assert rel_fro(x, ref_ln.x) < 1e-14 and np.abs(x - ref_ln.x).max() < 1e-13
+        xt, it, pt = c.download(1)
+        T = ref_ln.t()
+        assert np.array_equal(it, T.i) and np.array_equal(pt, T.p) and rel_fro(xt, T.x) < 1e-14
+        c.weight_by_split(sb, 4)
+        x2, _, _ = c.download(0)
+        assert rel_fro(x2, ref_ws.x) < 1e-14
+        xt2, _, _ = c.download(1)
+        assert rel_fro(xt2, ref_ws.t().x) < 1e-14
+        # the transformed matrix is what the fit then sees
+        c.fit_init(5, ora.synth_winit(5, A.nrow))
+        c.nmf_run(0.0, 3, 0.01, 0.01, 0.0, 0.0)
+        W, d, H = c.get_factors()
+        r = ora.c_nmf(ref_ws, ref_ws.t(), 0.0, 3, 0.01, 0.01, 0.0, 0.0, 0, ora.synth_winit(5, A.nrow))
+        assert rel_fro(W, r["w"]) < 1e-9 and rel_fro(H, r["h"]) < 1e-9
+    finally:
+        c.close()
+    # R-level mirrors (round trip through the device)
+    got = sa.PreprocessData(to_dgc(sa, counts))
+    assert rel_fro(got.x, ref_ln.x) < 1e-14
+    got2 = sa.weight_by_split(got, sb, 4)
+    assert rel_fro(got2.x, ref_ws.x) < 1e-13
+    with pytest.raises(sa.SingletHipError):
+        sa.weight_by_split(got, sb + 7, 4)   # group ids out of range

@@ -83,3 +83,44 @@ def test_two_shards_one_gpu_match_unsharded(sa, ora, m, n, k, split):
     H = np.vstack([H0, H1])
     assert rel_fro(W0, ref["w"]) < 1e-9 and rel_fro(H, ref["h"]) < 1e-9 and rel_fro(d0, ref["d"]) < 1e-9
     assert rel_fro(W0, one["w"].T) < 1e-11 and rel_fro(H, one["h"].T) < 1e-11
+
+
+@pytest.mark.timeout(300)
+def test_two_shards_weight_by_split_uses_global_group_sums(sa, ora):
+    """weight_by_split needs the group totals over ALL cells: each shard contributes its part through
+    the all-reduce hook, and the rescaled shard must equal the slice of the unsharded result."""
+    torch = pytest.importorskip("torch")
+    torch.cuda.init()
+    m, n, split = 200, 500, 170
+    A = ora.synth_csc(m, n, 10)
+    sb = np.random.default_rng(9).integers(0, 3, n).astype(np.int32)
+    ref = ora.weight_by_split(A, sb, 3)
+    bounds = [0, split, n]
+    red = TwoShardSum()
+    out, errs = [None, None], []
+
+    def worker(r):
+        try:
+            lo, hi = bounds[r], bounds[r + 1]
+            s, e = A.p[lo], A.p[hi]
+            Ash = ora.CSC(A.x[s:e], A.i[s:e], A.p[lo:hi + 1] - A.p[lo], m, hi - lo)
+            c = sa.Context(0)
+            try:
+                c.upload(to_dgc(sa, Ash), None, cell_offset=lo, ncells_total=n)
+                c.set_allreduce(red.hook(r))
+                c.weight_by_split(sb[lo:hi], 3)
+                out[r] = (c.download(0)[0], s, e)
+            finally:
+                c.close()
+        except Exception as exc:  # noqa: BLE001
+            errs.append(exc)
+            red.bar.abort()
+
+    th = [threading.Thread(target=worker, args=(r,)) for r in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(280)
+    assert not errs, errs
+    for x, s, e in out:
+        assert rel_fro(x, ref.x[s:e]) < 1e-14

@@ -116,6 +116,24 @@ def test_rcpp_predict_against_transcription(ora):
         assert np.array_equal(ora.rcpp_predict(A, w, 0.01, 0.0), ref), shape
 
 
+def test_staging_ops_against_transcription(ora):
+    """LogNormalize (R/PreprocessData.R:34-39) and weight_by_split (src/singlet.cpp:119-144)."""
+    from oracle import np_transcription as npt
+    A = ora.synth_csc(120, 90, 8)
+    counts = ora.CSC(np.round(np.expm1(A.x)), A.i, A.p, A.nrow, A.ncol)   # integer "counts"
+    ln = ora.log_normalize(counts, 1e4)
+    ref = npt.log_normalize(counts.x, counts.p, 1e4)
+    assert np.abs(ln.x - ref).max() <= 4e-16 * np.abs(ref).max()   # libm vs numpy log1p: last-bit differences
+    assert np.array_equal(ln.i, counts.i) and np.array_equal(ln.p, counts.p)
+    sb = np.random.default_rng(0).integers(0, 3, A.ncol)
+    ws = ora.weight_by_split(ln, sb, 3)
+    assert np.array_equal(ws.x, npt.weight_by_split(ln.x, ln.p, sb, 3))
+    per_cell = np.repeat(sb, np.diff(A.p))
+    totals = [ws.x[per_cell == g].sum() for g in range(3)]
+    assert np.allclose(totals, totals[0], rtol=1e-12)               # every group now weighs as much as group 0
+    assert np.array_equal(ws.x[per_cell == 0], ln.x[per_cell == 0])  # group 0 untouched (l.137)
+
+
 def test_nnls_quirks(ora):
     """SURVEY.md 8a quirks 2-5 on hand-made cases."""
     G = np.array([[2.0, 0.5], [0.5, 1.0]])
