@@ -102,6 +102,23 @@ SGL_API int sgl_c_ard_nmf(const double* Ax, const int32_t* Ai, const int32_t* Ap
                   double* test_mse, int32_t* iter, double* tol_out, double* score_overfit, int32_t* n_trace,
                   const sgl_callbacks* cb);
 
+/* c_linked_nmf (src/singlet.cpp:1059-1086; predict_link :416-433), the linked
+ * NMF behind R/RunLNMF.R:60.  Replaces _singlet_c_linked_nmf (11 args).  link_h
+ * (link_h_rows x link_h_cols, column-major) multiplies the first link_h_rows
+ * entries of every cell's right-hand side before its NNLS solve; it is applied
+ * iff link_h_cols == ncol (l.1064).  link_w likewise for genes, iff
+ * link_w_cols == nrow (l.1065).  Either may be NULL. */
+SGL_API int sgl_c_linked_nmf(const double* Ax, const int32_t* Ai, const int32_t* Ap,
+                     const double* Atx, const int32_t* Ati, const int32_t* Atp,
+                     int32_t nrow, int32_t ncol,
+                     double tol, uint16_t maxit, int verbose,
+                     double L1, double L2, uint16_t threads,
+                     const double* w_init, int32_t k,
+                     const double* link_h, int32_t link_h_rows, int32_t link_h_cols,
+                     const double* link_w, int32_t link_w_rows, int32_t link_w_cols,
+                     double* w_out, double* d_out, double* h_out,
+                     int32_t* n_iter, double* tol_trace, const sgl_callbacks* cb);
+
 /* c_project_model (src/singlet.cpp:405-413).
  * Replaces _singlet_c_project_model (src/RcppExports.cpp:444-447 region).
  * w is w_rows x w_cols column-major; if w_rows == nrow it is transposed first
@@ -171,6 +188,11 @@ SGL_API int sgl_weight_by_split(sgl_ctx* ctx, const int32_t* split_by, int32_t n
  * the device with the synthetic init ((rand_{S+2}(f,g) >> 11) + 0.5) * 2^-53.
  * h = 0, d = 1 as in src/singlet.cpp:639-641. */
 SGL_API int sgl_fit_init(sgl_ctx* ctx, int32_t k, const double* w_init, uint64_t synth_seed);
+
+/* Link matrices of c_linked_nmf for the current fit (after sgl_fit_init; the
+ * rules of sgl_c_linked_nmf; link_h columns are the cells of this shard). */
+SGL_API int sgl_set_links(sgl_ctx* ctx, const double* link_h, int32_t link_h_rows, int32_t link_h_cols,
+                          const double* link_w, int32_t link_w_rows, int32_t link_w_cols);
 
 /* Collective hook for cell-sharded runs.  Called with a device pointer to
  * `count` doubles that must be summed in place over all shards.  Ordering:

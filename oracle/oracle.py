@@ -63,6 +63,10 @@ def lib():
         L.ora_c_nmf.restype = C.c_int
         L.ora_c_nmf.argtypes = csc + csc + [C.c_int32, C.c_int32, C.c_double, C.c_int] + [C.c_double] * 4 + [
             C.c_int, C.c_int, _f64p, _f64p, _f64p, _f64p, _f64p, _i64p]
+        L.ora_c_linked_nmf.restype = C.c_int
+        L.ora_c_linked_nmf.argtypes = csc + csc + [C.c_int32, C.c_int32, C.c_double, C.c_int, C.c_double, C.c_double,
+                                                   C.c_int, C.c_int, _f64p, _f64p, C.c_int32, C.c_int32, _f64p,
+                                                   C.c_int32, C.c_int32, _f64p, _f64p, _f64p]
         L.ora_c_project_model.restype = C.c_int
         L.ora_c_project_model.argtypes = csc + [C.c_int32, C.c_int32, _f64p, C.c_int32, C.c_int32, C.c_double,
                                                 C.c_double, C.c_int, _f64p, _f64p]
@@ -243,6 +247,31 @@ def c_project_model(A, w, L1, L2, threads=0):
     lib().ora_c_project_model(*pa, A.nrow, A.ncol, _p(wf, _f64p), w_rows, w_cols, L1, L2, threads, _p(h, _f64p),
                               _p(d, _f64p))
     return dict(h=h, d=d)
+
+
+def c_linked_nmf(A, At, tol, maxit, L1, L2, threads, w, link_h, link_w):
+    """c_linked_nmf (src/singlet.cpp:1059-1086).  w: (m, k) array (== k x m column-major); link_h /
+    link_w: R-orientation 2-D arrays (rows x cols) or None.  Returns w (m, k), d, h (n, k), iter, tol."""
+    ka, pa = _csc(A.x, A.i, A.p)
+    kt, pt = _csc(At.x, At.i, At.p)
+    w = np.array(w, dtype=np.float64, order="C")
+    m, k = w.shape
+    n = A.ncol
+    h = np.empty((n, k))
+    d = np.empty(k)
+    tr = np.zeros(max(int(maxit), 1))
+
+    def link(Lk):
+        if Lk is None:
+            return None, 0, 0, None
+        Lk = np.asarray(Lk, dtype=np.float64)
+        buf = np.ascontiguousarray(Lk.T)   # column-major image
+        return _p(buf, _f64p), Lk.shape[0], Lk.shape[1], buf
+    lh, lhr, lhc, keep1 = link(link_h)
+    lw, lwr, lwc, keep2 = link(link_w)
+    it = lib().ora_c_linked_nmf(*pa, *pt, A.nrow, n, tol, int(maxit), L1, L2, threads, k, _p(w, _f64p), lh, lhr, lhc, lw,
+                                lwr, lwc, _p(h, _f64p), _p(d, _f64p), _p(tr, _f64p))
+    return dict(w=w, d=d, h=h, iter=it, tol=tr[:it].copy())
 
 
 def rcpp_predict(A, w, L1, L2, threads=0):

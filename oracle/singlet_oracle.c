@@ -196,8 +196,10 @@ typedef struct {
 /* predict(A, w, h, L1, L2, threads) sparse -- src/singlet.cpp:333-347
  * F: k x A.nrow (operand factor), X: k x A.ncol (in/out, warm start).
  * sweeps_out (optional): sum of NNLS sweeps over solved columns. */
-static void predict(csc_t A, const double* F, double* X, int k, double L1, double L2, int threads,
-                    int64_t* sweeps_out) {
+/* link == NULL: predict (l.333-347).  Otherwise predict_link (l.416-433): after the right-hand side
+ * of column c is summed, its first link_rows entries are multiplied by link[:, c] (l.429-430). */
+static void predict_x(csc_t A, const double* F, double* X, int k, double L1, double L2, int threads,
+                      int64_t* sweeps_out, const double* link, int link_rows) {
     double* a = (double*)malloc(sizeof(double) * k * k);
     ora_aat(F, k, A.nrow, a);
     int64_t sweeps = 0;
@@ -211,10 +213,17 @@ static void predict(csc_t A, const double* F, double* X, int k, double L1, doubl
             const double* f = F + (size_t)A.i[q] * k;
             for (int j = 0; j < k; ++j) b[j] += v * f[j];
         }
+        if (link)
+            for (int j = 0; j < link_rows && j < k; ++j) b[j] *= link[(size_t)c * link_rows + j];
         sweeps += nnls_col(a, b, X + (size_t)c * k, k, L1, L2);
     }
     if (sweeps_out) *sweeps_out += sweeps;
     free(a);
+}
+
+static void predict(csc_t A, const double* F, double* X, int k, double L1, double L2, int threads,
+                    int64_t* sweeps_out) {
+    predict_x(A, F, X, k, L1, L2, threads, sweeps_out, NULL, 0);
 }
 
 ORA_API void ora_predict(const double* Ax, const int32_t* Ai, const int32_t* Ap, int32_t nrow, int32_t ncol,
@@ -375,6 +384,36 @@ ORA_API int ora_c_nmf(const double* Ax, const int32_t* Ai, const int32_t* Ap, co
             phase_sec[2] += t3 - t2;
             phase_sec[3] += t4 - t3;
         }
+        if (tol_trace) tol_trace[iter_] = tol_;
+    }
+    free(w_it);
+    return iter_;
+}
+
+/* c_linked_nmf -- src/singlet.cpp:1059-1086.  link_h is link_h_rows x link_h_cols (column-major);
+ * it is applied iff link_h_cols == ncol(A) (l.1064), likewise link_w iff link_w_cols == nrow(A)
+ * (l.1065).  Returns the number of iterations run. */
+ORA_API int ora_c_linked_nmf(const double* Ax, const int32_t* Ai, const int32_t* Ap, const double* Atx, const int32_t* Ati,
+                             const int32_t* Atp, int32_t m, int32_t n, double tol, int maxit, double L1, double L2,
+                             int threads, int k, double* w, const double* link_h, int32_t link_h_rows, int32_t link_h_cols,
+                             const double* link_w, int32_t link_w_rows, int32_t link_w_cols, double* h, double* d,
+                             double* tol_trace) {
+    csc_t A = {Ax, Ai, Ap, m, n};
+    csc_t At = {Atx, Ati, Atp, n, m};
+    memset(h, 0, sizeof(double) * (size_t)k * (size_t)n);
+    for (int i = 0; i < k; ++i) d[i] = 1.0;
+    const int linking_h = (link_h != NULL && link_h_cols == n);
+    const int linking_w = (link_w != NULL && link_w_cols == m);
+    double tol_ = 1;
+    double* w_it = (double*)malloc(sizeof(double) * (size_t)k * (size_t)m);
+    int iter_ = 0;
+    for (; iter_ < maxit && tol_ > tol; ++iter_) {
+        memcpy(w_it, w, sizeof(double) * (size_t)k * (size_t)m);
+        predict_x(A, w, h, k, L1, L2, threads, NULL, linking_h ? link_h : NULL, link_h_rows);
+        ora_scale(h, k, n, d);
+        predict_x(At, h, w, k, L1, L2, threads, NULL, linking_w ? link_w : NULL, link_w_rows);
+        ora_scale(w, k, m, d);
+        tol_ = ora_cor(w, w_it, (size_t)k * (size_t)m);
         if (tol_trace) tol_trace[iter_] = tol_;
     }
     free(w_it);

@@ -48,6 +48,9 @@ SIGNATURES = {
                                               C.c_double, C.c_uint16, f64p, C.c_int32, C.c_uint64, C.c_uint64,
                                               C.c_double, C.c_uint16, f64p, f64p, f64p, f64p, i32p, f64p, f64p, i32p,
                                               _CB]),
+    "sgl_c_linked_nmf": (C.c_int, _CSC + _CSC + [C.c_int32, C.c_int32, C.c_double, C.c_uint16, C.c_int, C.c_double,
+                                                 C.c_double, C.c_uint16, f64p, C.c_int32, f64p, C.c_int32, C.c_int32, f64p,
+                                                 C.c_int32, C.c_int32, f64p, f64p, f64p, i32p, f64p, _CB]),
     "sgl_c_project_model": (C.c_int, _CSC + [C.c_int32, C.c_int32, f64p, C.c_int32, C.c_int32, C.c_double, C.c_double,
                                              C.c_uint16, f64p, f64p]),
     "sgl_rcpp_predict": (C.c_int, _CSC + [C.c_int32, C.c_int32, f64p, C.c_int32, C.c_int32, C.c_double, C.c_double,
@@ -62,6 +65,7 @@ SIGNATURES = {
     "sgl_log_normalize": (C.c_int, [C.c_void_p, C.c_double]),
     "sgl_weight_by_split": (C.c_int, [C.c_void_p, i32p, C.c_int32]),
     "sgl_fit_init": (C.c_int, [C.c_void_p, C.c_int32, f64p, C.c_uint64]),
+    "sgl_set_links": (C.c_int, [C.c_void_p, f64p, C.c_int32, C.c_int32, f64p, C.c_int32, C.c_int32]),
     "sgl_set_allreduce": (C.c_int, [C.c_void_p, ALLREDUCE_FN, C.c_void_p]),
     "sgl_step_begin": (C.c_int, [C.c_void_p]),
     "sgl_step_h": (C.c_int, [C.c_void_p, C.c_double, C.c_double]),

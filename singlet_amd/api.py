@@ -73,6 +73,39 @@ def c_nmf(A, At, tol, maxit, verbose, L1_w, L1_h, L2_w, L2_h, threads, w):
     return {"w": w_out.T, "d": d_out, "h": h_out.T, "iter": n_iter.value, "tol": tr[:n_iter.value].copy()}
 
 
+def c_linked_nmf(A, At, tol, maxit, verbose, L1, L2, threads, w, link_h, link_w):
+    """.Call(`_singlet_c_linked_nmf`, ...) -> list(w, d, h)  (src/singlet.cpp:1059-1086).  link_h / link_w
+    are R matrices (rows x cols); a link whose column count does not match its side is ignored, as in
+    the reference (R/RunLNMF.R passes a 1 x 1 matrix to switch a side off)."""
+    L = _lib.load()
+    A = as_dgCMatrix(A)
+    At = None if At is None else as_dgCMatrix(At)
+    wb = _w_in(w, A.nrow)
+    m, k = wb.shape
+    n = A.ncol
+    w_out, h_out, d_out = np.empty((m, k)), np.empty((n, k)), np.empty(k)
+    n_iter = C.c_int32()
+    tr = np.zeros(max(int(maxit), 1))
+    cb = make_callbacks(_verbose_log(verbose))
+    t = (ptr(At.x, f64p), ptr(At.i, i32p), ptr(At.p, i32p)) if At is not None else (None, None, None)
+
+    def link(Lk):
+        if Lk is None:
+            return None, 0, 0, None
+        Lk = np.asarray(Lk, dtype=np.float64)
+        if Lk.ndim != 2:
+            raise ValueError("link matrices must be 2-D")
+        buf = np.ascontiguousarray(Lk.T)   # column-major image of the R matrix
+        return ptr(buf, f64p), Lk.shape[0], Lk.shape[1], buf
+    lh, lhr, lhc, keep_h = link(link_h)
+    lw, lwr, lwc, keep_w = link(link_w)
+    check(L.sgl_c_linked_nmf(ptr(A.x, f64p), ptr(A.i, i32p), ptr(A.p, i32p), *t, A.nrow, A.ncol, float(tol), int(maxit),
+                             int(bool(verbose)), L1, L2, int(threads), ptr(wb, f64p), k, lh, lhr, lhc, lw, lwr, lwc,
+                             ptr(w_out, f64p), ptr(d_out, f64p), ptr(h_out, f64p), C.byref(n_iter), ptr(tr, f64p),
+                             C.byref(cb)))
+    return {"w": w_out.T, "d": d_out, "h": h_out.T, "iter": n_iter.value, "tol": tr[:n_iter.value].copy()}
+
+
 def c_ard_nmf(A, At, tol, maxit, verbose, L1, L2, threads, w, seed, inv_density, overfit_threshold, trace_test_mse):
     """.Call(`_singlet_c_ard_nmf`, ...) -> list(w, d, h, test_mse, iter, tol, score_overfit) (src/singlet.cpp:1144-1151)."""
     L = _lib.load()

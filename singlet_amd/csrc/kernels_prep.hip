@@ -74,3 +74,23 @@ int k_cell_factor(hipStream_t s, DevCSC& A, DevCSC& At, const double* f, int mod
     }
     return SGL_OK;
 }
+
+// predict_link (src/singlet.cpp:429-430): the first link_rows entries of every right-hand side are
+// multiplied by the matching column of the link matrix (link_rows x ncols, column-major)
+__global__ void link_mul_kernel(double* __restrict__ B, const double* __restrict__ L, int k, int link_rows, int64_t ncols) {
+    const int64_t total = ncols * link_rows;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t c = e / link_rows;
+        const int j = (int)(e - c * link_rows);
+        B[c * k + j] *= L[e];
+    }
+}
+
+int k_link_mul(hipStream_t s, double* B, const double* L, int k, int link_rows, int64_t ncols) {
+    if (ncols <= 0 || link_rows <= 0) return SGL_OK;
+    int64_t blocks = (ncols * link_rows + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    link_mul_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(B, L, k, link_rows, ncols);
+    HIPCHK(hipGetLastError());
+    return SGL_OK;
+}

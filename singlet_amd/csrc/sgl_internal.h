@@ -101,6 +101,9 @@ struct sgl_ctx {
     double* G = nullptr;    // k x k Gram (+1e-15 diagonal)
     double* Gpad = nullptr; // KP x KP zero-padded copy for the lane NNLS kernel
     NnlsScratch nnls_scr;   // lists / per-column state of the multi-pass lane NNLS
+    double* link_h = nullptr;  // c_linked_nmf: link_rows x ncol / x nrow multipliers of the right-hand sides
+    double* link_w = nullptr;
+    int link_h_rows = 0, link_w_rows = 0;
     double* ws = nullptr;   // partial-reduction workspace
     size_t ws_bytes = 0;
     double* scalars = nullptr;       // device scratch for cor / mse results
@@ -162,6 +165,7 @@ int k_acc_tiled(hipStream_t s, const DevTiled& S, const double* F, double* B);
 // input staging (kernels_prep.hip)
 int k_colsum(hipStream_t s, const DevCSC& M, double* sums);
 int k_cell_factor(hipStream_t s, DevCSC& A, DevCSC& At, const double* f, int mode, double scale);
+int k_link_mul(hipStream_t s, double* B, const double* L, int k, int link_rows, int64_t ncols);
 
 // NNLS
 #define SGL_NNLS_MAX_PASSES 10

@@ -143,6 +143,10 @@ static void free_fit(sgl_ctx* c) {
     dev_free(c->G);
     dev_free(c->Gpad);
     nnls_scratch_free(c->nnls_scr);
+    dev_free(c->link_h);
+    dev_free(c->link_w);
+    c->link_h = c->link_w = nullptr;
+    c->link_h_rows = c->link_w_rows = 0;
     dev_free(c->A.seg);
     dev_free(c->At.seg);
     sgl_tiled_free(c->TA);
@@ -533,7 +537,8 @@ extern "C" int sgl_step_h(sgl_ctx* c, double L1, double L2) {
     { Phase ph(c, SGL_PH_GRAM); SGLCHK(k_gram(c, c->W, k, c->A.nrow, c->G, 1e-15)); }
     { Phase ph(c, SGL_PH_RHS_H);
       if (c->use_tiled) SGLCHK(k_acc_tiled(c->stream, c->TA, c->W, c->B));
-      else SGLCHK(k_acc(c->stream, c->A, c->W, k, c->B, 0, 1, 0, 0, 0)); }
+      else SGLCHK(k_acc(c->stream, c->A, c->W, k, c->B, 0, 1, 0, 0, 0));
+      if (c->link_h) SGLCHK(k_link_mul(c->stream, c->B, c->link_h, k, c->link_h_rows, c->A.ncol)); }  // predict_link l.429-430
     { Phase ph(c, SGL_PH_NNLS_H);
       SGLCHK(nnls_shared(c, c->G, c->B, c->H, c->col_nnz_A, c->A.ncol, L1, L2, c->sweep_counters + 0)); }
     return SGL_OK;
@@ -566,6 +571,7 @@ extern "C" int sgl_step_w(sgl_ctx* c, double L1, double L2) {
       HIPCHK(hipMemcpyAsync(c->G, Gh, sizeof(double) * k * k, hipMemcpyDeviceToDevice, c->stream));
       SGLCHK(k_gram_add_diag(c->stream, c->G, k, 1e-15)); }
     { Phase ph(c, SGL_PH_NNLS_W);
+      if (c->link_w) SGLCHK(k_link_mul(c->stream, Bw, c->link_w, k, c->link_w_rows, m));  // on the complete (all-reduced) sums
       SGLCHK(nnls_shared(c, c->G, Bw, c->W, c->col_nnz_At, m, L1, L2, c->sweep_counters + 1)); }
     return SGL_OK;
 }
@@ -788,6 +794,50 @@ extern "C" int sgl_c_nmf(const double* Ax, const int32_t* Ai, const int32_t* Ap,
     SGLCHK(sgl_upload_csc(hd.c, Ax, Ai, Ap, Atx, Ati, Atp, nrow, ncol, 0, ncol));
     SGLCHK(sgl_fit_init(hd.c, k, w_init, 0));
     SGLCHK(sgl_nmf_run(hd.c, tol, maxit, L1_w, L1_h, L2_w, L2_h, n_iter, tol_trace, cb));
+    return sgl_get_factors(hd.c, w_out, d_out, h_out);
+}
+
+// c_linked_nmf's link matrices (src/singlet.cpp:1059-1065): each is used only if its column count
+// matches the side it links (link_h: cells of this shard, link_w: genes); otherwise it is ignored,
+// exactly like the reference's `linking_h` / `linking_w` tests.
+extern "C" int sgl_set_links(sgl_ctx* c, const double* link_h, int32_t link_h_rows, int32_t link_h_cols, const double* link_w,
+                             int32_t link_w_rows, int32_t link_w_cols) {
+    FIT_GUARD(c);
+    dev_free(c->link_h);
+    dev_free(c->link_w);
+    c->link_h = c->link_w = nullptr;
+    c->link_h_rows = c->link_w_rows = 0;
+    if (link_h && link_h_cols == c->A.ncol && link_h_rows > 0) {
+        const int rows = std::min<int>(link_h_rows, c->k);
+        SGLCHK(dev_alloc(&c->link_h, (size_t)link_h_rows * link_h_cols));
+        HIPCHK(hipMemcpyAsync(c->link_h, link_h, sizeof(double) * (size_t)link_h_rows * link_h_cols, hipMemcpyHostToDevice, c->stream));
+        c->link_h_rows = link_h_rows;
+        if (rows != link_h_rows) { sgl_set_error("sgl_set_links: link_h has more rows (%d) than the rank (%d)", link_h_rows, c->k); return SGL_EINVAL; }
+    }
+    if (link_w && link_w_cols == c->A.nrow && link_w_rows > 0) {
+        if (link_w_rows > c->k) { sgl_set_error("sgl_set_links: link_w has more rows (%d) than the rank (%d)", link_w_rows, c->k); return SGL_EINVAL; }
+        SGLCHK(dev_alloc(&c->link_w, (size_t)link_w_rows * link_w_cols));
+        HIPCHK(hipMemcpyAsync(c->link_w, link_w, sizeof(double) * (size_t)link_w_rows * link_w_cols, hipMemcpyHostToDevice, c->stream));
+        c->link_w_rows = link_w_rows;
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SGL_OK;
+}
+
+extern "C" int sgl_c_linked_nmf(const double* Ax, const int32_t* Ai, const int32_t* Ap, const double* Atx, const int32_t* Ati,
+                                const int32_t* Atp, int32_t nrow, int32_t ncol, double tol, uint16_t maxit, int verbose,
+                                double L1, double L2, uint16_t threads, const double* w_init, int32_t k, const double* link_h,
+                                int32_t link_h_rows, int32_t link_h_cols, const double* link_w, int32_t link_w_rows,
+                                int32_t link_w_cols, double* w_out, double* d_out, double* h_out, int32_t* n_iter,
+                                double* tol_trace, const sgl_callbacks* cb) {
+    (void)verbose; (void)threads;
+    if (!w_init || !w_out || !d_out || !h_out) { sgl_set_error("sgl_c_linked_nmf: NULL factor buffer"); return SGL_EINVAL; }
+    CtxHolder hd;
+    SGLCHK(sgl_create(current_device_or_zero(), &hd.c));
+    SGLCHK(sgl_upload_csc(hd.c, Ax, Ai, Ap, Atx, Ati, Atp, nrow, ncol, 0, ncol));
+    SGLCHK(sgl_fit_init(hd.c, k, w_init, 0));
+    SGLCHK(sgl_set_links(hd.c, link_h, link_h_rows, link_h_cols, link_w, link_w_rows, link_w_cols));
+    SGLCHK(sgl_nmf_run(hd.c, tol, maxit, L1, L1, L2, L2, n_iter, tol_trace, cb));
     return sgl_get_factors(hd.c, w_out, d_out, h_out);
 }
 

@@ -153,6 +153,36 @@ SEXP _singlet_c_ard_nmf(SEXP A_, SEXP At_, SEXP tol_, SEXP maxit_, SEXP verbose_
     return out;
 }
 
+/* ---- c_linked_nmf(A, At, tol, maxit, verbose, L1, L2, threads, w, link_h, link_w) ---- *
+ * (src/singlet.cpp:1059-1086; R/RunLNMF.R:60).  A link whose column count does not match its
+ * side is ignored by the library, as by the reference. */
+SEXP _singlet_c_linked_nmf(SEXP A_, SEXP At_, SEXP tol_, SEXP maxit_, SEXP verbose_, SEXP L1_, SEXP L2_, SEXP threads_, SEXP w_,
+                           SEXP link_h_, SEXP link_w_) {
+    dgc_view A = view_dgc(A_, "A"), At = view_dgc(At_, "At");
+    if (!Rf_isMatrix(w_) || TYPEOF(w_) != REALSXP) Rf_error("w must be a numeric matrix");
+    if (!Rf_isMatrix(link_h_) || TYPEOF(link_h_) != REALSXP || !Rf_isMatrix(link_w_) || TYPEOF(link_w_) != REALSXP)
+        Rf_error("link_h and link_w must be numeric matrices");
+    const int k = Rf_nrows(w_);
+    if (Rf_ncols(w_) != A.nrow) Rf_error("w must be k x nrow(A)");
+    const int verbose = Rf_asLogical(verbose_);
+    SEXP w = PROTECT(Rf_allocMatrix(REALSXP, k, A.nrow)), d = PROTECT(Rf_allocVector(REALSXP, k)),
+         h = PROTECT(Rf_allocMatrix(REALSXP, k, A.ncol));
+    sgl_callbacks cb = {NULL, verbose ? log_nmf : NULL, poll_cb};
+    if (verbose) Rprintf("\n%4s | %8s \n---------------\n", "iter", "tol");
+    int n_iter = 0;
+    int rc = sgl_c_linked_nmf(A.x, A.i, A.p, At.x, At.i, At.p, A.nrow, A.ncol, Rf_asReal(tol_), (uint16_t)Rf_asInteger(maxit_),
+                              verbose, Rf_asReal(L1_), Rf_asReal(L2_), (uint16_t)Rf_asInteger(threads_), REAL(w_), k,
+                              REAL(link_h_), Rf_nrows(link_h_), Rf_ncols(link_h_), REAL(link_w_), Rf_nrows(link_w_),
+                              Rf_ncols(link_w_), REAL(w), REAL(d), REAL(h), &n_iter, NULL, &cb);
+    if (rc == SGL_EINTR) { UNPROTECT(3); Rf_onintr(); }
+    fail_if(rc);
+    const char* names[3] = {"w", "d", "h"};
+    SEXP vals[3] = {w, d, h};
+    SEXP out = named_list(3, names, vals);
+    UNPROTECT(3);
+    return out;
+}
+
 /* ---- c_project_model(A, w, L1, L2, threads) -> list(h, d) ---------------- */
 SEXP _singlet_c_project_model(SEXP A_, SEXP w_, SEXP L1_, SEXP L2_, SEXP threads_) {
     dgc_view A = view_dgc(A_, "A");
@@ -189,6 +219,7 @@ SEXP _singlet_Rcpp_predict(SEXP A_, SEXP w_, SEXP L1_, SEXP L2_, SEXP threads_) 
 static const R_CallMethodDef call_entries[] = {
     {"_singlet_c_nmf", (DL_FUNC)&_singlet_c_nmf, 11},
     {"_singlet_c_ard_nmf", (DL_FUNC)&_singlet_c_ard_nmf, 13},
+    {"_singlet_c_linked_nmf", (DL_FUNC)&_singlet_c_linked_nmf, 11},
     {"_singlet_c_project_model", (DL_FUNC)&_singlet_c_project_model, 5},
     {"_singlet_Rcpp_predict", (DL_FUNC)&_singlet_Rcpp_predict, 5},
     {NULL, NULL, 0}};

@@ -298,3 +298,27 @@ def test_config3_full_size_tiled_equals_plain(sa):
         assert np.abs(W.sum(axis=0) - 1).max() < 1e-9
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("which", ["both", "h_only", "w_only", "none"])
+def test_c_linked_nmf(sa, ora, which):
+    """c_linked_nmf (src/singlet.cpp:1059-1086): link matrices multiply the right-hand sides; a link
+    whose column count does not match its side is ignored (R/RunLNMF.R switches a side off that way)."""
+    m, n, k = 260, 330, 9
+    A = ora.synth_csc(m, n, 15)
+    At = A.t()
+    w0 = ora.synth_winit(k, m)
+    rng = np.random.default_rng(4)
+    lh = (rng.random((k, n)) < 0.7) * (0.5 + rng.random((k, n)))
+    lw = (rng.random((k, m)) < 0.8).astype(np.float64)
+    off = np.ones((1, 1))
+    link_h = lh if which in ("both", "h_only") else (off if which == "w_only" else None)
+    link_w = lw if which in ("both", "w_only") else (off if which == "h_only" else None)
+    ref = ora.c_linked_nmf(A, At, 0.0, 4, 0.01, 0.0, 0, w0, link_h, link_w)
+    got = sa.c_linked_nmf(to_dgc(sa, A), to_dgc(sa, At), 0.0, 4, False, 0.01, 0.0, 0, w0.T, link_h, link_w)
+    _check(got, ref)
+    if which == "none":
+        plain = sa.c_nmf(to_dgc(sa, A), to_dgc(sa, At), 0.0, 4, False, 0.01, 0.01, 0.0, 0.0, 0, w0.T)
+        assert np.array_equal(plain["w"], got["w"]) and np.array_equal(plain["h"], got["h"])
+    if which in ("both", "h_only"):
+        assert np.all(got["h"][lh == 0] == 0)   # a zero link pins the coefficient at zero

@@ -134,6 +134,19 @@ def test_staging_ops_against_transcription(ora):
     assert np.array_equal(ws.x[per_cell == 0], ln.x[per_cell == 0])  # group 0 untouched (l.137)
 
 
+def test_c_linked_nmf_oracle(ora):
+    """No links == c_nmf bit for bit; a zero link pins its coefficient at zero; mismatched links are ignored."""
+    A = ora.synth_csc(80, 60, 8)
+    At = A.t()
+    w0 = ora.synth_winit(5, 80)
+    r0 = ora.c_nmf(A, At, 0.0, 3, 0.01, 0.01, 0.0, 0.0, 0, w0)
+    r1 = ora.c_linked_nmf(A, At, 0.0, 3, 0.01, 0.0, 0, w0, None, np.ones((1, 1)))
+    assert np.array_equal(r0["w"], r1["w"]) and np.array_equal(r0["h"], r1["h"]) and np.array_equal(r0["d"], r1["d"])
+    lh = (np.random.default_rng(0).random((5, 60)) < 0.7).astype(float)
+    r2 = ora.c_linked_nmf(A, At, 0.0, 3, 0.01, 0.0, 0, w0, lh, None)
+    assert np.all(r2["h"][lh.T == 0] == 0) and not np.array_equal(r2["h"], r0["h"])
+
+
 def test_nnls_quirks(ora):
     """SURVEY.md 8a quirks 2-5 on hand-made cases."""
     G = np.array([[2.0, 0.5], [0.5, 1.0]])
