@@ -322,3 +322,38 @@ def test_c_linked_nmf(sa, ora, which):
         assert np.array_equal(plain["w"], got["w"]) and np.array_equal(plain["h"], got["h"])
     if which in ("both", "h_only"):
         assert np.all(got["h"][lh == 0] == 0)   # a zero link pins the coefficient at zero
+
+
+def test_callbacks_log_poll_and_verbose(sa, ora, ctx, capsys):
+    """The two callbacks of the ABI: `log` fires once per iteration with the reference's 1-based
+    iteration number and that iteration's tol (src/singlet.cpp:661-662); `poll` is the
+    Rcpp::checkUserInterrupt() stand-in (:652, :663) -- a non-zero return stops the fit with SGL_EINTR
+    and leaves the context usable.  verbose = TRUE prints the reference's header and lines."""
+    A = ora.synth_csc(200, 240, 20)
+    w0 = ora.synth_winit(6, 200)
+    ctx.upload(to_dgc(sa, A), None)
+    ctx.fit_init(6, w0)
+    seen = []
+    it, tols = ctx.nmf_run(0.0, 4, 0.01, 0.01, 0.0, 0.0, log=lambda i, t, of: seen.append((i, t, of)))
+    assert [s[0] for s in seen] == [1, 2, 3, 4] and np.array_equal([s[1] for s in seen], tols)
+    assert all(np.isnan(s[2]) for s in seen)          # c_nmf has no overfit column
+    # interrupt at the second polling point of iteration 2 (two polls per iteration)
+    calls = []
+    ctx.fit_init(6, w0)
+    with pytest.raises(sa.SingletHipError) as ei:
+        ctx.nmf_run(0.0, 10, 0.01, 0.01, 0.0, 0.0, poll=lambda: (calls.append(1), len(calls) >= 4)[1])
+    assert ei.value.code == -5 and len(calls) == 4
+    ctx.fit_init(6, w0)                               # still usable afterwards
+    it2, tols2 = ctx.nmf_run(0.0, 4, 0.01, 0.01, 0.0, 0.0)
+    assert it2 == 4 and np.array_equal(tols2, tols)
+    # verbose output of the R-level wrappers
+    capsys.readouterr()
+    r = sa.c_nmf(to_dgc(sa, A), None, 0.0, 2, True, 0.01, 0.01, 0.0, 0.0, 0, w0.T)
+    out = capsys.readouterr().out.splitlines()
+    assert out[1] == "%4s | %8s " % ("iter", "tol") and out[2] == "-" * 15
+    assert out[3] == "%4d | %8.2e" % (1, r["tol"][0]) and out[4] == "%4d | %8.2e" % (2, r["tol"][1])
+    sa.c_ard_nmf(to_dgc(sa, A), to_dgc(sa, A.t()), 0.0, 3, True, 0.01, 0.0, 0, w0.T, 7, 10, 1e9, 2)
+    out = capsys.readouterr().out.splitlines()
+    # iter_ % trace_test_mse == 0 is traced (src/singlet.cpp:1116): iterations 1 and 3 print a score, 2 prints "-"
+    assert out[1] == "%4s | %8s | %8s " % ("iter", "tol", "overfit")
+    assert out[3].endswith("| 0.00e+00") and out[4].endswith("|        -") and "e" in out[5].split("|")[2]
