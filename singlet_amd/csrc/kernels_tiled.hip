@@ -338,14 +338,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(128), amdgpu_wa
         const int n = rows * k;
         const double* __restrict__ src = F + row0 * k;
         if (KS == k) {
-            // Each thread moves up to NST 16-byte pieces of the (contiguous) tile, in two rounds of
-            // NST/2.  Round 1 loads are issued before the barrier (they overlap the tail of the previous
-            // tile's work of other waves).
-            constexpr int NST = (TILED_LDS_BYTES / 16 + 64 * TILED_NW - 1) / (64 * TILED_NW) + ((TILED_LDS_BYTES / 16 + 64 * TILED_NW - 1) / (64 * TILED_NW)) % 2;
-            constexpr int HST = NST / 2;
-            double2 stg[HST];
+            // Each thread moves up to NST 16-byte pieces of the (contiguous) tile in NRND rounds of RST
+            // (small enough to stay inside the 128-VGPR compiler budget without spilling).  The loads of
+            // the first round are issued before the barrier: they overlap the tail of the previous tile's
+            // work of the other waves.
+            constexpr int RST = 5;
+            constexpr int NRND = (TILED_LDS_BYTES / 16 + RST * 64 * TILED_NW - 1) / (RST * 64 * TILED_NW);
+            static_assert(NRND * RST * 64 * TILED_NW * 16 >= TILED_LDS_BYTES, "staging must cover the whole tile");
+            double2 stg[RST];
 #pragma unroll
-            for (int j = 0; j < HST; ++j) {
+            for (int j = 0; j < RST; ++j) {
                 const int e = ((int)threadIdx.x + j * 64 * TILED_NW) * 2;
                 stg[j] = double2{0.0, 0.0};
                 if (e < n) stg[j] = *reinterpret_cast<const double2*>(src + e);
@@ -355,20 +357,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(128), amdgpu_wa
 #endif
             __syncthreads();  // everyone is done reading the previous tile
 #pragma unroll
-            for (int j = 0; j < HST; ++j) {
-                const int e = ((int)threadIdx.x + j * 64 * TILED_NW) * 2;
-                if (e < n) *reinterpret_cast<double2*>(tile + e) = stg[j];
-            }
+            for (int rd = 0; rd < NRND; ++rd) {
 #pragma unroll
-            for (int j = 0; j < HST; ++j) {
-                const int e = ((int)threadIdx.x + (j + HST) * 64 * TILED_NW) * 2;
-                stg[j] = double2{0.0, 0.0};
-                if (e < n) stg[j] = *reinterpret_cast<const double2*>(src + e);
-            }
+                for (int j = 0; j < RST; ++j) {
+                    const int e = ((int)threadIdx.x + (rd * RST + j) * 64 * TILED_NW) * 2;
+                    if (e < n) *reinterpret_cast<double2*>(tile + e) = stg[j];
+                }
+                if (rd + 1 < NRND) {
 #pragma unroll
-            for (int j = 0; j < HST; ++j) {
-                const int e = ((int)threadIdx.x + (j + HST) * 64 * TILED_NW) * 2;
-                if (e < n) *reinterpret_cast<double2*>(tile + e) = stg[j];
+                    for (int j = 0; j < RST; ++j) {
+                        const int e = ((int)threadIdx.x + ((rd + 1) * RST + j) * 64 * TILED_NW) * 2;
+                        stg[j] = double2{0.0, 0.0};
+                        if (e < n) stg[j] = *reinterpret_cast<const double2*>(src + e);
+                    }
+                }
             }
         } else {
             // odd k: rows are re-pitched to KS = k + 1 doubles (the pad column is never summed into a

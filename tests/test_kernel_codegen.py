@@ -1,0 +1,78 @@
+"""Static checks of the tiled accumulate's generated code (no GPU needed: hipcc cross-compiles).
+
+acc_tiled_kernel keeps its 64 FP64 accumulator pairs in v[128:255], outside hipcc's register
+allocation, addressed from inline asm through VGPR index mode.  That is only sound while the compiler
+itself never allocates a register at or above v128 and never spills: both are properties of a
+particular hipcc, so they are asserted on the assembly this toolchain emits."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "singlet_amd", "csrc", "kernels_tiled.hip")
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+@pytest.fixture(scope="module")
+def tiled_asm(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not installed")
+    out = str(tmp_path_factory.mktemp("asm") / "kernels_tiled.s")
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-S",
+                    "--cuda-device-only", "-o", out, SRC], check=True, capture_output=True, timeout=600)
+    text = open(out).read()
+    m = re.search(r"^_Z16acc_tiled_kernel.*?:\n(.*?)s_endpgm", text, re.S | re.M)
+    assert m, "acc_tiled_kernel not found in the assembly"
+    meta = text[text.index("s_endpgm", m.start()):]
+    end = meta.find(".end_amdhsa_kernel")
+    return m.group(1), meta[:end if end > 0 else 6000]
+
+
+def _vregs(line):
+    regs = set()
+    for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", line):
+        regs.update(range(int(a), int(b) + 1))
+    regs.update(int(a) for a in re.findall(r"\bv(\d+)\b", line))
+    return regs
+
+
+def test_compiler_stays_below_v128_and_never_spills(tiled_asm):
+    body, meta = tiled_asm
+    in_asm, worst = False, -1
+    for line in body.splitlines():
+        if "#ASMSTART" in line:
+            in_asm = True
+            continue
+        if "#ASMEND" in line:
+            in_asm = False
+            continue
+        code = line.split(";")[0]
+        if in_asm or not code.strip():
+            continue
+        r = _vregs(code)
+        if r:
+            worst = max(worst, max(r))
+    assert 0 <= worst < 128, "hipcc allocated v%d: the asm-managed accumulators v[128:255] would be clobbered" % worst
+    assert re.search(r"\.amdhsa_next_free_vgpr 256\b", meta), "the kernel descriptor must allocate all 256 VGPRs"
+    # a few loop-invariant 64-bit values may be parked in scratch around the tile loop, but nothing
+    # inside the per-set loop (between the first and the last counted stream wait) may touch scratch
+    m = re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", meta)
+    assert m and int(m.group(1)) <= 64, "acc_tiled_kernel spills %s bytes per lane" % (m.group(1) if m else "?")
+    lines = body.splitlines()
+    waits = [n for n, l in enumerate(lines) if "s_waitcnt vmcnt(6)" in l]
+    hot = lines[waits[0]:waits[-1] + 400]
+    assert not [l for l in hot if "scratch_" in l or "buffer_store" in l or "buffer_load" in l], "scratch access in the set loop"
+
+
+def test_no_compiler_wait_drains_the_stream_prefetch(tiled_asm):
+    """Inside the set loop only the counted asm wait (vmcnt(6)) may appear: a compiler-inserted
+    s_waitcnt vmcnt(0) there would drain the four-set prefetch queue on every set."""
+    body, _ = tiled_asm
+    lines = body.splitlines()
+    idx = [n for n, l in enumerate(lines) if "s_waitcnt vmcnt(6)" in l]
+    assert len(idx) == 4, "expected the four phase copies of the set body"
+    for a, b in zip(idx, idx[1:]):
+        seg = [l for l in lines[a + 1:b] if "s_waitcnt" in l and "vmcnt" in l]
+        assert not seg, "compiler vmcnt wait inside a set: %r" % seg[:2]
