@@ -338,11 +338,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(128), amdgpu_wa
         const int n = rows * k;
         const double* __restrict__ src = F + row0 * k;
         if (KS == k) {
-            // Each thread moves up to NST 16-byte pieces of the (contiguous) tile in NRND rounds of RST
-            // (small enough to stay inside the 128-VGPR compiler budget without spilling).  The loads of
-            // the first round are issued before the barrier: they overlap the tail of the previous tile's
+            // Each thread moves up to NRND * RST 16-byte pieces of the (contiguous) tile in NRND rounds of
+            // RST loads in flight (two rounds of ten measured faster than four of five).  The loads of the
+            // first round are issued before the barrier: they overlap the tail of the previous tile's
             // work of the other waves.
-            constexpr int RST = 5;
+            constexpr int RST = 10;
             constexpr int NRND = (TILED_LDS_BYTES / 16 + RST * 64 * TILED_NW - 1) / (RST * 64 * TILED_NW);
             static_assert(NRND * RST * 64 * TILED_NW * 16 >= TILED_LDS_BYTES, "staging must cover the whole tile");
             double2 stg[RST];

@@ -76,15 +76,18 @@ __global__ __launch_bounds__(256) void nnls_lane_kernel(const double* __restrict
                 double diff = b[i] / Gs[i + KP * i];
                 diff -= L1;                 // exact no-op when L1 == 0
                 diff = fma(L2, xi, diff);   // exact no-op when L2 == 0 (x >= 0)
+                // l.237-247 with the two inner tests folded away (fewer selects per coordinate):
+                //  clamp (-diff > x_i): x_i -> 0, b += G[:, i] x_i, tol = 1 -- when x_i == 0 all three
+                //    are no-ops (delta = -0.0 leaves b as it is), so only `tol = 1` needs the x_i != 0 test;
+                //  otherwise x_i += diff, b -= G[:, i] diff, tol += |diff / (x_i + 1e-15)| -- with
+                //    diff == 0 these add exact zeros, which is what skipping them does.
                 const bool clamp = -diff > xi;
-                const bool c2 = clamp && (xi != 0.0);
-                const bool upd = (!clamp) && (diff != 0.0);
-                const double xn = c2 ? 0.0 : (upd ? xi + diff : xi);
-                double delta = c2 ? -xi : (upd ? diff : 0.0);
+                const double xn = clamp ? 0.0 : xi + diff;
+                double delta = clamp ? -xi : diff;
                 delta = go ? delta : 0.0;
                 x[i] = go ? xn : xi;
                 const double tadd = fabs(diff / (xn + 1e-15));
-                const double tnew = c2 ? 1.0 : (upd ? tol + tadd : tol);
+                const double tnew = clamp ? ((xi != 0.0) ? 1.0 : tol) : tol + tadd;
                 tol = go ? tnew : tol;
                 const double nd = -delta;
                 static_for<KP>([&](auto jc) {
