@@ -37,6 +37,10 @@ int64_t nnls_repack_min_cols() {
     return (int64_t)(x > 0 ? x : (1 << 18));
 }
 
+// Row stride of the padded Gram the lane kernel reads (nnls_lane.h): KP for the scalar-operand instances
+// (KP <= 40, kernels_nnls_lane1.hip), KP rounded up to 16 for the vector-load + DPP instances (lane2).
+int nnls_gram_stride(int KP) { return KP > 40 ? (KP + 15) / 16 * 16 : KP; }
+
 int nnls_scratch_alloc(NnlsScratch& sc, int64_t cap) {
     nnls_scratch_free(sc);
     if (cap <= 0) return SGL_OK;

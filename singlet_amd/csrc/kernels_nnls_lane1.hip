@@ -5,10 +5,10 @@ int k_nnls_lane_launch1(hipStream_t s, const double* Gpad, int KP, double* B, do
                         int64_t ncols, double L1, double L2, unsigned long long* sweep_counter, const NnlsPass& ps, dim3 g,
                         dim3 b) {
     switch (KP) {
-        SGL_NNLS_CASE(2); SGL_NNLS_CASE(4); SGL_NNLS_CASE(6); SGL_NNLS_CASE(8); SGL_NNLS_CASE(10); SGL_NNLS_CASE(12);
-        SGL_NNLS_CASE(14); SGL_NNLS_CASE(16); SGL_NNLS_CASE(18); SGL_NNLS_CASE(20); SGL_NNLS_CASE(22); SGL_NNLS_CASE(24);
-        SGL_NNLS_CASE(26); SGL_NNLS_CASE(28); SGL_NNLS_CASE(30); SGL_NNLS_CASE(32); SGL_NNLS_CASE(34); SGL_NNLS_CASE(36);
-        SGL_NNLS_CASE(38); SGL_NNLS_CASE(40);
+        SGL_NNLS_CASE(2, false); SGL_NNLS_CASE(4, false); SGL_NNLS_CASE(6, false); SGL_NNLS_CASE(8, false); SGL_NNLS_CASE(10, false); SGL_NNLS_CASE(12, false);
+        SGL_NNLS_CASE(14, false); SGL_NNLS_CASE(16, false); SGL_NNLS_CASE(18, false); SGL_NNLS_CASE(20, false); SGL_NNLS_CASE(22, false); SGL_NNLS_CASE(24, false);
+        SGL_NNLS_CASE(26, false); SGL_NNLS_CASE(28, false); SGL_NNLS_CASE(30, false); SGL_NNLS_CASE(32, false); SGL_NNLS_CASE(34, false); SGL_NNLS_CASE(36, false);
+        SGL_NNLS_CASE(38, false); SGL_NNLS_CASE(40, false);
         default: sgl_set_error("k_nnls_lane: unsupported KP=%d", KP); return SGL_EINVAL;
     }
     return SGL_OK;

@@ -26,7 +26,25 @@ __device__ __forceinline__ void static_for(F&& f) {
     static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-template <int KP>
+// GV = false: the Gram reaches the FMAs as scalar operands (s_load; row stride KP).
+// GV = true : row i of the Gram is fetched with ceil(KP / 16) coalesced vector loads, every 16-lane row of
+//   the wave holding the same 16 entries (row stride GS = KP rounded up to 16), and entry j reaches FMA j as a
+//   DPP row broadcast (v_fmac_f64_dpp ... row_newbcast:j%16).  Vector loads return in order and cost no
+//   SGPRs: a whole row no longer has to fit the ~100 free SGPRs (the cliff above k = 50) and hipcc can
+//   keep the next rows in flight.
+template <int J>
+__device__ __forceinline__ void nnls_dpp_fmac(double& acc, double g, double nd) {
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(g), "v"(nd), "n"(J));
+}
+template <int J>
+__device__ __forceinline__ double nnls_dpp_bcast(double g) {
+    int lo = __double2loint(g), hi = __double2hiint(g), rl, rh;
+    asm("v_mov_b32_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(rl) : "v"(lo), "n"(J));
+    asm("v_mov_b32_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(rh) : "v"(hi), "n"(J));
+    return __hiloint2double(rh, rl);
+}
+
+template <int KP, bool GV>
 __global__ __launch_bounds__(256) void nnls_lane_kernel(const double* __restrict__ Gpad, double* __restrict__ B,
                                                         double* __restrict__ X, const int64_t* __restrict__ col_nnz,
                                                         int k, int64_t ncols, double L1, double L2,
@@ -69,11 +87,22 @@ __global__ __launch_bounds__(256) void nnls_lane_kernel(const double* __restrict
         // The pointer itself keeps its provenance (global, read-only) so the loads stay s_load.
         asm volatile("" : "+s"(gofs));
         const double* __restrict__ Gs = Gpad + gofs;
+        constexpr int NG = (KP + 15) / 16, GS = NG * 16;
+        const double* __restrict__ Gv = Gpad + gofs + (threadIdx.x & 15);
         static_for<KP>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             if (i < k) {
                 const double xi = x[i];
-                double diff = b[i] / Gs[i + KP * i];
+                double grow[NG];
+                double gii;
+                if (GV) {
+#pragma unroll
+                    for (int m = 0; m < NG; ++m) grow[m] = Gv[i * GS + 16 * m];
+                    gii = nnls_dpp_bcast<(i & 15)>(grow[i >> 4]);
+                } else {
+                    gii = Gs[i + KP * i];
+                }
+                double diff = b[i] / gii;
                 diff -= L1;                 // exact no-op when L1 == 0
                 diff = fma(L2, xi, diff);   // exact no-op when L2 == 0 (x >= 0)
                 // l.237-247 with the two inner tests folded away (fewer selects per coordinate):
@@ -92,7 +121,8 @@ __global__ __launch_bounds__(256) void nnls_lane_kernel(const double* __restrict
                 const double nd = -delta;
                 static_for<KP>([&](auto jc) {
                     constexpr int j = decltype(jc)::value;
-                    b[j] = fma(Gs[j + KP * i], nd, b[j]);
+                    if (GV) nnls_dpp_fmac<(j & 15)>(b[j], grow[j >> 4], nd);
+                    else b[j] = fma(Gs[j + KP * i], nd, b[j]);
                 });
             }
         });
@@ -131,5 +161,8 @@ __global__ __launch_bounds__(256) void nnls_lane_kernel(const double* __restrict
     }
 }
 
-#define SGL_NNLS_CASE(K_) \
-    case K_: nnls_lane_kernel<K_><<<g, b, 0, s>>>(Gpad, B, X, col_nnz, k, ncols, L1, L2, sweep_counter, ps); break
+// GV_ is fixed per translation unit: scalar operands up to KP = 40 (3-10 % faster there), vector loads +
+// DPP broadcast from KP = 42 (11 % faster at k = 50, 2.3x at k = 56 .. 64, where a row no longer fits the
+// free SGPRs).  nnls_gram_stride() in kernels_nnls.hip must agree.
+#define SGL_NNLS_CASE(K_, GV_) \
+    case K_: nnls_lane_kernel<K_, GV_><<<g, b, 0, s>>>(Gpad, B, X, col_nnz, k, ncols, L1, L2, sweep_counter, ps); break

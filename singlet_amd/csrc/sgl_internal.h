@@ -150,7 +150,7 @@ int k_gram_add_diag(hipStream_t s, double* G, int k, double v);
 int k_rowsum(sgl_ctx* c, const double* F, int k, int64_t cols, double* d_out);  // no +1e-15
 int k_scale_apply(hipStream_t s, double* F, int k, int64_t cols, double* d, int add_eps);
 int k_cor(sgl_ctx* c, const double* x, const double* y, int64_t n, double* out_dev);
-int k_pad_gram(hipStream_t s, const double* G, int k, int KP, double* Gpad);
+int k_pad_gram(hipStream_t s, const double* G, int k, int KP, int GS, double* Gpad);
 int k_transpose_dense(hipStream_t s, const double* in, int rows, int cols, double* out);
 
 // sparse accumulate: B[:, c] (+)= sum_{nz in tile t of column c} x * F[:, row]
@@ -171,6 +171,7 @@ int k_link_mul(hipStream_t s, double* B, const double* L, int k, int link_rows, 
 #define SGL_NNLS_MAX_PASSES 10
 // below this many columns the GPU is not full anyway: one pass (env SGL_NNLS_REPACK_MIN_COLS overrides, tests)
 int64_t nnls_repack_min_cols();
+int nnls_gram_stride(int KP);  // row stride of the padded Gram the lane kernel expects
 int nnls_scratch_alloc(NnlsScratch& sc, int64_t cap);
 void nnls_scratch_free(NnlsScratch& sc);
 // B is destroyed (and used as the spill space of b between passes).  scr == nullptr: one pass.

@@ -460,7 +460,7 @@ extern "C" int sgl_fit_init(sgl_ctx* c, int32_t k, const double* w_init, uint64_
     SGLCHK(dev_alloc(&c->red, (size_t)k * m + (size_t)k * k + (size_t)k));
     SGLCHK(dev_alloc(&c->G, (size_t)k * k));
     const int KP = lane_kp(k);
-    SGLCHK(dev_alloc(&c->Gpad, (size_t)KP * KP));
+    SGLCHK(dev_alloc(&c->Gpad, (size_t)64 * 64 + 64));
     {
         const int64_t cap = std::max<int64_t>(c->A.ncol, c->A.nrow);
         if (k <= SGL_LANE_NNLS_MAX_K && cap >= nnls_repack_min_cols()) SGLCHK(nnls_scratch_alloc(c->nnls_scr, cap));
@@ -517,7 +517,7 @@ static int nnls_shared(sgl_ctx* c, const double* G, double* B, double* X, const 
     const int k = c->k;
     if (k <= SGL_LANE_NNLS_MAX_K) {
         const int KP = lane_kp(k);
-        SGLCHK(k_pad_gram(c->stream, G, k, KP, c->Gpad));
+        SGLCHK(k_pad_gram(c->stream, G, k, KP, nnls_gram_stride(KP), c->Gpad));
         return k_nnls_lane(c->stream, c->Gpad, KP, B, X, col_nnz, k, ncols, L1, L2, counter, &c->nnls_scr);
     }
     return k_nnls_wave(c->stream, G, 0, B, X, col_nnz, k, ncols, L1, L2, counter);
@@ -1008,8 +1008,8 @@ extern "C" int sgl_op_nnls(sgl_ctx* c, const double* G, const double* B, double*
     int rc;
     if (k <= SGL_LANE_NNLS_MAX_K) {
         const int KP = lane_kp(k);
-        rc = dev_alloc(&dGp, (size_t)KP * KP);
-        if (rc == SGL_OK) rc = k_pad_gram(c->stream, dG, k, KP, dGp);
+        rc = dev_alloc(&dGp, (size_t)64 * 64 + 64);
+        if (rc == SGL_OK) rc = k_pad_gram(c->stream, dG, k, KP, nnls_gram_stride(KP), dGp);
         NnlsScratch scr;  // re-pack passes only pay off (and are only used) for many columns
         if (rc == SGL_OK && ncols >= nnls_repack_min_cols()) rc = nnls_scratch_alloc(scr, ncols);
         if (rc == SGL_OK) rc = k_nnls_lane(c->stream, dGp, KP, dB, dX, nullptr, k, ncols, L1, L2, c->sweep_counters + 4, &scr);

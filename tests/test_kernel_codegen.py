@@ -76,3 +76,39 @@ def test_no_compiler_wait_drains_the_stream_prefetch(tiled_asm):
     for a, b in zip(idx, idx[1:]):
         seg = [l for l in lines[a + 1:b] if "s_waitcnt" in l and "vmcnt" in l]
         assert not seg, "compiler vmcnt wait inside a set: %r" % seg[:2]
+
+
+def _dst_src0(code):
+    ops = code.split(None, 1)[1] if " " in code or "\t" in code else ""
+    parts = [p.strip() for p in ops.split(",")]
+    return (parts[0].split()[0] if parts and parts[0] else ""), (parts[1].split()[0] if len(parts) > 1 and parts[1] else "")
+
+
+def test_nnls_dpp_operands_have_no_valu_write_hazard(tmp_path):
+    """nnls_lane_kernel<KP, true> feeds the Gram to its FMAs with inline-asm DPP instructions.  A DPP read
+    of a VGPR needs two wait states after a VALU write of it, and hipcc pads nothing around inline asm: the
+    DPP source registers must come straight from vector loads.  Also: no scratch."""
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not installed")
+    out = str(tmp_path / "nnls50.s")
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+                    "-I" + os.path.join(ROOT, "singlet_amd", "csrc"), "-S", "--cuda-device-only", "-o", out,
+                    os.path.join(ROOT, "tests", "codegen", "nnls_lane_50.hip")], check=True, capture_output=True, timeout=600)
+    text = open(out).read()
+    m = re.search(r"^_Z16nnls_lane_kernelILi50ELb1EE[^\n]*\n(.*?)s_endpgm", text, re.S | re.M)
+    assert m, "kernel not found"
+    prev, n_dpp = [], 0
+    for line in m.group(1).splitlines():
+        code = line.split(";")[0].strip()
+        if not code or code.startswith(".") or code.endswith(":"):
+            continue
+        if "_dpp" in code:
+            n_dpp += 1
+            src0 = _vregs(_dst_src0(code)[1])
+            for pl in prev[-2:]:
+                if pl.startswith("v_") and (_vregs(_dst_src0(pl)[0]) & src0):
+                    raise AssertionError("DPP hazard: %r followed by %r" % (pl, code))
+        prev.append(code)
+    assert n_dpp >= 50 * 50, "expected one DPP FMA per (coordinate, row entry)"
+    d = text.index(".amdhsa_kernel _Z16nnls_lane_kernelILi50ELb1EE")
+    assert re.search(r"\.amdhsa_private_segment_fixed_size 0\b", text[d:d + 1500]), "NNLS lane kernel spills"
