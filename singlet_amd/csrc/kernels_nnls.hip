@@ -29,6 +29,9 @@ int k_nnls_lane_launch1(hipStream_t s, const double* Gpad, int KP, double* B, do
 int k_nnls_lane_launch2(hipStream_t s, const double* Gpad, int KP, double* B, double* X, const int64_t* col_nnz, int k,
                         int64_t ncols, double L1, double L2, unsigned long long* sweep_counter, const NnlsPass& ps, dim3 g,
                         dim3 b);
+int k_nnls_lane_launch3(hipStream_t s, const double* Gpad, int KP, double* B, double* X, const int64_t* col_nnz, int k,
+                        int64_t ncols, double L1, double L2, unsigned long long* sweep_counter, const NnlsPass& ps, dim3 g,
+                        dim3 b);
 
 int64_t nnls_repack_min_cols() {
     // read on every call (cheap): tests lower it to drive small problems through the multi-pass path
@@ -40,13 +43,21 @@ int64_t nnls_repack_min_cols() {
 // Row stride of the padded Gram the lane kernel reads (nnls_lane.h): KP for the scalar-operand instances
 // (KP <= 40, kernels_nnls_lane1.hip), KP rounded up to 16 for the vector-load + DPP instances (lane2).
 int nnls_gram_stride(int KP) { return KP > 40 ? (KP + 15) / 16 * 16 : KP; }
+// padded rank of the lane kernel instance serving rank k (0: no instance, use the wave kernel)
+int nnls_lane_kp(int k) { return k <= 64 ? (k + 1) / 2 * 2 : (k <= 104 ? (k + 7) / 8 * 8 : 0); }
 
-int nnls_scratch_alloc(NnlsScratch& sc, int64_t cap) {
+int nnls_scratch_alloc(NnlsScratch& sc, int64_t cap, int k_for_xt) {
     nnls_scratch_free(sc);
     if (cap <= 0) return SGL_OK;
-    if (hipMalloc(&sc.list[0], sizeof(int32_t) * cap) != hipSuccess || hipMalloc(&sc.list[1], sizeof(int32_t) * cap) != hipSuccess ||
-        hipMalloc(&sc.counts, sizeof(uint32_t) * (SGL_NNLS_MAX_PASSES + 1)) != hipSuccess ||
-        hipMalloc(&sc.it_state, (size_t)cap) != hipSuccess || hipMalloc(&sc.tol_state, sizeof(double) * cap) != hipSuccess) {
+    bool ok = true;
+    // x scratch of the k > 64 instances; lists / per-column state only where re-packing is used
+    if (k_for_xt > 64) ok = hipMalloc(&sc.xt, sizeof(double) * (size_t)cap * k_for_xt) == hipSuccess;
+    if (ok && cap >= nnls_repack_min_cols())
+        ok = hipMalloc(&sc.list[0], sizeof(int32_t) * cap) == hipSuccess && hipMalloc(&sc.list[1], sizeof(int32_t) * cap) == hipSuccess &&
+             hipMalloc(&sc.counts, sizeof(uint32_t) * (SGL_NNLS_MAX_PASSES + 1)) == hipSuccess &&
+             hipMalloc(&sc.it_state, (size_t)cap) == hipSuccess && hipMalloc(&sc.tol_state, sizeof(double) * cap) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
         nnls_scratch_free(sc);
         sgl_set_error("NNLS scratch: out of device memory");
         return SGL_ENOMEM;
@@ -61,17 +72,23 @@ void nnls_scratch_free(NnlsScratch& sc) {
     if (sc.counts) hipFree(sc.counts);
     if (sc.it_state) hipFree(sc.it_state);
     if (sc.tol_state) hipFree(sc.tol_state);
+    if (sc.xt) hipFree(sc.xt);
     sc = NnlsScratch();
 }
 
 int k_nnls_lane(hipStream_t s, const double* Gpad, int KP, double* B, double* X, const int64_t* col_nnz, int k,
                 int64_t ncols, double L1, double L2, unsigned long long* sweep_counter, const NnlsScratch* scr) {
     if (ncols <= 0) return SGL_OK;
-    auto launch = (KP <= 40) ? k_nnls_lane_launch1 : k_nnls_lane_launch2;
+    auto launch = (KP <= 40) ? k_nnls_lane_launch1 : (KP <= 64 ? k_nnls_lane_launch2 : k_nnls_lane_launch3);
+    if (KP > 64 && (scr == nullptr || scr->xt == nullptr || scr->cap < ncols)) {
+        sgl_set_error("k_nnls_lane: k > 64 needs the x scratch");
+        return SGL_ESTATE;
+    }
+    double* xt = (KP > 64) ? scr->xt : nullptr;
     const dim3 g((unsigned)((ncols + 255) / 256)), b(256);
-    const bool repack = scr != nullptr && scr->cap >= ncols && ncols >= nnls_repack_min_cols();
+    const bool repack = scr != nullptr && scr->list[0] != nullptr && scr->cap >= ncols && ncols >= nnls_repack_min_cols();
     if (!repack) {
-        const NnlsPass one = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+        const NnlsPass one = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, xt, ncols};
         SGLCHK(launch(s, Gpad, KP, B, X, col_nnz, k, ncols, L1, L2, sweep_counter, one, g, b));
         HIPCHK(hipGetLastError());
         return SGL_OK;
@@ -90,6 +107,8 @@ int k_nnls_lane(hipStream_t s, const double* Gpad, int KP, double* B, double* X,
         ps.it_state = scr->it_state;
         ps.tol_state = scr->tol_state;
         ps.final_below = (int32_t)std::min<int64_t>(64 * 1024, nnls_repack_min_cols() / 4);
+        ps.xt = xt;
+        ps.xt_stride = ncols;
         SGLCHK(launch(s, Gpad, KP, B, X, col_nnz, k, ncols, L1, L2, sweep_counter, ps, g, b));
         HIPCHK(hipGetLastError());
     }

@@ -44,8 +44,11 @@ __device__ __forceinline__ double nnls_dpp_bcast(double g) {
     return __hiloint2double(rh, rl);
 }
 
-template <int KP, bool GV>
-__global__ __launch_bounds__(256) void nnls_lane_kernel(const double* __restrict__ Gpad, double* __restrict__ B,
+// XM = true (k > 64): x does not fit the register file next to b any more (4 k VGPRs): it lives in a
+// per-launch scratch xt[i * xt_stride + position] (coalesced over the lanes) and is read PF coordinates
+// ahead; b stays in VGPRs.
+template <int KP, bool GV, bool XM = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void nnls_lane_kernel(const double* __restrict__ Gpad, double* __restrict__ B,
                                                         double* __restrict__ X, const int64_t* __restrict__ col_nnz,
                                                         int k, int64_t ncols, double L1, double L2,
                                                         unsigned long long* __restrict__ sweep_counter, NnlsPass ps) {
@@ -58,14 +61,24 @@ __global__ __launch_bounds__(256) void nnls_lane_kernel(const double* __restrict
     // empty columns are skipped and keep their stale values (src/singlet.cpp:340)
     const bool valid = in_range && (ps.list != nullptr || col_nnz == nullptr || col_nnz[col] != 0);
     const bool to_end = (ps.next_list == nullptr) || n_in <= (int64_t)ps.final_below;
-    double b[KP], x[KP];
+    constexpr int PF = XM ? 2 : 4;   // coordinates of x read ahead (XM)
+    constexpr bool G2 = !XM;          // one-row-ahead double buffer of the Gram rows (registers permitting)
+    double b[KP], x[XM ? PF : KP];
     double* bp = B + col * k;
     double* xp = X + col * k;
+    double* __restrict__ xt = XM ? ps.xt + gid : nullptr;  // this lane's column of the scratch
+    const int64_t xs = ps.xt_stride;
     static_for<KP>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
         b[j] = (valid && j < k) ? bp[j] : 0.0;
-        x[j] = (valid && j < k) ? xp[j] : 0.0;
+        if (!XM) x[j] = (valid && j < k) ? xp[j] : 0.0;
     });
+    if (XM) {
+        // only lanes that own a column touch the scratch: a lane past the end of the list would land in
+        // another column's slot of the next row
+        if (valid)
+            for (int j = 0; j < k; ++j) xt[j * xs] = xp[j];
+    }
     const double kd = (double)k;
     double tol = 1.0;
     int it = 0;
@@ -89,15 +102,38 @@ __global__ __launch_bounds__(256) void nnls_lane_kernel(const double* __restrict
         const double* __restrict__ Gs = Gpad + gofs;
         constexpr int NG = (KP + 15) / 16, GS = NG * 16;
         const double* __restrict__ Gv = Gpad + gofs + (threadIdx.x & 15);
+        // GV: explicit one-row-ahead software pipeline of the Gram rows (g2[parity]), fenced with
+        // scheduling barriers: left alone, hipcc hoists the loads of dozens of rows of this straight-line
+        // code and spills (kilobytes of scratch per lane at k > 64).
+        double g2[G2 ? 2 : 1][NG];
+        if (GV && G2) {
+#pragma unroll
+            for (int m = 0; m < NG; ++m) g2[0][m] = Gv[16 * m];
+        }
+        if (XM) {  // the first PF coordinates of this sweep (slot = coordinate % PF)
+#pragma unroll
+            for (int q = 0; q < PF; ++q) x[q] = valid ? xt[q * xs] : 0.0;
+        }
         static_for<KP>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             if (i < k) {
-                const double xi = x[i];
+                const double xi = x[XM ? (i % PF) : i];
+                if (XM && i + PF < k) x[i % PF] = valid ? xt[(i + PF) * xs] : 0.0;  // x of coordinate i + PF (same slot)
                 double grow[NG];
                 double gii;
                 if (GV) {
+                    if (G2) {
+                        if (i + 1 < k) {
 #pragma unroll
-                    for (int m = 0; m < NG; ++m) grow[m] = Gv[i * GS + 16 * m];
+                            for (int m = 0; m < NG; ++m) g2[(i + 1) & 1][m] = Gv[(i + 1) * GS + 16 * m];
+                        }
+                    } else {
+#pragma unroll
+                        for (int m = 0; m < NG; ++m) g2[0][m] = Gv[i * GS + 16 * m];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int m = 0; m < NG; ++m) grow[m] = g2[G2 ? (i & 1) : 0][m];
                     gii = nnls_dpp_bcast<(i & 15)>(grow[i >> 4]);
                 } else {
                     gii = Gs[i + KP * i];
@@ -114,7 +150,11 @@ __global__ __launch_bounds__(256) void nnls_lane_kernel(const double* __restrict
                 const double xn = clamp ? 0.0 : xi + diff;
                 double delta = clamp ? -xi : diff;
                 delta = go ? delta : 0.0;
-                x[i] = go ? xn : xi;
+                if (XM) {
+                    if (go) xt[i * xs] = xn;
+                } else {
+                    x[i] = go ? xn : xi;
+                }
                 const double tadd = fabs(diff / (xn + 1e-15));
                 const double tnew = clamp ? ((xi != 0.0) ? 1.0 : tol) : tol + tadd;
                 tol = go ? tnew : tol;
@@ -124,16 +164,21 @@ __global__ __launch_bounds__(256) void nnls_lane_kernel(const double* __restrict
                     if (GV) nnls_dpp_fmac<(j & 15)>(b[j], grow[j >> 4], nd);
                     else b[j] = fma(Gs[j + KP * i], nd, b[j]);
                 });
+                if (GV) __builtin_amdgcn_sched_barrier(0);
             }
         });
         it += go ? 1 : 0;
     }
     const bool unfinished = valid && it < 100 && (tol / kd) > 1e-8;  // only possible when !to_end
     if (valid) {
-        static_for<KP>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            if (j < k) xp[j] = x[j];
-        });
+        if (XM) {
+            for (int j = 0; j < k; ++j) xp[j] = xt[j * xs];
+        } else {
+            static_for<KP>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                if (j < k) xp[j] = x[j];
+            });
+        }
     }
     if (unfinished) {
         static_for<KP>([&](auto jc) {
@@ -166,3 +211,5 @@ __global__ __launch_bounds__(256) void nnls_lane_kernel(const double* __restrict
 // free SGPRs).  nnls_gram_stride() in kernels_nnls.hip must agree.
 #define SGL_NNLS_CASE(K_, GV_) \
     case K_: nnls_lane_kernel<K_, GV_><<<g, b, 0, s>>>(Gpad, B, X, col_nnz, k, ncols, L1, L2, sweep_counter, ps); break
+#define SGL_NNLS_CASE_XM(K_) \
+    case K_: nnls_lane_kernel<K_, true, true><<<g, b, 0, s>>>(Gpad, B, X, col_nnz, k, ncols, L1, L2, sweep_counter, ps); break

@@ -12,7 +12,7 @@
 
 #define SGL_WAVE 64
 #define SGL_MAX_K 256          // generic (wave-per-column) NNLS handles k <= 256
-#define SGL_LANE_NNLS_MAX_K 64  // register-resident lane-per-column NNLS handles k <= 64
+#define SGL_LANE_NNLS_MAX_K 104  // lane-per-column NNLS: k <= 64 all in registers, k <= 104 with x in a memory scratch
 
 void sgl_set_error(const char* fmt, ...);
 
@@ -71,6 +71,8 @@ struct NnlsPass {
     uint8_t* it_state;    // sweeps done so far, per column
     double* tol_state;    // running tol, per column
     int32_t final_below;  // a pass over at most this many columns runs them to the end
+    double* xt;           // k > 64: scratch holding x, xt[i * xt_stride + position in this pass]
+    int64_t xt_stride;
 };
 // device scratch of the multi-pass solve, sized for `cap` columns (owned by the caller)
 struct NnlsScratch {
@@ -78,6 +80,7 @@ struct NnlsScratch {
     uint32_t* counts = nullptr;   // SGL_NNLS_MAX_PASSES + 1
     uint8_t* it_state = nullptr;
     double* tol_state = nullptr;
+    double* xt = nullptr;         // k x cap doubles when the fit's rank is above 64
     int64_t cap = 0;
 };
 
@@ -172,7 +175,8 @@ int k_link_mul(hipStream_t s, double* B, const double* L, int k, int link_rows, 
 // below this many columns the GPU is not full anyway: one pass (env SGL_NNLS_REPACK_MIN_COLS overrides, tests)
 int64_t nnls_repack_min_cols();
 int nnls_gram_stride(int KP);  // row stride of the padded Gram the lane kernel expects
-int nnls_scratch_alloc(NnlsScratch& sc, int64_t cap);
+int nnls_lane_kp(int k);
+int nnls_scratch_alloc(NnlsScratch& sc, int64_t cap, int k_for_xt);
 void nnls_scratch_free(NnlsScratch& sc);
 // B is destroyed (and used as the spill space of b between passes).  scr == nullptr: one pass.
 int k_nnls_lane(hipStream_t s, const double* Gpad, int KP, double* B, double* X, const int64_t* col_nnz,

@@ -388,7 +388,7 @@ static int build_tiles(sgl_ctx* c, DevCSC& M, int k) {
     return k_build_segments(c->stream, M);
 }
 
-static int lane_kp(int k) { return (k + 1) / 2 * 2; }
+static int lane_kp(int k) { return nnls_lane_kp(k); }
 
 // ------------------------------------------------------------ input staging --
 extern "C" int sgl_log_normalize(sgl_ctx* c, double scale_factor) {
@@ -460,10 +460,10 @@ extern "C" int sgl_fit_init(sgl_ctx* c, int32_t k, const double* w_init, uint64_
     SGLCHK(dev_alloc(&c->red, (size_t)k * m + (size_t)k * k + (size_t)k));
     SGLCHK(dev_alloc(&c->G, (size_t)k * k));
     const int KP = lane_kp(k);
-    SGLCHK(dev_alloc(&c->Gpad, (size_t)64 * 64 + 64));
+    SGLCHK(dev_alloc(&c->Gpad, (size_t)112 * 112 + 64));
     {
         const int64_t cap = std::max<int64_t>(c->A.ncol, c->A.nrow);
-        if (k <= SGL_LANE_NNLS_MAX_K && cap >= nnls_repack_min_cols()) SGLCHK(nnls_scratch_alloc(c->nnls_scr, cap));
+        if (k <= SGL_LANE_NNLS_MAX_K) SGLCHK(nnls_scratch_alloc(c->nnls_scr, cap, k));
     }
     if (w_init) HIPCHK(hipMemcpyAsync(c->W, w_init, sizeof(double) * (size_t)k * m, hipMemcpyHostToDevice, c->stream));
     else SGLCHK(k_synth_winit(c->stream, synth_seed, k, (int32_t)m, c->W));
@@ -1008,10 +1008,10 @@ extern "C" int sgl_op_nnls(sgl_ctx* c, const double* G, const double* B, double*
     int rc;
     if (k <= SGL_LANE_NNLS_MAX_K) {
         const int KP = lane_kp(k);
-        rc = dev_alloc(&dGp, (size_t)64 * 64 + 64);
+        rc = dev_alloc(&dGp, (size_t)112 * 112 + 64);
         if (rc == SGL_OK) rc = k_pad_gram(c->stream, dG, k, KP, nnls_gram_stride(KP), dGp);
         NnlsScratch scr;  // re-pack passes only pay off (and are only used) for many columns
-        if (rc == SGL_OK && ncols >= nnls_repack_min_cols()) rc = nnls_scratch_alloc(scr, ncols);
+        if (rc == SGL_OK && (ncols >= nnls_repack_min_cols() || k > 64)) rc = nnls_scratch_alloc(scr, ncols, k);
         if (rc == SGL_OK) rc = k_nnls_lane(c->stream, dGp, KP, dB, dX, nullptr, k, ncols, L1, L2, c->sweep_counters + 4, &scr);
         if (rc == SGL_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = SGL_EHIP;
         nnls_scratch_free(scr);
