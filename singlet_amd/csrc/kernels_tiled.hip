@@ -281,7 +281,10 @@ __device__ __forceinline__ void acc_load(int idx4, double& v0, double& v1) {
 __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(128), amdgpu_waves_per_eu(4, 4))) void acc_tiled_kernel(
     const uint32_t* __restrict__ sroff, const double* __restrict__ sx, const int64_t* __restrict__ cstart,
     const uint8_t* __restrict__ cnt, int T, int64_t nwb, const double* __restrict__ F, int k, int TR, int64_t nrow,
-    int tiles_per_range, double* __restrict__ Bout, int64_t ncol) {
+    int tiles_per_range, double* __restrict__ Bout, int64_t ncol, int KS, int ldf, int ldb, int64_t slab) {
+    // k = factor rows handled by this launch (a part of the rank when it is above 64), KS = LDS row
+    // stride the stream's offsets were built for, ldf / ldb = strides (doubles) between rows of F /
+    // columns of the output, slab = doubles between the outputs of two tile ranges (blockIdx.y)
     asm volatile("" ::: "v255");  // make the kernel descriptor allocate 256 VGPRs
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* tile = reinterpret_cast<double*>(smem);
@@ -291,7 +294,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(128), amdgpu_wa
     const int t0 = blockIdx.y * tiles_per_range;
     const int t1 = (t0 + tiles_per_range < T) ? (t0 + tiles_per_range) : T;
     const bool wact = wb < nwb;
-    const int KS = (k + 1) & ~1;
     // LDS byte address of this lane's pair of factor rows inside a tile row (raw 32-bit LDS addresses
     // are used below so that no per-entry base add is emitted)
     typedef __attribute__((address_space(3))) char lds_char;
@@ -336,8 +338,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(128), amdgpu_wa
         const int64_t row0 = (int64_t)t * TR;
         const int rows = (int)((nrow - row0 < TR) ? (nrow - row0) : TR);
         const int n = rows * k;
-        const double* __restrict__ src = F + row0 * k;
-        if (KS == k) {
+        const double* __restrict__ src = F + row0 * ldf;
+        if (KS == k && ldf == k) {
             // Each thread moves up to NRND * RST 16-byte pieces of the (contiguous) tile in NRND rounds of
             // RST loads in flight (two rounds of ten measured faster than four of five).  The loads of the
             // first round are issued before the barrier: they overlap the tail of the previous tile's
@@ -376,11 +378,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(128), amdgpu_wa
             // odd k: rows are re-pitched to KS = k + 1 doubles (the pad column is never summed into a
             // stored factor row: lane 2l+1 == k is not written out)
             __syncthreads();
+            // (also the path of a rank split into parts: rows of F are then ldf > k apart)
             for (int e = (int)threadIdx.x; e < n; e += 64 * TILED_NW) {
                 const int r = e / k, f = e - r * k;
-                tile[r * KS + f] = src[e];
+                tile[r * KS + f] = src[(int64_t)r * ldf + f];
             }
-            for (int r = (int)threadIdx.x; r < rows; r += 64 * TILED_NW) tile[r * KS + k] = 0.0;
+            if (KS != k)
+                for (int r = (int)threadIdx.x; r < rows; r += 64 * TILED_NW) tile[r * KS + k] = 0.0;
         }
         // hipcc's wait-count pass cannot see that the conditional staging loads above are complete on
         // every path, and it does not see the asm stream loads at all: without this explicit wait (which
@@ -470,30 +474,39 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(128), amdgpu_wa
                  :
                  : "memory");
     if (wact) {
-        double* out = Bout + (size_t)blockIdx.y * (size_t)k * (size_t)ncol;
+        double* out = Bout + (size_t)blockIdx.y * (size_t)slab;
         const int f = 2 * (lane & 31);
         for (int p = 0; p < TILED_NP; ++p) {
             double v0, v1;
             acc_load(4 * p, v0, v1);
             const int64_t col = wb * TILED_CW + p + ((lane >> 5) ? TILED_NP : 0);
             if (col < ncol) {
-                if (f < k) out[col * k + f] = v0;
-                if (f + 1 < k) out[col * k + f + 1] = v1;
+                if (f < k) out[col * ldb + f] = v0;
+                if (f + 1 < k) out[col * ldb + f + 1] = v1;
             }
         }
     }
 }
 
-__global__ void acc_tiled_reduce_kernel(const double* __restrict__ part, int R, int64_t n, double* __restrict__ B) {
+// B[col * ldb + f] = sum over the R tile-range slabs (compact k x ncol each, fixed order)
+__global__ void acc_tiled_reduce_kernel(const double* __restrict__ part, int R, int64_t n, int k, int ldb, double* __restrict__ B) {
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
         double s = part[e];
         for (int r = 1; r < R; ++r) s += part[(size_t)r * n + e];
-        B[e] = s;
+        if (ldb == k) {
+            B[e] = s;
+        } else {
+            const int64_t col = e / k;
+            B[col * ldb + (e - col * k)] = s;
+        }
     }
 }
 
-int k_acc_tiled(hipStream_t s, const DevTiled& S, const double* F, double* B) {
+// F: first factor row of this part (row stride ldf), B: its first output row (column stride ldb), kf <= S.k
+// factor rows.  One launch = one pass over the stream.
+int k_acc_tiled(hipStream_t s, const DevTiled& S, const double* F, int ldf, double* B, int ldb, int kf) {
     if (S.ncol <= 0) return SGL_OK;
+    if (kf <= 0 || kf > S.k) { sgl_set_error("k_acc_tiled: bad part size %d (stream built for %d)", kf, S.k); return SGL_EINVAL; }
     const int KS = (S.k + 1) & ~1;
     const size_t lds = (size_t)S.TR * KS * 8 + 512;
     static bool attr_set = false;
@@ -503,16 +516,35 @@ int k_acc_tiled(hipStream_t s, const DevTiled& S, const double* F, double* B) {
         attr_set = true;
     }
     const int64_t nwg_x = (S.nwb + TILED_NW - 1) / TILED_NW;
-    double* out = (S.R > 1) ? S.part : B;
+    const bool slabs = S.R > 1;
+    double* out = slabs ? S.part : B;
+    const int64_t n = (int64_t)kf * S.ncol;
     acc_tiled_kernel<<<dim3((unsigned)nwg_x, (unsigned)S.R), dim3(64 * TILED_NW), lds, s>>>(
-        S.roff, S.x, S.cstart, S.cnt, S.T, S.nwb, F, S.k, S.TR, S.nrow, S.tiles_per_range, out, S.ncol);
+        S.roff, S.x, S.cstart, S.cnt, S.T, S.nwb, F, kf, S.TR, S.nrow, S.tiles_per_range, out, S.ncol, KS, ldf,
+        slabs ? kf : ldb, slabs ? n : 0);
     HIPCHK(hipGetLastError());
-    if (S.R > 1) {
-        const int64_t n = (int64_t)S.k * S.ncol;
+    if (slabs) {
         int64_t blocks = (n + 255) / 256;
         if (blocks > 4096) blocks = 4096;
-        acc_tiled_reduce_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(S.part, S.R, n, B);
+        acc_tiled_reduce_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(S.part, S.R, n, kf, ldb, B);
         HIPCHK(hipGetLastError());
     }
     return SGL_OK;
+}
+
+// the whole rank: one pass per part of at most S.k factor rows (one part for k <= 64)
+int k_acc_tiled_all(hipStream_t s, const DevTiled& S, const double* F, double* B, int k) {
+    for (int f0 = 0; f0 < k; f0 += S.k) {
+        const int kf = (k - f0 < S.k) ? (k - f0) : S.k;
+        SGLCHK(k_acc_tiled(s, S, F + f0, k, B + f0, k, kf));
+    }
+    return SGL_OK;
+}
+
+// part size the entry streams are built for at rank k (0: no tiled path): even, at most 64
+int tiled_part_size(int k) {
+    if (k <= 64) return k;
+    if (k > 128) return 0;
+    const int parts = (k + 63) / 64;
+    return ((k + parts - 1) / parts + 1) & ~1;
 }

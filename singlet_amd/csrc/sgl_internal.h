@@ -163,7 +163,9 @@ int k_acc(hipStream_t s, const DevCSC& M, const double* F, int k, double* B,
 // LDS-tiled accumulate
 void sgl_tiled_free(DevTiled& S);
 int sgl_tiled_build(sgl_ctx* c, const DevCSC& M, int k, DevTiled& S);
-int k_acc_tiled(hipStream_t s, const DevTiled& S, const double* F, double* B);
+int k_acc_tiled(hipStream_t s, const DevTiled& S, const double* F, int ldf, double* B, int ldb, int kf);
+int k_acc_tiled_all(hipStream_t s, const DevTiled& S, const double* F, double* B, int k);
+int tiled_part_size(int k);
 
 // input staging (kernels_prep.hip)
 int k_colsum(hipStream_t s, const DevCSC& M, double* sums);

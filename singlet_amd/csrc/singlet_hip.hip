@@ -472,11 +472,11 @@ extern "C" int sgl_fit_init(sgl_ctx* c, int32_t k, const double* w_init, uint64_
     HIPCHK(hipMemcpyAsync(c->d, ones.data(), sizeof(double) * k, hipMemcpyHostToDevice, c->stream));
     SGLCHK(build_tiles(c, c->A, k));
     SGLCHK(build_tiles(c, c->At, k));
-    // LDS-tiled accumulate (lanes over the k factor rows): k <= 64
+    // LDS-tiled accumulate (lanes over the factor rows): k <= 128
     c->use_tiled = false;
-    if (k <= 64 && !getenv("SGL_NO_TILED")) {
-        SGLCHK(sgl_tiled_build(c, c->A, k, c->TA));
-        if (c->At.nnz > 0) SGLCHK(sgl_tiled_build(c, c->At, k, c->TAt));
+    if (tiled_part_size(k) > 0 && !getenv("SGL_NO_TILED")) {  // ranks above 64 run as two passes of k / 2 factor rows
+        SGLCHK(sgl_tiled_build(c, c->A, tiled_part_size(k), c->TA));
+        if (c->At.nnz > 0) SGLCHK(sgl_tiled_build(c, c->At, tiled_part_size(k), c->TAt));
         c->use_tiled = true;
     }
     // global per-gene non-zero counts decide which W columns predict() skips (l.340)
@@ -536,7 +536,7 @@ extern "C" int sgl_step_h(sgl_ctx* c, double L1, double L2) {
     const int k = c->k;
     { Phase ph(c, SGL_PH_GRAM); SGLCHK(k_gram(c, c->W, k, c->A.nrow, c->G, 1e-15)); }
     { Phase ph(c, SGL_PH_RHS_H);
-      if (c->use_tiled) SGLCHK(k_acc_tiled(c->stream, c->TA, c->W, c->B));
+      if (c->use_tiled) SGLCHK(k_acc_tiled_all(c->stream, c->TA, c->W, c->B, k));
       else SGLCHK(k_acc(c->stream, c->A, c->W, k, c->B, 0, 1, 0, 0, 0));
       if (c->link_h) SGLCHK(k_link_mul(c->stream, c->B, c->link_h, k, c->link_h_rows, c->A.ncol)); }  // predict_link l.429-430
     { Phase ph(c, SGL_PH_NNLS_H);
@@ -562,7 +562,7 @@ extern "C" int sgl_step_w(sgl_ctx* c, double L1, double L2) {
     double* Bw = c->red;
     double* Gh = c->red + (size_t)k * m;
     { Phase ph(c, SGL_PH_RHS_W);
-      if (c->use_tiled && c->TAt.roff) SGLCHK(k_acc_tiled(c->stream, c->TAt, c->H, Bw));
+      if (c->use_tiled && c->TAt.roff) SGLCHK(k_acc_tiled_all(c->stream, c->TAt, c->H, Bw, k));
       else SGLCHK(k_acc(c->stream, c->At, c->H, k, Bw, 0, 1, 0, 0, 0)); }
     { Phase ph(c, SGL_PH_GRAM); SGLCHK(k_gram(c, c->H, k, c->A.ncol, Gh, 0.0)); }
     SGLCHK(do_allreduce(c, c->red, (int64_t)k * m + (int64_t)k * k));
@@ -965,7 +965,7 @@ extern "C" int sgl_op_rhs(sgl_ctx* c, int which, const double* F, int32_t k, dou
     const bool tiled = (which & 2) != 0;  // which = 2 / 3: same right-hand sides through the LDS-tiled kernel
     DevCSC& M = (which & 1) ? c->At : c->A;
     if (!M.p) { sgl_set_error("no matrix resident"); return SGL_ESTATE; }
-    if (!F || !B || k <= 0 || k > SGL_MAX_K || (tiled && k > 64)) { sgl_set_error("sgl_op_rhs: bad arguments"); return SGL_EINVAL; }
+    if (!F || !B || k <= 0 || k > SGL_MAX_K || (tiled && tiled_part_size(k) == 0)) { sgl_set_error("sgl_op_rhs: bad arguments"); return SGL_EINVAL; }
     double *dF = nullptr, *dB = nullptr;
     SGLCHK(dev_alloc(&dF, (size_t)k * M.nrow + 2));
     SGLCHK(dev_alloc(&dB, (size_t)k * M.ncol));
@@ -973,8 +973,8 @@ extern "C" int sgl_op_rhs(sgl_ctx* c, int which, const double* F, int32_t k, dou
     int rc;
     if (tiled) {
         DevTiled S;
-        rc = sgl_tiled_build(c, M, k, S);
-        if (rc == SGL_OK) rc = k_acc_tiled(c->stream, S, dF, dB);
+        rc = sgl_tiled_build(c, M, tiled_part_size(k), S);
+        if (rc == SGL_OK) rc = k_acc_tiled_all(c->stream, S, dF, dB, k);
         HIPCHK(hipMemcpyAsync(B, dB, sizeof(double) * (size_t)k * M.ncol, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         sgl_tiled_free(S);

@@ -70,6 +70,20 @@ def test_rhs_both_orientations(ctx, ora, sa, k):
     assert rel_fro(ctx.op_rhs(1, H), ora.rhs(At, H)) < 1e-14
 
 
+@pytest.mark.parametrize("k", [2, 7, 31, 50, 64, 65, 70, 100, 127, 128])
+def test_rhs_tiled_kernel_all_ranks(ctx, ora, sa, k):
+    """The LDS-tiled accumulate (which = 2 / 3): one pass for k <= 64, two passes over factor halves
+    for 64 < k <= 128 (strided factor rows and outputs), odd ranks through the re-pitched staging."""
+    A = ora.synth_csc(700, 900, 12)
+    At = A.t()
+    ctx.upload(to_dgc(sa, A), to_dgc(sa, At))
+    rng = np.random.default_rng(k)
+    W = rng.random((A.nrow, k))
+    H = rng.random((A.ncol, k))
+    assert rel_fro(ctx.op_rhs(2, W), ora.rhs(A, W)) < 1e-14
+    assert rel_fro(ctx.op_rhs(3, H), ora.rhs(At, H)) < 1e-14
+
+
 def test_rhs_ragged_and_empty_columns(ctx, ora, sa):
     rng = np.random.default_rng(3)
     D = (rng.random((90, 140)) < 0.3) * rng.random((90, 140))
