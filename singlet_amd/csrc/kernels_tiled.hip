@@ -379,9 +379,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(128), amdgpu_wa
             // stored factor row: lane 2l+1 == k is not written out)
             __syncthreads();
             // (also the path of a rank split into parts: rows of F are then ldf > k apart)
-            for (int e = (int)threadIdx.x; e < n; e += 64 * TILED_NW) {
-                const int r = e / k, f = e - r * k;
-                tile[r * KS + f] = src[(int64_t)r * ldf + f];
+            if (((k | ldf) & 1) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+                const int hp = k >> 1;  // 16-byte pieces per row
+                for (int e = (int)threadIdx.x; e < rows * hp; e += 64 * TILED_NW) {
+                    const int r = e / hp, c2 = (e - r * hp) * 2;
+                    *reinterpret_cast<double2*>(tile + r * KS + c2) = *reinterpret_cast<const double2*>(src + (int64_t)r * ldf + c2);
+                }
+            } else {
+                for (int e = (int)threadIdx.x; e < n; e += 64 * TILED_NW) {
+                    const int r = e / k, f = e - r * k;
+                    tile[r * KS + f] = src[(int64_t)r * ldf + f];
+                }
             }
             if (KS != k)
                 for (int r = (int)threadIdx.x; r < rows; r += 64 * TILED_NW) tile[r * KS + k] = 0.0;
