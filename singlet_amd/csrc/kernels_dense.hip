@@ -79,6 +79,76 @@ __global__ __launch_bounds__(256) void gram_mfma_kernel(const double* __restrict
         }
 }
 
+// 64 < k <= 128 (NT = 5 .. 8): all NT (NT + 1) / 2 tiles no longer fit one wave's registers, so the tiles
+// are dealt out to the 4 waves of the workgroup (tile t to wave t % 4) and every wave walks ALL columns of
+// the block's chunk (the operand loads of the 4 waves hit the same cache lines).  No cross-wave reduction:
+// each tile of the block's partial has one owner.
+template <int NT, int W>
+__device__ __forceinline__ void gram_split_wave(const double* __restrict__ F, int k, int64_t c_begin, int64_t c_end,
+                                                double* __restrict__ out) {
+    constexpr int NTILES = NT * (NT + 1) / 2;
+    constexpr int MINE = (NTILES - W + 3) / 4;  // tiles t = W, W + 4, ...
+    const int lane = threadIdx.x & 63;
+    const int r16 = lane & 15, kk = lane >> 4;
+    d4 acc[MINE];
+#pragma unroll
+    for (int q = 0; q < MINE; ++q) acc[q] = d4{0, 0, 0, 0};
+    for (int64_t c = c_begin; c < c_end; c += 4) {
+        const int64_t cc = c + kk;
+        double f[NT];
+#pragma unroll
+        for (int b = 0; b < NT; ++b) {
+            const int row = b * 16 + r16;
+            f[b] = (cc < c_end && row < k) ? F[cc * k + row] : 0.0;
+        }
+        int t = 0, q = 0;
+#pragma unroll
+        for (int bi = 0; bi < NT; ++bi)
+#pragma unroll
+            for (int bj = 0; bj <= bi; ++bj) {
+                if (t % 4 == W) {
+                    acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[bi], f[bj], acc[q], 0, 0, 0);
+                    ++q;
+                }
+                ++t;
+            }
+    }
+    int t = 0, q = 0;
+#pragma unroll
+    for (int bi = 0; bi < NT; ++bi)
+#pragma unroll
+        for (int bj = 0; bj <= bi; ++bj) {
+            if (t % 4 == W) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = bi * 16 + kk + 4 * r;  // D row (lane >> 4) + 4 r
+                    const int col = bj * 16 + r16;         // D col lane & 15
+                    if (row < k && col < k) {
+                        out[(size_t)col * k + row] = acc[q][r];
+                        if (bi != bj) out[(size_t)row * k + col] = acc[q][r];
+                    }
+                }
+                ++q;
+            }
+            ++t;
+        }
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void gram_mfma_split_kernel(const double* __restrict__ F, int k, int64_t cols,
+                                                              int64_t cols_per_block, double* __restrict__ part) {
+    const int64_t c_begin = (int64_t)blockIdx.x * cols_per_block;
+    int64_t c_end = c_begin + cols_per_block;
+    if (c_end > cols) c_end = cols;
+    double* out = part + (size_t)blockIdx.x * k * k;
+    switch (threadIdx.x >> 6) {
+        case 0: gram_split_wave<NT, 0>(F, k, c_begin, c_end, out); break;
+        case 1: gram_split_wave<NT, 1>(F, k, c_begin, c_end, out); break;
+        case 2: gram_split_wave<NT, 2>(F, k, c_begin, c_end, out); break;
+        default: gram_split_wave<NT, 3>(F, k, c_begin, c_end, out); break;
+    }
+}
+
 // generic VALU fallback for k > 64 (NT > 4 would need > 10 accumulator tiles).
 __global__ __launch_bounds__(256) void gram_valu_kernel(const double* __restrict__ F, int k, int64_t cols,
                                                         int64_t cols_per_block, double* __restrict__ part) {
@@ -138,6 +208,10 @@ int k_gram(sgl_ctx* c, const double* F, int k, int64_t cols, double* G, double d
     else if (NT == 2) gram_mfma_kernel<2><<<dim3(nblocks), dim3(256), 0, s>>>(F, k, cols, cpb, c->ws);
     else if (NT == 3) gram_mfma_kernel<3><<<dim3(nblocks), dim3(256), 0, s>>>(F, k, cols, cpb, c->ws);
     else if (NT == 4) gram_mfma_kernel<4><<<dim3(nblocks), dim3(256), 0, s>>>(F, k, cols, cpb, c->ws);
+    else if (NT == 5) gram_mfma_split_kernel<5><<<dim3(nblocks), dim3(256), 0, s>>>(F, k, cols, cpb, c->ws);
+    else if (NT == 6) gram_mfma_split_kernel<6><<<dim3(nblocks), dim3(256), 0, s>>>(F, k, cols, cpb, c->ws);
+    else if (NT == 7) gram_mfma_split_kernel<7><<<dim3(nblocks), dim3(256), 0, s>>>(F, k, cols, cpb, c->ws);
+    else if (NT == 8) gram_mfma_split_kernel<8><<<dim3(nblocks), dim3(256), 0, s>>>(F, k, cols, cpb, c->ws);
     else gram_valu_kernel<<<dim3(nblocks), dim3(256), sizeof(double) * 16 * k, s>>>(F, k, cols, cpb, c->ws);
     HIPCHK(hipGetLastError());
     gram_reduce_kernel<<<dim3((k * k + 255) / 256), dim3(256), 0, s>>>(c->ws, nblocks, k, diag_add, G);
