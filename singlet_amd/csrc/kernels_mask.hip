@@ -100,13 +100,17 @@ __global__ __launch_bounds__(256) void mask_gram_kernel(int64_t col0, int64_t nc
 typedef double mg_d4 __attribute__((ext_vector_type(4)));
 #define MG_QW 1024  // drawn rows a wave queues in LDS before it turns to the matrix cores
 
-template <int NT>
+// NPARTS > 1 (k > 96): the tile set no longer fits a wave's registers; launch PART = 0 .. NPARTS-1, each
+// computing the tiles t with t % NPARTS == PART (the rows are hashed again in every part).
+template <int NT, int NPARTS = 1, int PART = 0>
 __global__ __launch_bounds__(256) void mask_gram_mfma_kernel(int64_t col0, int64_t ncols, int32_t nrow,
                                                              const int64_t* __restrict__ col_nnz,
                                                              const double* __restrict__ F, const double* __restrict__ G,
                                                              int k, uint64_t seed, SglDiv inv_density, int mask_t,
                                                              int64_t col_off, int64_t row_off, double* __restrict__ Gout) {
-    constexpr int NTILES = NT * (NT + 1) / 2;
+    constexpr int NTILES_ALL = NT * (NT + 1) / 2;
+    constexpr int NTILES = (NTILES_ALL - PART + NPARTS - 1) / NPARTS;  // tiles of this part
+    constexpr int DEPTH = (NT <= 4) ? 4 : 2;                             // row groups in flight
     __shared__ int list[4 * MG_QW];
     __shared__ double sm[4][64 * 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -135,12 +139,15 @@ __global__ __launch_bounds__(256) void mask_gram_mfma_kernel(int64_t col0, int64
         }
     };
     auto mfma_group = [&](const double (&f)[NT]) {
-        int t = 0;
+        int t = 0, q = 0;
 #pragma unroll
         for (int bi = 0; bi < NT; ++bi)
 #pragma unroll
             for (int bj = 0; bj <= bi; ++bj) {
-                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[bi], f[bj], acc[t], 0, 0, 0);
+                if (t % NPARTS == PART) {
+                    acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[bi], f[bj], acc[q], 0, 0, 0);
+                    ++q;
+                }
                 ++t;
             }
     };
@@ -149,10 +156,18 @@ __global__ __launch_bounds__(256) void mask_gram_mfma_kernel(int64_t col0, int64
     auto drain = [&](int pending, bool all) -> int {
         const int ngroups = all ? (pending + 3) / 4 : pending / 4;
         int g = 0;
-        for (; g + 4 <= ngroups; g += 4) {
-            double f0[NT], f1[NT], f2[NT], f3[NT];
-            load_group(f0, g, pending); load_group(f1, g + 1, pending); load_group(f2, g + 2, pending); load_group(f3, g + 3, pending);
-            mfma_group(f0); mfma_group(f1); mfma_group(f2); mfma_group(f3);
+        if (DEPTH == 4) {
+            for (; g + 4 <= ngroups; g += 4) {
+                double f0[NT], f1[NT], f2[NT], f3[NT];
+                load_group(f0, g, pending); load_group(f1, g + 1, pending); load_group(f2, g + 2, pending); load_group(f3, g + 3, pending);
+                mfma_group(f0); mfma_group(f1); mfma_group(f2); mfma_group(f3);
+            }
+        } else {
+            for (; g + 2 <= ngroups; g += 2) {
+                double f0[NT], f1[NT];
+                load_group(f0, g, pending); load_group(f1, g + 1, pending);
+                mfma_group(f0); mfma_group(f1);
+            }
         }
         for (; g < ngroups; ++g) {
             double f0[NT];
@@ -185,14 +200,16 @@ __global__ __launch_bounds__(256) void mask_gram_mfma_kernel(int64_t col0, int64
     drain(pending, true);
 
     // sum the 4 waves' tiles in a fixed order; Gout = G - (Gsub + 1e-15 I)  (quirk 8: the two 1e-15 cancel)
-    int t = 0;
+    int t = 0, qa = 0;
 #pragma unroll
     for (int bi = 0; bi < NT; ++bi)
 #pragma unroll
         for (int bj = 0; bj <= bi; ++bj) {
+            if (t % NPARTS != PART) { ++t; continue; }
             __syncthreads();
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sm[wave][lane * 4 + r] = acc[t][r];
+            for (int r = 0; r < 4; ++r) sm[wave][lane * 4 + r] = acc[qa][r];
+            ++qa;
             __syncthreads();
             if (wave == 0) {
 #pragma unroll
@@ -217,13 +234,17 @@ int k_mask_gram_cols(hipStream_t s, int64_t col0, int64_t ncols, int32_t nrow, c
                      int64_t col_offset, int64_t row_offset, double* Gcols) {
     if (ncols <= 0) return SGL_OK;
     dim3 g((unsigned)ncols), b(256);
-    if (k <= 64 && !getenv("SGL_MASK_GRAM_VALU")) {  // env: keep the VALU kernel reachable for A/B tests
-#define SGL_MGM(NT_) mask_gram_mfma_kernel<NT_><<<g, b, 0, s>>>(col0, ncols, nrow, col_nnz, F, G, k, seed, sgl_div_make(inv_density), mask_t, col_offset, row_offset, Gcols)
+    if (k <= 128 && !getenv("SGL_MASK_GRAM_VALU")) {  // env: keep the VALU kernel reachable for A/B tests
+#define SGL_MGM(...) mask_gram_mfma_kernel<__VA_ARGS__><<<g, b, 0, s>>>(col0, ncols, nrow, col_nnz, F, G, k, seed, sgl_div_make(inv_density), mask_t, col_offset, row_offset, Gcols)
         switch ((k + 15) / 16) {
             case 1: SGL_MGM(1); break;
             case 2: SGL_MGM(2); break;
             case 3: SGL_MGM(3); break;
-            default: SGL_MGM(4); break;
+            case 4: SGL_MGM(4); break;
+            case 5: SGL_MGM(5); break;
+            case 6: SGL_MGM(6); break;
+            case 7: SGL_MGM(7, 2, 0); SGL_MGM(7, 2, 1); break;
+            default: SGL_MGM(8, 2, 0); SGL_MGM(8, 2, 1); break;
         }
 #undef SGL_MGM
         HIPCHK(hipGetLastError());

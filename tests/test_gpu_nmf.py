@@ -85,11 +85,12 @@ def test_rcpp_predict(sa, ora, shape):
     assert rel_fro(got.T, ref) < TOL and same_zero_pattern(got.T, ref)
 
 
-@pytest.mark.parametrize("k,trace,maxit", [(6, 1, 4), (8, 2, 5), (5, 3, 4)])
+@pytest.mark.parametrize("k,trace,maxit", [(6, 1, 4), (8, 2, 5), (5, 3, 4), (30, 2, 3), (50, 2, 2), (70, 2, 2), (90, 1, 2), (100, 2, 2), (116, 2, 2)])
 def test_c_ard_nmf_parity(sa, ora, k, trace, maxit):
-    A = ora.synth_csc(220, 260, 20)
+    m, n = (220, 260) if k <= 100 else (900, 1000)   # enough data for every factor to stay alive
+    A = ora.synth_csc(m, n, 20)
     At = A.t()
-    w0 = ora.synth_winit(k, 220)
+    w0 = ora.synth_winit(k, m)
     ref = ora.c_ard_nmf(A, At, 0.0, maxit, 0.01, 0.0, 0, w0, 77, 20, 1e-3, trace)
     got = sa.c_ard_nmf(to_dgc(sa, A), to_dgc(sa, At), 0.0, maxit, False, 0.01, 0.0, 0, w0.T, 77, 20, 1e-3, trace)
     _check(got, ref)
