@@ -12,6 +12,11 @@
 // packing; only the order in which columns land in the list varies from run to run.
 #pragma once
 #include "sgl_internal.h"
+// a wave leaves a pass when fewer than NUM / DEN of the lanes it started with are still iterating
+#ifndef SGL_NNLS_REPACK_NUM
+#define SGL_NNLS_REPACK_NUM 3
+#define SGL_NNLS_REPACK_DEN 8
+#endif
 #include <utility>
 #include <type_traits>
 
@@ -92,7 +97,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void n
         const bool go = valid && it < 100 && (tol / kd) > 1e-8;
         const int n_act = __popcll(__ballot(go));
         if (n_act == 0) break;
-        if (!to_end && n_act * 8 < n_act0 * 3) break;  // re-pack the stragglers
+        if (!to_end && n_act * SGL_NNLS_REPACK_DEN < n_act0 * SGL_NNLS_REPACK_NUM) break;  // re-pack the stragglers
         ++ran;
         if (go) tol = 0.0;
         // launder a (wave-uniform, always zero) offset once per sweep: the k*k scalar loads of the
