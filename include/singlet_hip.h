@@ -249,7 +249,7 @@ SGL_API int sgl_op_mask(sgl_ctx* ctx, uint64_t state, uint64_t inv_density, int6
 SGL_API int sgl_op_gram(sgl_ctx* ctx, const double* F, int32_t k, int64_t cols, double* G);
 /* Right-hand sides of predict (src/singlet.cpp:341-343) for the resident
  * shard: which = 0: B = F * A (F k x nrow, B k x ncol); which = 1: B = F * At;
- * which = 2 / 3: the same two products through the LDS-tiled kernel (k <= 64) that the
+ * which = 2 / 3: the same two products through the LDS-tiled kernel (k <= 128) that the
  * fit uses, instead of the plain CSC kernel. */
 SGL_API int sgl_op_rhs(sgl_ctx* ctx, int which, const double* F, int32_t k, double* B);
 /* nnls (src/singlet.cpp:229-250) on ncols independent columns sharing G:
@@ -287,7 +287,7 @@ SGL_API int sgl_sweeps_get(sgl_ctx* ctx, int64_t* out4, int reset);
  * the roofline report: per orientation (A then At) five numbers --
  * entries stored (non-zeros + padding), row tiles T, rows per tile TR, tile
  * ranges R (blockIdx.y slabs), column blocks of 64.  out10 all zero when the
- * fit runs on the plain CSC kernel (k > 64). */
+ * fit runs on the plain CSC kernel (k > 128). */
 SGL_API int sgl_layout_get(sgl_ctx* ctx, int64_t* out10);
 
 #ifdef __cplusplus
