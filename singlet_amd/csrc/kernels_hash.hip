@@ -70,12 +70,10 @@ __global__ __launch_bounds__(256) void synth_kernel(uint64_t S, SglDiv inv_densi
             if (FILL) {
                 if (drawn) {
                     const int64_t dst = pos + __popcll(m & ((1ull << lane) - 1ull));
+                    const uint64_t h1 = transposed ? sgl_rand2(S + 1, (uint64_t)(cell_offset + r), (uint64_t)col)
+                                                   : sgl_rand_j(xi1, (uint64_t)r);
                     idx[dst] = (int32_t)r;
-                    if (x != nullptr) {  // pattern only (mask cache): no values
-                        const uint64_t h1 = transposed ? sgl_rand2(S + 1, (uint64_t)(cell_offset + r), (uint64_t)col)
-                                                       : sgl_rand_j(xi1, (uint64_t)r);
-                        x[dst] = levels[(h1 >> 11) & 15];
-                    }
+                    x[dst] = levels[(h1 >> 11) & 15];
                 }
                 pos += __popcll(m);
             } else {

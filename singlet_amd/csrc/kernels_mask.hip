@@ -107,10 +107,7 @@ __global__ __launch_bounds__(256) void mask_gram_mfma_kernel(int64_t col0, int64
                                                              const int64_t* __restrict__ col_nnz,
                                                              const double* __restrict__ F, const double* __restrict__ G,
                                                              int k, uint64_t seed, SglDiv inv_density, int mask_t,
-                                                             int64_t col_off, int64_t row_off, double* __restrict__ Gout,
-                                                             const int64_t* __restrict__ Mp, const int32_t* __restrict__ Mi) {
-    // Mp / Mi != nullptr: the drawn rows of every column were listed once per fit (the mask does not
-    // change between iterations): no hashing, each wave takes a contiguous quarter of the column's list.
+                                                             int64_t col_off, int64_t row_off, double* __restrict__ Gout) {
     constexpr int NTILES_ALL = NT * (NT + 1) / 2;
     constexpr int NTILES = (NTILES_ALL - PART + NPARTS - 1) / NPARTS;  // tiles of this part
     constexpr int DEPTH = (NT <= 4) ? 4 : 2;                             // row groups in flight
@@ -130,16 +127,7 @@ __global__ __launch_bounds__(256) void mask_gram_mfma_kernel(int64_t col0, int64
     // Every wave works on its own: it hashes 64 rows per step (one per lane), compacts the drawn ones
     // into its own LDS queue (no workgroup barrier), and drains the queue through the matrix cores in
     // groups of 4 rows.  operands of group g for this lane: row q[4 g + kk], factors b*16 + r16.
-    const int* q = list + wave * MG_QW;
-    int listed = -1;
-    if (Mp != nullptr) {
-        const int64_t lo = Mp[col], len = Mp[col + 1] - lo;
-        const int64_t per = ((len + 3) / 4 + 3) / 4 * 4;  // quarter of the list, whole groups of 4
-        const int64_t a = (int64_t)wave * per < len ? (int64_t)wave * per : len;
-        const int64_t e = a + per < len ? a + per : len;
-        q = Mi + lo + a;
-        listed = (int)(e - a);
-    }
+    int* q = list + wave * MG_QW;
     auto load_group = [&](double (&f)[NT], int g, int pending) {
         const int idx = 4 * g + kk;
         const bool valid = idx < pending;
@@ -163,9 +151,8 @@ __global__ __launch_bounds__(256) void mask_gram_mfma_kernel(int64_t col0, int64
                 ++t;
             }
     };
-    // DEPTH groups' gathers (from L2) in flight before their MFMAs; `all` also takes the last, partial
-    // group (missing rows contribute zeros).  (An explicit double-buffered pipeline of the gathers was
-    // tried: hipcc spilled the operand buffers and it ran several times slower.)
+    // four groups' gathers (from L2) in flight before their MFMAs; `all` also takes the last, partial
+    // group (missing rows contribute zeros)
     auto drain = [&](int pending, bool all) -> int {
         const int ngroups = all ? (pending + 3) / 4 : pending / 4;
         int g = 0;
@@ -192,9 +179,7 @@ __global__ __launch_bounds__(256) void mask_gram_mfma_kernel(int64_t col0, int64
 
     const uint64_t gcol = (uint64_t)(col + col_off);
     int pending = 0;  // rows queued by this wave (wave-uniform)
-    int* qw = list + wave * MG_QW;
-    if (listed >= 0) pending = listed;
-    for (int64_t r0 = (int64_t)wave * 64; listed < 0 && r0 < nrow; r0 += 256) {
+    for (int64_t r0 = (int64_t)wave * 64; r0 < nrow; r0 += 256) {
         const int64_t r = r0 + lane;
         bool drawn = false;
         if (r < nrow) {
@@ -202,13 +187,13 @@ __global__ __launch_bounds__(256) void mask_gram_mfma_kernel(int64_t col0, int64
             drawn = mask_t ? sgl_draw(seed, grow, gcol, inv_density) : sgl_draw(seed, gcol, grow, inv_density);
         }
         const unsigned long long m = __ballot(drawn);
-        if (drawn) qw[pending + __popcll(m & ((1ull << lane) - 1ull))] = (int)r;
+        if (drawn) q[pending + __popcll(m & ((1ull << lane) - 1ull))] = (int)r;
         pending += __popcll(m);
         if (pending > MG_QW - 64) {  // another step might not fit
             const int done = drain(pending, false);
             const int rem = pending - done;  // < 4 left-over rows move to the front
-            const int v = (lane < rem) ? qw[done + lane] : 0;
-            if (lane < rem) qw[lane] = v;
+            const int v = (lane < rem) ? q[done + lane] : 0;
+            if (lane < rem) q[lane] = v;
             pending = rem;
         }
     }
@@ -246,11 +231,11 @@ __global__ __launch_bounds__(256) void mask_gram_mfma_kernel(int64_t col0, int64
 
 int k_mask_gram_cols(hipStream_t s, int64_t col0, int64_t ncols, int32_t nrow, const int64_t* col_nnz,
                      const double* F, const double* G, int k, uint64_t seed, uint64_t inv_density, int mask_t,
-                     int64_t col_offset, int64_t row_offset, double* Gcols, const int64_t* Mp, const int32_t* Mi) {
+                     int64_t col_offset, int64_t row_offset, double* Gcols) {
     if (ncols <= 0) return SGL_OK;
     dim3 g((unsigned)ncols), b(256);
     if (k <= 128 && !getenv("SGL_MASK_GRAM_VALU")) {  // env: keep the VALU kernel reachable for A/B tests
-#define SGL_MGM(...) mask_gram_mfma_kernel<__VA_ARGS__><<<g, b, 0, s>>>(col0, ncols, nrow, col_nnz, F, G, k, seed, sgl_div_make(inv_density), mask_t, col_offset, row_offset, Gcols, Mp, Mi)
+#define SGL_MGM(...) mask_gram_mfma_kernel<__VA_ARGS__><<<g, b, 0, s>>>(col0, ncols, nrow, col_nnz, F, G, k, seed, sgl_div_make(inv_density), mask_t, col_offset, row_offset, Gcols)
         switch ((k + 15) / 16) {
             case 1: SGL_MGM(1); break;
             case 2: SGL_MGM(2); break;
@@ -287,8 +272,7 @@ __global__ __launch_bounds__(256) void mse_test_kernel(const double* __restrict_
                                                        const int64_t* __restrict__ Ap, int32_t m, int64_t n,
                                                        int64_t cell_off, const double* __restrict__ Wd,
                                                        const double* __restrict__ H, int k, uint64_t seed,
-                                                       SglDiv inv_density, double* __restrict__ losses,
-                                                       const int64_t* __restrict__ Mp, const int32_t* __restrict__ Mi) {
+                                                       SglDiv inv_density, double* __restrict__ losses) {
     __shared__ int queue[4][128];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t gw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -301,29 +285,7 @@ __global__ __launch_bounds__(256) void mse_test_kernel(const double* __restrict_
         double s = 0.0;
         long long cnt = 0;
         int qn = 0;
-        if (Mp != nullptr) {
-            // listed mask: the drawn genes of this cell, 64 at a time, lane l takes the l-th of a batch --
-            // the same assignment (and so the same summation order) as the hashing loop below
-            const int64_t mlo = Mp[cell], mhi = Mp[cell + 1];
-            for (int64_t q0 = mlo; q0 < mhi; q0 += 64) {
-                if (q0 + lane < mhi) {
-                    const int gene = Mi[q0 + lane];
-                    double pred = 0.0;
-                    const double* wd = Wd + (int64_t)gene * k;
-                    for (int t = 0; t < k; ++t) pred = fma(wd[t], h[t], pred);
-                    int64_t lo = lo0, hi = hi0;
-                    while (lo < hi) {
-                        const int64_t mid = (lo + hi) >> 1;
-                        if (Ai[mid] < gene) lo = mid + 1; else hi = mid;
-                    }
-                    const double val = (lo < hi0 && Ai[lo] == gene) ? Ax[lo] : 0.0;
-                    const double e = pred - val;
-                    s = fma(e, e, s);
-                    ++cnt;
-                }
-            }
-        }
-        for (int g0 = 0; Mp == nullptr && g0 < m + 64; g0 += 64) {
+        for (int g0 = 0; g0 < m + 64; g0 += 64) {
             const int g = g0 + lane;
             const bool last = g0 >= m;
             bool drawn = false;
@@ -392,7 +354,7 @@ __global__ void sum_final_kernel(const double* __restrict__ part, int nblocks, d
 // out_dev[0] = sum over local cells of the per-cell mean squared test error
 // (the caller divides by the global number of cells, src/singlet.cpp:567).
 int k_mse_test(sgl_ctx* c, const double* Wd, const double* H, int k, uint64_t seed, uint64_t inv_density,
-               double* out_dev, const int64_t* Mp, const int32_t* Mi) {
+               double* out_dev) {
     const int64_t n = c->A.ncol;
     if (n <= 0) return SGL_OK;
     int nblocks = (int)((n + 4095) / 4096);
@@ -405,7 +367,7 @@ int k_mse_test(sgl_ctx* c, const double* Wd, const double* H, int k, uint64_t se
     if (blocks > 256 * 16) blocks = 256 * 16;
     mse_test_kernel<<<dim3((unsigned)blocks), dim3(256), 0, c->stream>>>(c->A.x, c->A.i, c->A.p, c->A.nrow, n,
                                                                          c->cell_offset, Wd, H, k, seed, sgl_div_make(inv_density),
-                                                                         losses, Mp, Mi);
+                                                                         losses);
     HIPCHK(hipGetLastError());
     sum_partial_kernel<<<dim3(nblocks), dim3(256), 0, c->stream>>>(losses, n, part);
     HIPCHK(hipGetLastError());

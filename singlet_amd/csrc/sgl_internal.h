@@ -104,13 +104,6 @@ struct sgl_ctx {
     double* G = nullptr;    // k x k Gram (+1e-15 diagonal)
     double* Gpad = nullptr; // KP x KP zero-padded copy for the lane NNLS kernel
     NnlsScratch nnls_scr;   // lists / per-column state of the multi-pass lane NNLS
-    // The cross-validation mask {(cell, gene): draw(seed, cell, gene)} listed once per (seed, inv_density) in
-    // both orientations ([0] by cell: rows = genes; [1] by gene: rows = local cells): it does not change between
-    // iterations, and re-hashing all m*n pairs twice per iteration was the bulk of the masked path's time.
-    int64_t* mask_p[2] = {nullptr, nullptr};
-    int32_t* mask_i[2] = {nullptr, nullptr};
-    uint64_t mask_seed = 0, mask_inv = 0;
-    bool mask_valid = false;
     double* link_h = nullptr;  // c_linked_nmf: link_rows x ncol / x nrow multipliers of the right-hand sides
     double* link_w = nullptr;
     int link_h_rows = 0, link_w_rows = 0;
@@ -196,9 +189,9 @@ int k_nnls_wave(hipStream_t s, const double* G, int64_t gstride, const double* B
 // masked path
 int k_mask_gram_cols(hipStream_t s, int64_t col0, int64_t ncols, int32_t nrow, const int64_t* col_nnz,
                      const double* F, const double* G, int k, uint64_t seed, uint64_t inv_density, int mask_t,
-                     int64_t col_offset, int64_t row_offset, double* Gcols, const int64_t* Mp, const int32_t* Mi);
+                     int64_t col_offset, int64_t row_offset, double* Gcols);
 int k_mse_test(sgl_ctx* c, const double* Wd, const double* H, int k, uint64_t seed, uint64_t inv_density,
-               double* out_dev, const int64_t* Mp, const int32_t* Mi);
+               double* out_dev);
 int k_wd(hipStream_t s, const double* W, const double* d, int k, int64_t cols, double* Wd);
 
 // ---- device-side hash (rng::rand, src/singlet.cpp:30-64) ------------------

@@ -155,18 +155,7 @@ static void free_fit(sgl_ctx* c) {
     c->k = 0;
 }
 
-static void free_mask_cache(sgl_ctx* c) {
-    for (int o = 0; o < 2; ++o) {
-        dev_free(c->mask_p[o]);
-        dev_free(c->mask_i[o]);
-        c->mask_p[o] = nullptr;
-        c->mask_i[o] = nullptr;
-    }
-    c->mask_valid = false;
-}
-
 static void free_matrix(sgl_ctx* c) {
-    free_mask_cache(c);
     free_csc(c->A);
     free_csc(c->At);
     dev_free(c->col_nnz_A);
@@ -669,46 +658,10 @@ extern "C" int sgl_set_factors(sgl_ctx* c, const double* w, const double* d, con
 // ------------------------------------------------------------- masked path --
 // predict_mask (src/singlet.cpp:436-466) for one orientation, columns in
 // chunks so the per-column Grams a_i (k*k doubles each) stay bounded.
-// List the mask once per (seed, inv_density): the same kernels as the synthetic generator, pattern only
-// (draw(seed, cell, gene) is the generator's predicate with S = seed).  Failing to allocate the lists
-// (or SGL_NO_MASK_CACHE) leaves the hashing path in place.
-static int ensure_mask_cache(sgl_ctx* c, uint64_t seed, uint64_t inv_density) {
-    if (c->mask_valid && c->mask_seed == seed && c->mask_inv == inv_density) return SGL_OK;
-    free_mask_cache(c);
-    if (getenv("SGL_NO_MASK_CACHE")) return SGL_OK;
-    const int32_t ngenes = c->A.nrow, ncells = c->A.ncol;
-    for (int o = 0; o < 2; ++o) {
-        const int64_t ncol = o ? ngenes : ncells;
-        int64_t* counts = nullptr;
-        int rc = dev_alloc(&counts, (size_t)std::max<int64_t>(ncol, 1));
-        if (rc == SGL_OK) rc = dev_alloc(&c->mask_p[o], (size_t)ncol + 1);
-        if (rc == SGL_OK) rc = k_synth_count(c->stream, seed, inv_density, o, c->cell_offset, ncells, ngenes, counts);
-        if (rc == SGL_OK) rc = k_exclusive_scan(c, counts, c->mask_p[o], ncol);
-        if (rc == SGL_OK) rc = k_scan_total(c->stream, counts, c->mask_p[o], ncol);
-        int64_t nnz = 0;
-        if (rc == SGL_OK && (hipMemcpyAsync(&nnz, c->mask_p[o] + ncol, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-                             hipStreamSynchronize(c->stream) != hipSuccess)) rc = SGL_EHIP;
-        if (rc == SGL_OK) rc = dev_alloc(&c->mask_i[o], (size_t)std::max<int64_t>(nnz, 1));
-        if (rc == SGL_OK) rc = k_synth_fill(c->stream, seed, inv_density, nullptr, o, c->cell_offset, ncells, ngenes, c->mask_p[o], c->mask_i[o], nullptr);
-        if (rc == SGL_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = SGL_EHIP;
-        dev_free(counts);
-        if (rc != SGL_OK) {  // not fatal: hash instead
-            (void)hipGetLastError();
-            free_mask_cache(c);
-            return SGL_OK;
-        }
-    }
-    c->mask_seed = seed;
-    c->mask_inv = inv_density;
-    c->mask_valid = true;
-    return SGL_OK;
-}
-
 static int predict_mask_dev(sgl_ctx* c, const DevCSC& M, const int64_t* col_nnz, const double* F, double* X,
                             double* Bbuf, uint64_t seed, uint64_t inv_density, double L1, double L2, int mask_t,
                             int rhs_phase, int nnls_phase, unsigned long long* counter) {
     const int k = c->k;
-    SGLCHK(ensure_mask_cache(c, seed, inv_density));
     // hash argument order: A pass draw(cell = col + cell_offset, gene = row); At pass draw(cell = row + cell_offset, gene = col)
     const int64_t col_off = mask_t ? 0 : c->cell_offset;
     const int64_t row_off = mask_t ? c->cell_offset : 0;
@@ -722,9 +675,7 @@ static int predict_mask_dev(sgl_ctx* c, const DevCSC& M, const int64_t* col_nnz,
     for (int64_t c0 = 0; c0 < M.ncol && rc == SGL_OK; c0 += chunk) {
         const int64_t nc = std::min<int64_t>(chunk, M.ncol - c0);
         { Phase ph(c, SGL_PH_MASK);
-          const int o = mask_t ? 1 : 0;
-          rc = k_mask_gram_cols(c->stream, c0, nc, M.nrow, col_nnz, F, c->G, k, seed, inv_density, mask_t, col_off, row_off, Gcols,
-                                c->mask_valid ? c->mask_p[o] : nullptr, c->mask_valid ? c->mask_i[o] : nullptr); }
+          rc = k_mask_gram_cols(c->stream, c0, nc, M.nrow, col_nnz, F, c->G, k, seed, inv_density, mask_t, col_off, row_off, Gcols); }
         if (rc != SGL_OK) break;
         { Phase ph(c, nnls_phase);
           rc = k_nnls_wave(c->stream, Gcols, (int64_t)k * k, Bbuf + (size_t)c0 * k, X + (size_t)c0 * k,
@@ -745,9 +696,7 @@ static int mse_test_dev(sgl_ctx* c, uint64_t seed, uint64_t inv_density, double*
     {
         Phase ph(c, SGL_PH_MASK);
         rc = k_wd(c->stream, c->W, c->d, k, m, Wd);
-        if (rc == SGL_OK) rc = ensure_mask_cache(c, seed, inv_density);
-        if (rc == SGL_OK) rc = k_mse_test(c, Wd, c->H, k, seed, inv_density, c->scalars + 1, c->mask_valid ? c->mask_p[0] : nullptr,
-                                          c->mask_valid ? c->mask_i[0] : nullptr);
+        if (rc == SGL_OK) rc = k_mse_test(c, Wd, c->H, k, seed, inv_density, c->scalars + 1);
     }
     if (rc == SGL_OK) rc = do_allreduce(c, c->scalars + 1, 1);
     if (rc == SGL_OK) {

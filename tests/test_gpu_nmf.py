@@ -358,20 +358,3 @@ def test_callbacks_log_poll_and_verbose(sa, ora, ctx, capsys):
     # iter_ % trace_test_mse == 0 is traced (src/singlet.cpp:1116): iterations 1 and 3 print a score, 2 prints "-"
     assert out[1] == "%4s | %8s | %8s " % ("iter", "tol", "overfit")
     assert out[3].endswith("| 0.00e+00") and out[4].endswith("|        -") and "e" in out[5].split("|")[2]
-
-
-def test_mask_cache_equals_hashing(sa, ora, monkeypatch):
-    """The listed mask (built once per fit) and the per-iteration hashing are two routes to the same
-    cross-validation mask: same trace lengths, test errors to the last bits (mse_test keeps its
-    summation order), factors to rounding (the Gram downdate groups the rows differently)."""
-    A = ora.synth_csc(300, 350, 20)
-    At = A.t()
-    w0 = ora.synth_winit(12, 300)
-    args = (to_dgc(sa, A), to_dgc(sa, At), 0.0, 5, False, 0.01, 0.0, 0, w0.T, 1234, 10, 1e9, 2)
-    monkeypatch.delenv("SGL_NO_MASK_CACHE", raising=False)
-    a = sa.c_ard_nmf(*args)
-    monkeypatch.setenv("SGL_NO_MASK_CACHE", "1")
-    b = sa.c_ard_nmf(*args)
-    assert np.array_equal(a["iter"], b["iter"])
-    assert np.allclose(a["test_mse"], b["test_mse"], rtol=1e-12, atol=0)
-    assert rel_fro(a["w"], b["w"]) < 1e-11 and rel_fro(a["h"], b["h"]) < 1e-11
