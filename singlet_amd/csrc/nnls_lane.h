@@ -13,6 +13,9 @@
 #pragma once
 #include "sgl_internal.h"
 // a wave leaves a pass when fewer than NUM / DEN of the lanes it started with are still iterating
+#ifndef SGL_NNLS_WPE
+#define SGL_NNLS_WPE 2   // minimum waves per SIMD the register allocation must allow
+#endif
 #ifndef SGL_NNLS_REPACK_NUM
 #define SGL_NNLS_REPACK_NUM 3
 #define SGL_NNLS_REPACK_DEN 8
@@ -53,7 +56,7 @@ __device__ __forceinline__ double nnls_dpp_bcast(double g) {
 // per-launch scratch xt[i * xt_stride + position] (coalesced over the lanes) and is read PF coordinates
 // ahead; b stays in VGPRs.
 template <int KP, bool GV, bool XM = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void nnls_lane_kernel(const double* __restrict__ Gpad, double* __restrict__ B,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SGL_NNLS_WPE))) void nnls_lane_kernel(const double* __restrict__ Gpad, double* __restrict__ B,
                                                         double* __restrict__ X, const int64_t* __restrict__ col_nnz,
                                                         int k, int64_t ncols, double L1, double L2,
                                                         unsigned long long* __restrict__ sweep_counter, NnlsPass ps) {
