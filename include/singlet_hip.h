@@ -102,6 +102,18 @@ SGL_API int sgl_c_ard_nmf(const double* Ax, const int32_t* Ai, const int32_t* Ap
                   double* test_mse, int32_t* iter, double* tol_out, double* score_overfit, int32_t* n_trace,
                   const sgl_callbacks* cb);
 
+/* c_nmf_dense (src/singlet.cpp:1052-1054; dense predict :370-381), the branch
+ * R/run_nmf.R:57 takes for a dense matrix.  Replaces _singlet_c_nmf_dense
+ * (11 args; At is not needed).  A: nrow x ncol column-major doubles.  Unlike the
+ * sparse path, all-zero columns are solved too (the dense predict has no
+ * empty-column skip). */
+SGL_API int sgl_c_nmf_dense(const double* A, int32_t nrow, int32_t ncol,
+                    double tol, uint16_t maxit, int verbose,
+                    double L1_w, double L1_h, double L2_w, double L2_h, uint16_t threads,
+                    const double* w_init, int32_t k,
+                    double* w_out, double* d_out, double* h_out,
+                    int32_t* n_iter, double* tol_trace, const sgl_callbacks* cb);
+
 /* c_linked_nmf (src/singlet.cpp:1059-1086; predict_link :416-433), the linked
  * NMF behind R/RunLNMF.R:60.  Replaces _singlet_c_linked_nmf (11 args).  link_h
  * (link_h_rows x link_h_cols, column-major) multiplies the first link_h_rows

@@ -63,6 +63,9 @@ def lib():
         L.ora_c_nmf.restype = C.c_int
         L.ora_c_nmf.argtypes = csc + csc + [C.c_int32, C.c_int32, C.c_double, C.c_int] + [C.c_double] * 4 + [
             C.c_int, C.c_int, _f64p, _f64p, _f64p, _f64p, _f64p, _i64p]
+        L.ora_c_nmf_dense.restype = C.c_int
+        L.ora_c_nmf_dense.argtypes = [_f64p, _f64p, C.c_int32, C.c_int32, C.c_double, C.c_int] + [C.c_double] * 4 + [
+            C.c_int, C.c_int, _f64p, _f64p, _f64p, _f64p]
         L.ora_c_linked_nmf.restype = C.c_int
         L.ora_c_linked_nmf.argtypes = csc + csc + [C.c_int32, C.c_int32, C.c_double, C.c_int, C.c_double, C.c_double,
                                                    C.c_int, C.c_int, _f64p, _f64p, C.c_int32, C.c_int32, _f64p,
@@ -247,6 +250,22 @@ def c_project_model(A, w, L1, L2, threads=0):
     lib().ora_c_project_model(*pa, A.nrow, A.ncol, _p(wf, _f64p), w_rows, w_cols, L1, L2, threads, _p(h, _f64p),
                               _p(d, _f64p))
     return dict(h=h, d=d)
+
+
+def c_nmf_dense(A, tol, maxit, L1_w, L1_h, L2_w, L2_h, threads, w):
+    """c_nmf_dense (src/singlet.cpp:1052-1054).  A: dense (m, n) array; w: (m, k) (== k x m column-major)."""
+    A = np.asarray(A, dtype=np.float64)
+    m, n = A.shape
+    Af = np.ascontiguousarray(A.T)      # column-major image of A
+    Atf = np.ascontiguousarray(A)       # column-major image of t(A)
+    w = np.array(w, dtype=np.float64, order="C")
+    k = w.shape[1]
+    h = np.empty((n, k))
+    d = np.empty(k)
+    tr = np.zeros(max(int(maxit), 1))
+    it = lib().ora_c_nmf_dense(_p(Af, _f64p), _p(Atf, _f64p), m, n, tol, int(maxit), L1_w, L1_h, L2_w, L2_h, threads, k,
+                               _p(w, _f64p), _p(h, _f64p), _p(d, _f64p), _p(tr, _f64p))
+    return dict(w=w, d=d, h=h, iter=it, tol=tr[:it].copy())
 
 
 def c_linked_nmf(A, At, tol, maxit, L1, L2, threads, w, link_h, link_w):

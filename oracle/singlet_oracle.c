@@ -390,6 +390,49 @@ ORA_API int ora_c_nmf(const double* Ax, const int32_t* Ai, const int32_t* Ap, co
     return iter_;
 }
 
+/* predict for a dense matrix -- src/singlet.cpp:370-381: EVERY column is solved (no empty-column skip),
+ * b = w * A.col(i) summed over all rows in order (zeros add exact zeros).  A: rows x cols column-major. */
+static void predict_dense(const double* A, int64_t rows, int64_t cols, const double* F, double* X, int k, double L1,
+                          double L2, int threads) {
+    double* a = (double*)malloc(sizeof(double) * k * k);
+    ora_aat(F, k, rows, a);
+#pragma omp parallel for num_threads(pick_threads(threads))
+    for (int64_t c = 0; c < cols; ++c) {
+        double b[k];
+        for (int j = 0; j < k; ++j) b[j] = 0.0;
+        for (int64_t r = 0; r < rows; ++r) {
+            const double v = A[(size_t)c * rows + r];
+            const double* f = F + (size_t)r * k;
+            for (int j = 0; j < k; ++j) b[j] += v * f[j];
+        }
+        nnls_col(a, b, X + (size_t)c * k, k, L1, L2);
+    }
+    free(a);
+}
+
+/* c_nmf_dense -- src/singlet.cpp:1052-1054 (c_nmf_base on Eigen::MatrixXd, predict :370-381).
+ * A: m x n column-major, At: n x m column-major. */
+ORA_API int ora_c_nmf_dense(const double* A, const double* At, int32_t m, int32_t n, double tol, int maxit, double L1_w,
+                            double L1_h, double L2_w, double L2_h, int threads, int k, double* w, double* h, double* d,
+                            double* tol_trace) {
+    memset(h, 0, sizeof(double) * (size_t)k * (size_t)n);
+    for (int i = 0; i < k; ++i) d[i] = 1.0;
+    double tol_ = 1;
+    double* w_it = (double*)malloc(sizeof(double) * (size_t)k * (size_t)m);
+    int iter_ = 0;
+    for (; iter_ < maxit && tol_ > tol; ++iter_) {
+        memcpy(w_it, w, sizeof(double) * (size_t)k * (size_t)m);
+        predict_dense(A, m, n, w, h, k, L1_h, L2_h, threads);
+        ora_scale(h, k, n, d);
+        predict_dense(At, n, m, h, w, k, L1_w, L2_w, threads);
+        ora_scale(w, k, m, d);
+        tol_ = ora_cor(w, w_it, (size_t)k * (size_t)m);
+        if (tol_trace) tol_trace[iter_] = tol_;
+    }
+    free(w_it);
+    return iter_;
+}
+
 /* c_linked_nmf -- src/singlet.cpp:1059-1086.  link_h is link_h_rows x link_h_cols (column-major);
  * it is applied iff link_h_cols == ncol(A) (l.1064), likewise link_w iff link_w_cols == nrow(A)
  * (l.1065).  Returns the number of iterations run. */

@@ -48,6 +48,8 @@ SIGNATURES = {
                                               C.c_double, C.c_uint16, f64p, C.c_int32, C.c_uint64, C.c_uint64,
                                               C.c_double, C.c_uint16, f64p, f64p, f64p, f64p, i32p, f64p, f64p, i32p,
                                               _CB]),
+    "sgl_c_nmf_dense": (C.c_int, [f64p, C.c_int32, C.c_int32, C.c_double, C.c_uint16, C.c_int, C.c_double, C.c_double,
+                                  C.c_double, C.c_double, C.c_uint16, f64p, C.c_int32, f64p, f64p, f64p, i32p, f64p, _CB]),
     "sgl_c_linked_nmf": (C.c_int, _CSC + _CSC + [C.c_int32, C.c_int32, C.c_double, C.c_uint16, C.c_int, C.c_double,
                                                  C.c_double, C.c_uint16, f64p, C.c_int32, f64p, C.c_int32, C.c_int32, f64p,
                                                  C.c_int32, C.c_int32, f64p, f64p, f64p, i32p, f64p, _CB]),

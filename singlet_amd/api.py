@@ -73,6 +73,46 @@ def c_nmf(A, At, tol, maxit, verbose, L1_w, L1_h, L2_w, L2_h, threads, w):
     return {"w": w_out.T, "d": d_out, "h": h_out.T, "iter": n_iter.value, "tol": tr[:n_iter.value].copy()}
 
 
+def c_nmf_dense(A, At, tol, maxit, verbose, L1_w, L1_h, L2_w, L2_h, threads, w):
+    """.Call(`_singlet_c_nmf_dense`, ...) -> list(w, d, h)  (src/singlet.cpp:1052-1054).  A: dense m x n
+    array; At is accepted for signature parity and ignored (the transpose is built on the device)."""
+    L = _lib.load()
+    A = np.asarray(A, dtype=np.float64)
+    if A.ndim != 2:
+        raise ValueError("A must be a matrix")
+    m, n = A.shape
+    Af = np.ascontiguousarray(A.T)   # column-major image
+    wb = _w_in(w, m)
+    k = wb.shape[1]
+    w_out, h_out, d_out = np.empty((m, k)), np.empty((n, k)), np.empty(k)
+    n_iter = C.c_int32()
+    tr = np.zeros(max(int(maxit), 1))
+    cb = make_callbacks(_verbose_log(verbose))
+    check(L.sgl_c_nmf_dense(ptr(Af, f64p), m, n, float(tol), int(maxit), int(bool(verbose)), L1_w, L1_h, L2_w, L2_h,
+                            int(threads), ptr(wb, f64p), k, ptr(w_out, f64p), ptr(d_out, f64p), ptr(h_out, f64p),
+                            C.byref(n_iter), ptr(tr, f64p), C.byref(cb)))
+    return {"w": w_out.T, "d": d_out, "h": h_out.T, "iter": n_iter.value, "tol": tr[:n_iter.value].copy()}
+
+
+def c_nmf_sparse_list(A_, At_, tol, maxit, verbose, L1, L2, threads, w):
+    """.Call(`_singlet_c_nmf_sparse_list`, ...)  (src/singlet.cpp:715-743): A_ is a list of column chunks
+    of A (the predict over chunks carries a running column offset, :384-402), At_ a list of column
+    chunks of t(A).  The chunks are concatenated on the host and run as one matrix: same sums, same
+    solves, same order."""
+    chunks = [as_dgCMatrix(a) for a in A_]
+    if not chunks:
+        raise ValueError("A_ must hold at least one matrix")
+    nrow = chunks[0].nrow
+    if any(a.nrow != nrow for a in chunks):
+        raise ValueError("all chunks of A_ must have the same number of rows")
+    x = np.concatenate([a.x for a in chunks])
+    i = np.concatenate([a.i for a in chunks])
+    off = np.cumsum([0] + [a.nnz for a in chunks[:-1]])
+    p = np.concatenate([chunks[0].p[:1]] + [a.p[1:] + o for a, o in zip(chunks, off)])
+    A = dgCMatrix(x, i, p, (nrow, sum(a.ncol for a in chunks)))
+    return c_nmf(A, None, tol, maxit, verbose, L1, L1, L2, L2, threads, w)
+
+
 def c_linked_nmf(A, At, tol, maxit, verbose, L1, L2, threads, w, link_h, link_w):
     """.Call(`_singlet_c_linked_nmf`, ...) -> list(w, d, h)  (src/singlet.cpp:1059-1086).  link_h / link_w
     are R matrices (rows x cols); a link whose column count does not match its side is ignored, as in
@@ -191,13 +231,19 @@ def _sort_model(model, rn=None, cn=None):
 def run_nmf(A, rank, tol=1e-4, maxit=100, verbose=True, L1=0.01, L2=0, threads=0, seed=None):
     """R/run_nmf.R:18-77 (sparse, single-matrix branch).  `seed` replaces R's global RNG state
     (stats::runif, l.55): an int or numpy Generator."""
-    A = as_dgCMatrix(A)
-    if verbose:
-        print("running with sparse optimization")
+    dense_mode = isinstance(A, np.ndarray)   # R/run_nmf.R:41-46: a base matrix stays dense
+    if not dense_mode:
+        A = as_dgCMatrix(A)
+        if verbose:
+            print("running with sparse optimization")
     L1 = _pair(L1)
     L2 = _pair(L2)
+    nrow = A.shape[0] if dense_mode else A.nrow
     # w_init <- matrix(stats::runif(nrow(A) * rank), rank, nrow(A))
-    w_init = _rng(seed).random((A.nrow, rank)).T
+    w_init = _rng(seed).random((nrow, rank)).T
+    if dense_mode:
+        model = c_nmf_dense(A, None, tol, maxit, bool(verbose), L1[0], L1[1], L2[0], L2[1], threads, w_init)
+        return _sort_model(model, None, None)
     model = c_nmf(A, None, tol, maxit, bool(verbose), L1[0], L1[1], L2[0], L2[1], threads, w_init)
     return _sort_model(model, A.Dimnames[0], A.Dimnames[1])
 

@@ -104,6 +104,7 @@ struct sgl_ctx {
     double* G = nullptr;    // k x k Gram (+1e-15 diagonal)
     double* Gpad = nullptr; // KP x KP zero-padded copy for the lane NNLS kernel
     NnlsScratch nnls_scr;   // lists / per-column state of the multi-pass lane NNLS
+    bool solve_empty = false;  // dense front-end (src/singlet.cpp:370-381): no empty-column skip
     double* link_h = nullptr;  // c_linked_nmf: link_rows x ncol / x nrow multipliers of the right-hand sides
     double* link_w = nullptr;
     int link_h_rows = 0, link_w_rows = 0;

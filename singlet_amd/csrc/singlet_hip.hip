@@ -540,7 +540,7 @@ extern "C" int sgl_step_h(sgl_ctx* c, double L1, double L2) {
       else SGLCHK(k_acc(c->stream, c->A, c->W, k, c->B, 0, 1, 0, 0, 0));
       if (c->link_h) SGLCHK(k_link_mul(c->stream, c->B, c->link_h, k, c->link_h_rows, c->A.ncol)); }  // predict_link l.429-430
     { Phase ph(c, SGL_PH_NNLS_H);
-      SGLCHK(nnls_shared(c, c->G, c->B, c->H, c->col_nnz_A, c->A.ncol, L1, L2, c->sweep_counters + 0)); }
+      SGLCHK(nnls_shared(c, c->G, c->B, c->H, c->solve_empty ? nullptr : c->col_nnz_A, c->A.ncol, L1, L2, c->sweep_counters + 0)); }
     return SGL_OK;
 }
 
@@ -572,7 +572,7 @@ extern "C" int sgl_step_w(sgl_ctx* c, double L1, double L2) {
       SGLCHK(k_gram_add_diag(c->stream, c->G, k, 1e-15)); }
     { Phase ph(c, SGL_PH_NNLS_W);
       if (c->link_w) SGLCHK(k_link_mul(c->stream, Bw, c->link_w, k, c->link_w_rows, m));  // on the complete (all-reduced) sums
-      SGLCHK(nnls_shared(c, c->G, Bw, c->W, c->col_nnz_At, m, L1, L2, c->sweep_counters + 1)); }
+      SGLCHK(nnls_shared(c, c->G, Bw, c->W, c->solve_empty ? nullptr : c->col_nnz_At, m, L1, L2, c->sweep_counters + 1)); }
     return SGL_OK;
 }
 
@@ -838,6 +838,35 @@ extern "C" int sgl_c_linked_nmf(const double* Ax, const int32_t* Ai, const int32
     SGLCHK(sgl_fit_init(hd.c, k, w_init, 0));
     SGLCHK(sgl_set_links(hd.c, link_h, link_h_rows, link_h_cols, link_w, link_w_rows, link_w_cols));
     SGLCHK(sgl_nmf_run(hd.c, tol, maxit, L1, L1, L2, L2, n_iter, tol_trace, cb));
+    return sgl_get_factors(hd.c, w_out, d_out, h_out);
+}
+
+// c_nmf_dense (src/singlet.cpp:1052-1054): a dense matrix runs through the same kernels as its CSC image
+// (zeros add exact zeros to the right-hand sides); the one semantic difference of the dense predict
+// (:370-381) is that it solves EVERY column, all-zero ones included.
+extern "C" int sgl_c_nmf_dense(const double* A, int32_t nrow, int32_t ncol, double tol, uint16_t maxit, int verbose,
+                               double L1_w, double L1_h, double L2_w, double L2_h, uint16_t threads, const double* w_init,
+                               int32_t k, double* w_out, double* d_out, double* h_out, int32_t* n_iter, double* tol_trace,
+                               const sgl_callbacks* cb) {
+    (void)verbose; (void)threads;
+    if (!A || !w_init || !w_out || !d_out || !h_out || nrow <= 0 || ncol <= 0) { sgl_set_error("sgl_c_nmf_dense: bad arguments"); return SGL_EINVAL; }
+    std::vector<double> x;
+    std::vector<int32_t> idx, p((size_t)ncol + 1, 0);
+    for (int64_t c = 0; c < ncol; ++c) {
+        for (int64_t r = 0; r < nrow; ++r) {
+            const double v = A[(size_t)c * nrow + r];
+            if (v != 0.0) { x.push_back(v); idx.push_back((int32_t)r); }
+        }
+        if (x.size() > (size_t)INT32_MAX) { sgl_set_error("sgl_c_nmf_dense: more than 2^31 non-zeros"); return SGL_EINVAL; }
+        p[(size_t)c + 1] = (int32_t)x.size();
+    }
+    if (x.empty()) { x.push_back(0.0); idx.push_back(0); }  // keep the slot pointers valid for an all-zero matrix
+    CtxHolder hd;
+    SGLCHK(sgl_create(current_device_or_zero(), &hd.c));
+    SGLCHK(sgl_upload_csc(hd.c, x.data(), idx.data(), p.data(), nullptr, nullptr, nullptr, nrow, ncol, 0, ncol));
+    SGLCHK(sgl_fit_init(hd.c, k, w_init, 0));
+    hd.c->solve_empty = true;
+    SGLCHK(sgl_nmf_run(hd.c, tol, maxit, L1_w, L1_h, L2_w, L2_h, n_iter, tol_trace, cb));
     return sgl_get_factors(hd.c, w_out, d_out, h_out);
 }
 

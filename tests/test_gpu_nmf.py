@@ -358,3 +358,34 @@ def test_callbacks_log_poll_and_verbose(sa, ora, ctx, capsys):
     # iter_ % trace_test_mse == 0 is traced (src/singlet.cpp:1116): iterations 1 and 3 print a score, 2 prints "-"
     assert out[1] == "%4s | %8s | %8s " % ("iter", "tol", "overfit")
     assert out[3].endswith("| 0.00e+00") and out[4].endswith("|        -") and "e" in out[5].split("|")[2]
+
+
+def test_c_nmf_dense_and_sparse_list(sa, ora):
+    """The dense front-end (src/singlet.cpp:1052-1054, predict :370-381) solves every column, all-zero
+    ones included -- unlike the sparse path, which skips them; the chunk-list front-end (:715-743) equals
+    c_nmf on the concatenated matrix."""
+    m, n, k = 180, 230, 7
+    A = ora.synth_csc(m, n, 12)
+    D = np.zeros((m, n))
+    for c in range(n):
+        D[A.i[A.p[c]:A.p[c + 1]], c] = A.x[A.p[c]:A.p[c + 1]]
+    D[:, [5, 77]] = 0.0      # empty cells
+    D[[3, 100], :] = 0.0     # empty genes
+    w0 = ora.synth_winit(k, m)
+    ref = ora.c_nmf_dense(D, 0.0, 4, 0.01, 0.01, 0.0, 0.0, 0, w0)
+    got = sa.c_nmf_dense(D, None, 0.0, 4, False, 0.01, 0.01, 0.0, 0.0, 0, w0.T)
+    _check(got, ref)
+    # the sparse path on the same data keeps the stale (zero-initialised h / initial w) values instead
+    import scipy.sparse as sp
+    S = sp.csc_matrix(D)
+    dS = sa.dgCMatrix(S.data, S.indices, S.indptr, (m, n))
+    sparse = sa.c_nmf(dS, None, 0.0, 4, False, 0.01, 0.01, 0.0, 0.0, 0, w0.T)
+    assert not np.array_equal(sparse["w"][:, 3], got["w"][:, 3])
+    # chunk list: three ragged column chunks of A (and of t(A), accepted and unused)
+    cuts = [0, 60, 61, n]
+    chunks = [dS.col_slice(a, b) for a, b in zip(cuts, cuts[1:])]
+    lst = sa.c_nmf_sparse_list(chunks, None, 0.0, 4, False, 0.01, 0.0, 0, w0.T)
+    assert np.array_equal(lst["w"], sparse["w"]) and np.array_equal(lst["h"], sparse["h"]) and np.array_equal(lst["d"], sparse["d"])
+    # run_nmf takes the dense branch for a plain array (R/run_nmf.R:57)
+    fit = sa.run_nmf(D, 5, tol=1e-3, maxit=5, verbose=False, seed=3)
+    assert fit["w"].shape == (m, 5) and np.all(np.diff(fit["d"]) <= 0)

@@ -147,6 +147,22 @@ def test_c_linked_nmf_oracle(ora):
     assert np.all(r2["h"][lh.T == 0] == 0) and not np.array_equal(r2["h"], r0["h"])
 
 
+def test_c_nmf_dense_oracle(ora):
+    """Dense front-end: equals the sparse loop bit for bit when no column is empty; an all-zero column is
+    still solved (src/singlet.cpp:370-381 has no skip), which the sparse loop would leave untouched."""
+    A = ora.synth_csc(60, 50, 6)
+    D = np.zeros((60, 50))
+    for c in range(50):
+        D[A.i[A.p[c]:A.p[c + 1]], c] = A.x[A.p[c]:A.p[c + 1]]
+    w0 = ora.synth_winit(4, 60)
+    r0 = ora.c_nmf(A, A.t(), 0.0, 3, 0.01, 0.01, 0.0, 0.0, 0, w0)
+    r1 = ora.c_nmf_dense(D, 0.0, 3, 0.01, 0.01, 0.0, 0.0, 0, w0)
+    assert np.array_equal(r0["w"], r1["w"]) and np.array_equal(r0["h"], r1["h"])
+    D[7, :] = 0.0     # gene 7 never expressed: its w column is clamped by the L1 step instead of kept
+    r2 = ora.c_nmf_dense(D, 0.0, 3, 0.01, 0.01, 0.0, 0.0, 0, w0)
+    assert np.all(r2["w"][7] == 0.0)
+
+
 def test_nnls_quirks(ora):
     """SURVEY.md 8a quirks 2-5 on hand-made cases."""
     G = np.array([[2.0, 0.5], [0.5, 1.0]])
