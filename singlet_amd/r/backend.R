@@ -20,6 +20,8 @@ singlet_hip_enable <- function(shim = Sys.getenv("SINGLET_HIP_SHIM", "singlet_hi
           overfit_threshold, trace_test_mse))
   rebind("c_linked_nmf", function(A, At, tol, maxit, verbose, L1, L2, threads, w, link_h, link_w)
     .Call(dll[["_singlet_c_linked_nmf"]], A, At, tol, maxit, verbose, L1, L2, threads, w, link_h, link_w))
+  rebind("c_nmf_dense", function(A, At, tol, maxit, verbose, L1_w, L1_h, L2_w, L2_h, threads, w)
+    .Call(dll[["_singlet_c_nmf_dense"]], A, At, tol, maxit, verbose, L1_w, L1_h, L2_w, L2_h, threads, w))
   rebind("c_project_model", function(A, w, L1, L2, threads)
     .Call(dll[["_singlet_c_project_model"]], A, w, L1, L2, threads))
   rebind("Rcpp_predict", function(A, w, L1, L2, threads)

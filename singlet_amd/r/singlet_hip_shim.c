@@ -183,6 +183,33 @@ SEXP _singlet_c_linked_nmf(SEXP A_, SEXP At_, SEXP tol_, SEXP maxit_, SEXP verbo
     return out;
 }
 
+/* ---- c_nmf_dense(A, At, tol, maxit, verbose, L1_w, L1_h, L2_w, L2_h, threads, w) ---- *
+ * (src/singlet.cpp:1052-1054; R/run_nmf.R:57).  A is a base numeric matrix; At is not needed. */
+SEXP _singlet_c_nmf_dense(SEXP A_, SEXP At_, SEXP tol_, SEXP maxit_, SEXP verbose_, SEXP L1w_, SEXP L1h_, SEXP L2w_, SEXP L2h_,
+                          SEXP threads_, SEXP w_) {
+    (void)At_;
+    if (!Rf_isMatrix(A_) || TYPEOF(A_) != REALSXP) Rf_error("A must be a numeric matrix");
+    if (!Rf_isMatrix(w_) || TYPEOF(w_) != REALSXP) Rf_error("w must be a numeric matrix");
+    const int m = Rf_nrows(A_), n = Rf_ncols(A_), k = Rf_nrows(w_);
+    if (Rf_ncols(w_) != m) Rf_error("w must be k x nrow(A)");
+    const int verbose = Rf_asLogical(verbose_);
+    SEXP w = PROTECT(Rf_allocMatrix(REALSXP, k, m)), d = PROTECT(Rf_allocVector(REALSXP, k)),
+         h = PROTECT(Rf_allocMatrix(REALSXP, k, n));
+    sgl_callbacks cb = {NULL, verbose ? log_nmf : NULL, poll_cb};
+    if (verbose) Rprintf("\n%4s | %8s \n---------------\n", "iter", "tol");
+    int n_iter = 0;
+    int rc = sgl_c_nmf_dense(REAL(A_), m, n, Rf_asReal(tol_), (uint16_t)Rf_asInteger(maxit_), verbose, Rf_asReal(L1w_),
+                             Rf_asReal(L1h_), Rf_asReal(L2w_), Rf_asReal(L2h_), (uint16_t)Rf_asInteger(threads_), REAL(w_), k,
+                             REAL(w), REAL(d), REAL(h), &n_iter, NULL, &cb);
+    if (rc == SGL_EINTR) { UNPROTECT(3); Rf_onintr(); }
+    fail_if(rc);
+    const char* names[3] = {"w", "d", "h"};
+    SEXP vals[3] = {w, d, h};
+    SEXP out = named_list(3, names, vals);
+    UNPROTECT(3);
+    return out;
+}
+
 /* ---- c_project_model(A, w, L1, L2, threads) -> list(h, d) ---------------- */
 SEXP _singlet_c_project_model(SEXP A_, SEXP w_, SEXP L1_, SEXP L2_, SEXP threads_) {
     dgc_view A = view_dgc(A_, "A");
@@ -220,6 +247,7 @@ static const R_CallMethodDef call_entries[] = {
     {"_singlet_c_nmf", (DL_FUNC)&_singlet_c_nmf, 11},
     {"_singlet_c_ard_nmf", (DL_FUNC)&_singlet_c_ard_nmf, 13},
     {"_singlet_c_linked_nmf", (DL_FUNC)&_singlet_c_linked_nmf, 11},
+    {"_singlet_c_nmf_dense", (DL_FUNC)&_singlet_c_nmf_dense, 11},
     {"_singlet_c_project_model", (DL_FUNC)&_singlet_c_project_model, 5},
     {"_singlet_Rcpp_predict", (DL_FUNC)&_singlet_Rcpp_predict, 5},
     {NULL, NULL, 0}};
