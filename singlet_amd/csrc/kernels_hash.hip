@@ -202,3 +202,30 @@ int k_build_segments(hipStream_t s, const DevCSC& M) {
     HIPCHK(hipGetLastError());
     return SGL_OK;
 }
+
+// dgCMatrix invariants the kernels rely on (a wrong row index would read or write out of bounds): row
+// indices inside [0, nrow) and strictly ascending within a column.  flag |= 1 / 2.
+__global__ __launch_bounds__(256) void validate_csc_kernel(const int32_t* __restrict__ idx, const int64_t* __restrict__ p,
+                                                           int64_t ncol, int32_t nrow, int* __restrict__ flag) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    int bad = 0;
+    for (int64_t c = wave; c < ncol; c += nwaves) {
+        const int64_t lo = p[c], hi = p[c + 1];
+        for (int64_t e = lo + lane; e < hi; e += 64) {
+            const int32_t r = idx[e];
+            if (r < 0 || r >= nrow) bad |= 1;
+            if (e > lo && idx[e - 1] >= r) bad |= 2;
+        }
+    }
+    if (bad) atomicOr(flag, bad);
+}
+
+int k_validate_csc(hipStream_t s, const int32_t* idx, const int64_t* p, int64_t ncol, int32_t nrow, int* flag_dev) {
+    if (ncol <= 0) return SGL_OK;
+    HIPCHK(hipMemsetAsync(flag_dev, 0, sizeof(int), s));
+    validate_csc_kernel<<<dim3(wave_grid(ncol)), dim3(256), 0, s>>>(idx, p, ncol, nrow, flag_dev);
+    HIPCHK(hipGetLastError());
+    return SGL_OK;
+}

@@ -249,6 +249,8 @@ static int upload_one(sgl_ctx* c, DevCSC& M, const double* x, const int32_t* i, 
                       int32_t ncol) {
     const int64_t nnz = (int64_t)p[ncol];
     if (p[0] != 0 || nnz < 0) { sgl_set_error("invalid column pointer array (p[0]=%d, p[ncol]=%lld)", p[0], (long long)nnz); return SGL_EINVAL; }
+    for (int32_t q = 0; q < ncol; ++q)
+        if (p[q + 1] < p[q]) { sgl_set_error("invalid column pointer array: p decreases at column %d", q); return SGL_EINVAL; }
     M.nrow = nrow;
     M.ncol = ncol;
     M.nnz = nnz;
@@ -261,8 +263,17 @@ static int upload_one(sgl_ctx* c, DevCSC& M, const double* x, const int32_t* i, 
     SGLCHK(dev_alloc(&p32, (size_t)ncol + 1));
     HIPCHK(hipMemcpyAsync(p32, p, sizeof(int32_t) * ((size_t)ncol + 1), hipMemcpyHostToDevice, c->stream));
     int rc = k_widen_p(c->stream, p32, (int64_t)ncol + 1, M.p);
+    // the kernels index factor rows by these values: refuse anything that is not a valid dgCMatrix
+    int flag = 0;
+    if (rc == SGL_OK) rc = k_validate_csc(c->stream, M.i, M.p, ncol, nrow, reinterpret_cast<int*>(p32));
+    if (rc == SGL_OK && hipMemcpyAsync(&flag, p32, sizeof(int), hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = SGL_EHIP;
     HIPCHK(hipStreamSynchronize(c->stream));
     dev_free(p32);
+    if (rc == SGL_OK && flag != 0) {
+        sgl_set_error("not a valid dgCMatrix: %s%s", (flag & 1) ? "row index outside [0, nrow) " : "",
+                      (flag & 2) ? "row indices not strictly ascending within a column" : "");
+        return SGL_EINVAL;
+    }
     return rc;
 }
 

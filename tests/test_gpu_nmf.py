@@ -389,3 +389,37 @@ def test_c_nmf_dense_and_sparse_list(sa, ora):
     # run_nmf takes the dense branch for a plain array (R/run_nmf.R:57)
     fit = sa.run_nmf(D, 5, tol=1e-3, maxit=5, verbose=False, seed=3)
     assert fit["w"].shape == (m, 5) and np.all(np.diff(fit["d"]) <= 0)
+
+
+def test_edge_arguments(sa, ora, ctx):
+    """maxit = 0 runs no iteration (w returned as given, h = 0, d = 1, src/singlet.cpp:639-647); bad
+    arguments come back as errors from the library, not as crashes."""
+    A = ora.synth_csc(120, 90, 10)
+    w0 = ora.synth_winit(5, 120)
+    got = sa.c_nmf(to_dgc(sa, A), None, 0.0, 0, False, 0.01, 0.01, 0.0, 0.0, 0, w0.T)
+    assert got["iter"] == 0 and np.array_equal(got["w"].T, w0) and not got["h"].any() and np.array_equal(got["d"], np.ones(5))
+    # tol larger than the first change stops after one iteration, like the reference's loop test
+    one = sa.c_nmf(to_dgc(sa, A), None, 2.0, 10, False, 0.01, 0.01, 0.0, 0.0, 0, w0.T)
+    ref = ora.c_nmf(A, A.t(), 2.0, 10, 0.01, 0.01, 0.0, 0.0, 0, w0)
+    assert one["iter"] == ref["iter"] == 0 or one["iter"] == ref["iter"]
+    ctx.upload(to_dgc(sa, A), None)
+    with pytest.raises(sa.SingletHipError):
+        ctx.fit_init(0, None)
+    with pytest.raises(sa.SingletHipError):
+        ctx.fit_init(300, None)                       # above SGL_MAX_K
+    ctx.fit_init(5, w0)
+    with pytest.raises(sa.SingletHipError):
+        ctx.ard_run(0.0, 3, 0.01, 0.0, 1, 0, 1e9, 1)  # inv_density = 0
+    with pytest.raises(sa.SingletHipError):
+        ctx.ard_run(0.0, 3, 0.01, 0.0, 1, 20, 1e9, 0)  # trace_test_mse = 0 would divide by zero (never passed by R)
+    bad = sa.dgCMatrix(A.x, A.i, A.p, (A.nrow, A.ncol))
+    bad.i = bad.i.copy()
+    bad.i[0] = A.nrow + 5                              # row index out of range
+    with pytest.raises(sa.SingletHipError):
+        sa.c_nmf(bad, None, 0.0, 1, False, 0.0, 0.0, 0.0, 0.0, 0, w0.T)
+    bad.i = A.i.copy()
+    s0, s1 = A.p[0], A.p[1]
+    assert s1 - s0 >= 2
+    bad.i[s0], bad.i[s0 + 1] = A.i[s0 + 1], A.i[s0]    # not ascending inside the first column
+    with pytest.raises(sa.SingletHipError):
+        sa.c_nmf(bad, None, 0.0, 1, False, 0.0, 0.0, 0.0, 0.0, 0, w0.T)
