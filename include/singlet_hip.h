@@ -47,7 +47,7 @@ extern "C" {
 
 SGL_API const char* sgl_last_error(void);
 /* ABI version of this header; bumped on any signature change. */
-SGL_API int sgl_abi_version(void);
+SGL_API int sgl_abi_version(void);   /* 2: native multi-GPU section, sgl_nmf_iterate, chunk-list / dense ARD entry points */
 /* Number of usable gfx950 devices (0 if none); never fails. */
 SGL_API int sgl_device_count(void);
 
@@ -90,7 +90,8 @@ SGL_API int sgl_c_nmf(const double* Ax, const int32_t* Ai, const int32_t* Ap,
  * Replaces _singlet_c_ard_nmf (src/RcppExports.cpp:284-304).
  * Trace arrays (test_mse, iter, tol, score_overfit) must hold maxit + 1
  * entries; *n_trace receives their used length (the reference returns them as
- * R vectors, src/singlet.cpp:1144-1151). */
+ * R vectors, src/singlet.cpp:1144-1151).  The masked path supports ranks k <= 128
+ * (SGL_EINVAL above, before anything is uploaded). */
 SGL_API int sgl_c_ard_nmf(const double* Ax, const int32_t* Ai, const int32_t* Ap,
                   const double* Atx, const int32_t* Ati, const int32_t* Atp,
                   int32_t nrow, int32_t ncol,
@@ -215,6 +216,9 @@ SGL_API int sgl_set_links(sgl_ctx* ctx, const double* link_h, int32_t link_h_row
  * the hook must have completed its writes when it returns.  NULL = one shard. */
 typedef int (*sgl_allreduce_fn)(void* user, void* dev_ptr, int64_t count);
 SGL_API int sgl_set_allreduce(sgl_ctx* ctx, sgl_allreduce_fn fn, void* user);
+/* The hook may be installed or cleared at any time, before or after sgl_fit_init: what depends on it
+ * (the per-gene non-zero counts over all shards, which decide the W columns predict() skips,
+ * src/singlet.cpp:340) is rebuilt through the new hook at the next W-update. */
 
 /* Step-level operators (what c_nmf_base's loop body is made of).  A sharded
  * host runs them in this order per iteration; sgl_nmf_run does the same
@@ -246,6 +250,50 @@ SGL_API int sgl_project_run(sgl_ctx* ctx, double L1, double L2);
 SGL_API int sgl_get_factors(sgl_ctx* ctx, double* w, double* d, double* h);
 /* Overwrite the current factors (warm start / tests).  Any may be NULL. */
 SGL_API int sgl_set_factors(sgl_ctx* ctx, const double* w, const double* d, const double* h);
+
+/* One ALS iteration (src/singlet.cpp:648-659) on a context, whatever its exchange: none (one shard),
+ * the all-reduce hook (the five steps above) or a native team (section 2b).  *tol = cor(w, w_prev). */
+SGL_API int sgl_nmf_iterate(sgl_ctx* ctx, double L1_w, double L1_h, double L2_w, double L2_h, double* tol);
+
+/* ------------------------------------------------------------------------
+ * 2b. Native multi-GPU: cells sharded over the GPUs of one node, the exchange done by the library
+ *     itself over RCCL / xGMI (no hook, no launcher, nothing for the R side to do).  Per iteration:
+ *     ONE grouped collective -- reduce-scatter of the k x genes right-hand sides of the W-update by
+ *     gene blocks + all-reduce of [k x k Gram of h | k row sums of h], all taken from the UNSCALED h
+ *     (they commute with scale(h, d), src/singlet.cpp:651) -- then every rank solves its block of
+ *     genes and the blocks of w are all-gathered.  W, d and tol come out identical on all ranks.
+ *     Results equal the one-GPU fit to rounding (the scaling is applied after the sums).
+ *     Limits: c_nmf only (no links, no dense front-end, no masked path), k as for one GPU.
+ *     RCCL is loaded at run time (librccl.so.1; SGL_RCCL_PATH overrides); SGL_ECOMM if absent.
+ * ---------------------------------------------------------------------- */
+/* (a) ONE process drives all devices -- the form an R session uses.  sgl_c_nmf itself takes this
+ *     path when the environment variable SINGLET_NGPU is set to a number > 1.
+ *     devices: ndev device ids (NULL: 0 .. ndev-1), all distinct -> RCCL (ncclCommInitAll); all
+ *     equal -> the ranks share one device and exchange through a HIP kernel (test configuration). */
+typedef struct sgl_multi sgl_multi;
+SGL_API int sgl_multi_create(int ndev, const int* devices, sgl_multi** out);
+SGL_API int sgl_multi_destroy(sgl_multi* m);
+SGL_API int sgl_multi_size(const sgl_multi* m);
+/* rank's context, owned by m (for timing / layout queries; do not destroy). */
+SGL_API int sgl_multi_ctx(sgl_multi* m, int rank, sgl_ctx** out);
+/* Whole matrix in, cells split into contiguous blocks of (nearly) equal non-zero count; the transposed
+ * shards are built on the devices. */
+SGL_API int sgl_multi_upload_csc(sgl_multi* m, const double* Ax, const int32_t* Ai, const int32_t* Ap, int32_t nrow, int32_t ncol);
+SGL_API int sgl_multi_synth_csc(sgl_multi* m, uint64_t S, uint64_t inv_density, const double* levels16, int32_t ngenes,
+                                int64_t ncells_total);
+SGL_API int sgl_multi_fit_init(sgl_multi* m, int32_t k, const double* w_init, uint64_t synth_seed);
+SGL_API int sgl_multi_iterate(sgl_multi* m, double L1_w, double L1_h, double L2_w, double L2_h, double* tol);
+SGL_API int sgl_multi_nmf_run(sgl_multi* m, double tol, int32_t maxit, double L1_w, double L1_h, double L2_w, double L2_h,
+                              int32_t* n_iter, double* tol_trace, const sgl_callbacks* cb);
+/* w k x nrow, d k, h k x ncol (all cells, in matrix order); any may be NULL. */
+SGL_API int sgl_multi_get_factors(sgl_multi* m, double* w, double* d, double* h);
+/* (b) one process per GPU (torch.distributed.run, MPI ...): rank 0 makes an id, the host broadcasts
+ *     its SGL_COMM_ID_BYTES bytes, every rank joins with its context BEFORE sgl_fit_init.  The
+ *     collectives run on the context's stream; sgl_nmf_iterate / sgl_nmf_run then do the team
+ *     iteration.  The communicator is destroyed with the context. */
+#define SGL_COMM_ID_BYTES 128
+SGL_API int sgl_comm_unique_id(void* id);
+SGL_API int sgl_comm_init_rank(sgl_ctx* ctx, int nranks, int rank, const void* id);
 
 /* ------------------------------------------------------------------------
  * 3. Single operators, exposed for the parity tests (each is one kernel

@@ -79,6 +79,20 @@ SIGNATURES = {
     "sgl_ard_run": (C.c_int, [C.c_void_p, C.c_double, C.c_int32, C.c_double, C.c_double, C.c_uint64, C.c_uint64,
                               C.c_double, C.c_int32, f64p, i32p, f64p, f64p, i32p, i32p, _CB]),
     "sgl_project_run": (C.c_int, [C.c_void_p, C.c_double, C.c_double]),
+    "sgl_nmf_iterate": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, f64p]),
+    "sgl_multi_create": (C.c_int, [C.c_int, i32p, C.POINTER(C.c_void_p)]),
+    "sgl_multi_destroy": (C.c_int, [C.c_void_p]),
+    "sgl_multi_size": (C.c_int, [C.c_void_p]),
+    "sgl_multi_ctx": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "sgl_multi_upload_csc": (C.c_int, [C.c_void_p] + _CSC + [C.c_int32, C.c_int32]),
+    "sgl_multi_synth_csc": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, f64p, C.c_int32, C.c_int64]),
+    "sgl_multi_fit_init": (C.c_int, [C.c_void_p, C.c_int32, f64p, C.c_uint64]),
+    "sgl_multi_iterate": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, f64p]),
+    "sgl_multi_nmf_run": (C.c_int, [C.c_void_p, C.c_double, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double,
+                                    i32p, f64p, _CB]),
+    "sgl_multi_get_factors": (C.c_int, [C.c_void_p, f64p, f64p, f64p]),
+    "sgl_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "sgl_comm_init_rank": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "sgl_get_factors": (C.c_int, [C.c_void_p, f64p, f64p, f64p]),
     "sgl_set_factors": (C.c_int, [C.c_void_p, f64p, f64p, f64p]),
     "sgl_op_rand": (C.c_int, [C.c_void_p, C.c_uint64, u64p, u64p, C.c_int64, u64p]),

@@ -32,20 +32,50 @@ def make_callbacks(log=None, poll=None):
     return cb
 
 
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """RCCL unique id (bytes) for Context.comm_init_rank: rank 0 makes it, the host broadcasts it."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    check(_lib.load().sgl_comm_unique_id(buf))
+    return buf.raw
+
+
 class Context:
-    def __init__(self, device=0):
+    def __init__(self, device=0, _borrowed=None):
         self._L = _lib.load()
-        h = C.c_void_p()
-        check(self._L.sgl_create(int(device), C.byref(h)))
-        self._h = h
+        if _borrowed is not None:   # a rank of a Multi: owned by it
+            self._h = _borrowed
+            self._owned = False
+        else:
+            h = C.c_void_p()
+            check(self._L.sgl_create(int(device), C.byref(h)))
+            self._h = h
+            self._owned = True
         self._keep = []
         self.k = 0
 
     # -- lifetime ---------------------------------------------------------
     def close(self):
         if getattr(self, "_h", None):
-            self._L.sgl_destroy(self._h)
+            if self._owned:
+                self._L.sgl_destroy(self._h)
             self._h = None
+
+    def comm_init_rank(self, nranks, rank, comm_id):
+        """Join the native team of `nranks` processes (one per GPU) with the id rank 0 made
+        (comm_unique_id); call before fit_init.  nmf_iterate / nmf_run then exchange over RCCL."""
+        if len(comm_id) != COMM_ID_BYTES:
+            raise ValueError("comm_id must be %d bytes" % COMM_ID_BYTES)
+        buf = C.create_string_buffer(bytes(comm_id), COMM_ID_BYTES)
+        check(self._L.sgl_comm_init_rank(self._h, int(nranks), int(rank), buf))
+
+    def nmf_iterate(self, L1_w, L1_h, L2_w, L2_h):
+        """One ALS iteration (any exchange mode); returns tol."""
+        t = C.c_double()
+        check(self._L.sgl_nmf_iterate(self._h, L1_w, L1_h, L2_w, L2_h, C.byref(t)))
+        return t.value
 
     def __del__(self):
         try:
@@ -272,3 +302,82 @@ class Context:
         check(self._L.sgl_layout_get(self._h, ptr(out, i64p)))
         keys = ("entries", "tiles", "tile_rows", "tile_ranges", "col_blocks")
         return {name: dict(zip(keys, (int(v) for v in out[5 * o:5 * o + 5]))) for o, name in enumerate(("A", "At"))}
+
+
+class Multi:
+    """sgl_multi: ONE process driving several devices, cells sharded, exchange over RCCL inside the
+    library (include/singlet_hip.h section 2b).  devices: list of device ids -- all distinct (RCCL) or
+    all equal (ranks share one device and exchange through a HIP kernel: the test configuration)."""
+
+    def __init__(self, devices):
+        self._L = _lib.load()
+        dev = np.ascontiguousarray(devices, dtype=np.int32)
+        h = C.c_void_p()
+        check(self._L.sgl_multi_create(int(dev.size), ptr(dev, i32p), C.byref(h)))
+        self._h = h
+        self.n = int(dev.size)
+        self.k = 0
+        self._dims = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.sgl_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def rank_ctx(self, r):
+        h = C.c_void_p()
+        check(self._L.sgl_multi_ctx(self._h, int(r), C.byref(h)))
+        c = Context(_borrowed=h)
+        c.k = self.k
+        return c
+
+    def upload(self, A):
+        check(self._L.sgl_multi_upload_csc(self._h, ptr(A.x, f64p), ptr(A.i, i32p), ptr(A.p, i32p), A.nrow, A.ncol))
+        self._dims = (A.nrow, A.ncol)
+        self.k = 0
+
+    def synth(self, ngenes, ncells_total, inv_density=20, seed=SYNTH_SEED):
+        lv = _f(LEVELS16)
+        check(self._L.sgl_multi_synth_csc(self._h, seed, inv_density, ptr(lv, f64p), int(ngenes), int(ncells_total)))
+        self._dims = (int(ngenes), int(ncells_total))
+        self.k = 0
+
+    def fit_init(self, k, w_init=None, synth_seed=SYNTH_SEED):
+        w = None
+        if w_init is not None:
+            w = _f(w_init)
+            if w.shape != (self._dims[0], k):
+                raise ValueError("w_init must be k x nrow(A)")
+        check(self._L.sgl_multi_fit_init(self._h, int(k), ptr(w, f64p), synth_seed))
+        self.k = int(k)
+
+    def iterate(self, L1_w, L1_h, L2_w, L2_h):
+        t = C.c_double()
+        check(self._L.sgl_multi_iterate(self._h, L1_w, L1_h, L2_w, L2_h, C.byref(t)))
+        return t.value
+
+    def nmf_run(self, tol, maxit, L1_w, L1_h, L2_w, L2_h, log=None, poll=None):
+        n_iter = C.c_int32()
+        tr = np.zeros(max(int(maxit), 1))
+        cb = make_callbacks(log, poll)
+        check(self._L.sgl_multi_nmf_run(self._h, tol, int(maxit), L1_w, L1_h, L2_w, L2_h, C.byref(n_iter), ptr(tr, f64p),
+                                        C.byref(cb)))
+        return n_iter.value, tr[:n_iter.value].copy()
+
+    def get_factors(self):
+        nr, nc = self._dims
+        W, D, H = np.empty((nr, self.k)), np.empty(self.k), np.empty((nc, self.k))
+        check(self._L.sgl_multi_get_factors(self._h, ptr(W, f64p), ptr(D, f64p), ptr(H, f64p)))
+        return W, D, H

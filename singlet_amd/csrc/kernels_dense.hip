@@ -399,3 +399,39 @@ int k_wd(hipStream_t s, const double* W, const double* d, int k, int64_t cols, d
     HIPCHK(hipGetLastError());
     return SGL_OK;
 }
+
+// G[i, j] = (G[i, j] / d_i) / d_j (+ diag_add on the diagonal): the Gram of a row-scaled factor from the
+// Gram of the unscaled one (cell-sharded runs reduce unscaled partials, multi.hip)
+__global__ void gram_rescale_kernel(double* __restrict__ G, int k, const double* __restrict__ d, double diag_add) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= k * k) return;
+    const int i = e % k, j = e / k;
+    double v = (G[e] / d[i]) / d[j];
+    if (i == j) v += diag_add;
+    G[e] = v;
+}
+
+int k_gram_rescale(hipStream_t s, double* G, int k, const double* d, double diag_add) {
+    gram_rescale_kernel<<<dim3((k * k + 255) / 256), dim3(256), 0, s>>>(G, k, d, diag_add);
+    HIPCHK(hipGetLastError());
+    return SGL_OK;
+}
+
+__global__ void i64_to_f64_kernel(const int64_t* __restrict__ in, double* __restrict__ out, int64_t n) {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) out[t] = (double)in[t];
+}
+__global__ void f64_to_i64_kernel(const double* __restrict__ in, int64_t* __restrict__ out, int64_t n) {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) out[t] = (int64_t)in[t];
+}
+int k_i64_to_f64(hipStream_t s, const int64_t* in, double* out, int64_t n) {
+    if (n <= 0) return SGL_OK;
+    i64_to_f64_kernel<<<dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, s>>>(in, out, n);
+    HIPCHK(hipGetLastError());
+    return SGL_OK;
+}
+int k_f64_to_i64(hipStream_t s, const double* in, int64_t* out, int64_t n) {
+    if (n <= 0) return SGL_OK;
+    f64_to_i64_kernel<<<dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, s>>>(in, out, n);
+    HIPCHK(hipGetLastError());
+    return SGL_OK;
+}

@@ -33,6 +33,10 @@ int k_nnls_lane_launch3(hipStream_t s, const double* Gpad, int KP, double* B, do
                         int64_t ncols, double L1, double L2, unsigned long long* sweep_counter, const NnlsPass& ps, dim3 g,
                         dim3 b);
 
+int k_nnls_lane_launch4(hipStream_t s, const double* Gpad, int KP, double* B, double* X, const int64_t* col_nnz, int k,
+                        int64_t ncols, double L1, double L2, unsigned long long* sweep_counter, const NnlsPass& ps, dim3 g,
+                        dim3 b);
+
 int64_t nnls_repack_min_cols() {
     // read on every call (cheap): tests lower it to drive small problems through the multi-pass path
     const char* e = getenv("SGL_NNLS_REPACK_MIN_COLS");
@@ -44,7 +48,7 @@ int64_t nnls_repack_min_cols() {
 // (KP <= 40, kernels_nnls_lane1.hip), KP rounded up to 16 for the vector-load + DPP instances (lane2).
 int nnls_gram_stride(int KP) { return KP > 40 ? (KP + 15) / 16 * 16 : KP; }
 // padded rank of the lane kernel instance serving rank k (0: no instance, use the wave kernel)
-int nnls_lane_kp(int k) { return k <= 64 ? (k + 1) / 2 * 2 : (k <= 104 ? (k + 7) / 8 * 8 : 0); }
+int nnls_lane_kp(int k) { return k <= 64 ? (k + 1) / 2 * 2 : (k <= SGL_LANE_NNLS_MAX_K ? (k + 7) / 8 * 8 : 0); }
 
 int nnls_scratch_alloc(NnlsScratch& sc, int64_t cap, int k_for_xt) {
     nnls_scratch_free(sc);
@@ -67,19 +71,19 @@ int nnls_scratch_alloc(NnlsScratch& sc, int64_t cap, int k_for_xt) {
 }
 
 void nnls_scratch_free(NnlsScratch& sc) {
-    if (sc.list[0]) hipFree(sc.list[0]);
-    if (sc.list[1]) hipFree(sc.list[1]);
-    if (sc.counts) hipFree(sc.counts);
-    if (sc.it_state) hipFree(sc.it_state);
-    if (sc.tol_state) hipFree(sc.tol_state);
-    if (sc.xt) hipFree(sc.xt);
+    if (sc.list[0]) (void)hipFree(sc.list[0]);
+    if (sc.list[1]) (void)hipFree(sc.list[1]);
+    if (sc.counts) (void)hipFree(sc.counts);
+    if (sc.it_state) (void)hipFree(sc.it_state);
+    if (sc.tol_state) (void)hipFree(sc.tol_state);
+    if (sc.xt) (void)hipFree(sc.xt);
     sc = NnlsScratch();
 }
 
 int k_nnls_lane(hipStream_t s, const double* Gpad, int KP, double* B, double* X, const int64_t* col_nnz, int k,
                 int64_t ncols, double L1, double L2, unsigned long long* sweep_counter, const NnlsScratch* scr) {
     if (ncols <= 0) return SGL_OK;
-    auto launch = (KP <= 40) ? k_nnls_lane_launch1 : (KP <= 64 ? k_nnls_lane_launch2 : k_nnls_lane_launch3);
+    auto launch = (KP <= 40) ? k_nnls_lane_launch1 : (KP <= 64 ? k_nnls_lane_launch2 : (KP <= 104 ? k_nnls_lane_launch3 : k_nnls_lane_launch4));
     if (KP > 64 && (scr == nullptr || scr->xt == nullptr || scr->cap < ncols)) {
         sgl_set_error("k_nnls_lane: k > 64 needs the x scratch");
         return SGL_ESTATE;

@@ -163,14 +163,14 @@ int sgl_tiled_build(sgl_ctx* c, const DevCSC& M, int k, DevTiled& S) {
     if (rc == SGL_OK) {
         tiled_count_kernel<<<dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, s>>>(tmp.seg, M.ncol, S.T, S.nwb, S.cnt,
                                                                                          chunk_entries);
-        if (hipGetLastError() != hipSuccess) rc = SGL_EHIP;
+        if (hipGetLastError() != hipSuccess) { sgl_set_error("tiled build: count kernel launch failed"); rc = SGL_EHIP; }
     }
     if (rc == SGL_OK) rc = k_exclusive_scan(c, chunk_entries, S.cstart, nchunks);
     if (rc == SGL_OK) rc = k_scan_total(s, chunk_entries, S.cstart, nchunks);
     int64_t E = 0;
     if (rc == SGL_OK) {
         if (hipMemcpyAsync(&E, S.cstart + nchunks, sizeof(int64_t), hipMemcpyDeviceToHost, s) != hipSuccess ||
-            hipStreamSynchronize(s) != hipSuccess) rc = SGL_EHIP;
+            hipStreamSynchronize(s) != hipSuccess) { sgl_set_error("tiled build: reading the stream size failed"); rc = SGL_EHIP; }
     }
     S.E = E;
     // + 512 entries of slack: the kernel prefetches four 64-entry sets past the end
@@ -178,14 +178,14 @@ int sgl_tiled_build(sgl_ctx* c, const DevCSC& M, int k, DevTiled& S) {
     if (rc == SGL_OK) rc = t_alloc(&S.x, (size_t)E + 512);
     if (rc == SGL_OK) {
         if (hipMemsetAsync(S.roff + E, 0, 512 * sizeof(uint32_t), s) != hipSuccess ||
-            hipMemsetAsync(S.x + E, 0, 512 * sizeof(double), s) != hipSuccess) rc = SGL_EHIP;
+            hipMemsetAsync(S.x + E, 0, 512 * sizeof(double), s) != hipSuccess) { sgl_set_error("tiled build: clearing the stream slack failed"); rc = SGL_EHIP; }
     }
     if (rc == SGL_OK && nchunks > 0) {
         int64_t blocks = (nchunks + 3) / 4;
         if (blocks > 256 * 64) blocks = 256 * 64;
         tiled_fill_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(M.x, M.i, tmp.seg, M.ncol, S.T, S.nwb, TR, KS * 8,
                                                                        S.cnt, S.cstart, S.roff, S.x);
-        if (hipGetLastError() != hipSuccess) rc = SGL_EHIP;
+        if (hipGetLastError() != hipSuccess) { sgl_set_error("tiled build: fill kernel launch failed"); rc = SGL_EHIP; }
     }
     // split of the tile range over blockIdx.y so that the grid fills 256 CUs (1 workgroup per CU)
     const int64_t nwg_x = (S.nwb + TILED_NW - 1) / TILED_NW;
@@ -244,11 +244,6 @@ int sgl_tiled_build(sgl_ctx* c, const DevCSC& M, int k, DevTiled& S) {
 typedef double d2_t __attribute__((ext_vector_type(2)));
 #define TILED_SET_WAIT "s_waitcnt vmcnt(6)"
 
-#ifdef TILED_ABL_NOSTREAM  // ablation build: never refill the stream registers (wrong results, timing only)
-#define TILED_ABL_LOAD(...) do { if (pos < 256) asm volatile(__VA_ARGS__); } while (0)
-#else
-#define TILED_ABL_LOAD(...) asm volatile(__VA_ARGS__)
-#endif
 
 template <int J>
 __device__ __forceinline__ int dpp_addr(uint32_t roff, int lane_off) {
@@ -314,8 +309,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(128), amdgpu_wa
     do {                                                                                          \
         const uint32_t* pr_ = sroff + (pos + lane);                                               \
         const double* px_ = sx + (pos + lane);                                                    \
-        TILED_ABL_LOAD("global_load_dword %0, %1, off" : "=v"(ER) : "v"(pr_) : "memory");        \
-        TILED_ABL_LOAD("global_load_dwordx2 %0, %1, off" : "=v"(EX) : "v"(px_) : "memory");      \
+        asm volatile("global_load_dword %0, %1, off" : "=v"(ER) : "v"(pr_) : "memory");        \
+        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(EX) : "v"(px_) : "memory");      \
         pos += 64;                                                                                \
     } while (0)
     int phase = 0;
@@ -354,9 +349,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(128), amdgpu_wa
                 stg[j] = double2{0.0, 0.0};
                 if (e < n) stg[j] = *reinterpret_cast<const double2*>(src + e);
             }
-#ifdef TILED_ABL_NOSTAGE  // ablation build: stage only the first tile (wrong results, timing only)
-            if (t > t0) goto staged;
-#endif
             __syncthreads();  // everyone is done reading the previous tile
 #pragma unroll
             for (int rd = 0; rd < NRND; ++rd) {
@@ -400,9 +392,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(128), amdgpu_wa
         // drains the four-set prefetch queue each time.
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
         __syncthreads();
-#ifdef TILED_ABL_NOSTAGE
-    staged:
-#endif
         if (!wact) continue;
 
         int s = -1, rem = 0;
@@ -517,11 +506,14 @@ int k_acc_tiled(hipStream_t s, const DevTiled& S, const double* F, int ldf, doub
     if (kf <= 0 || kf > S.k) { sgl_set_error("k_acc_tiled: bad part size %d (stream built for %d)", kf, S.k); return SGL_EINVAL; }
     const int KS = (S.k + 1) & ~1;
     const size_t lds = (size_t)S.TR * KS * 8 + 512;
-    static bool attr_set = false;
-    if (!attr_set) {
+    // the attribute belongs to the (function, device) pair: one process may drive several devices
+    static bool attr_set[64] = {false};
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&acc_tiled_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, TILED_LDS_BYTES + 512));
-        attr_set = true;
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
     const int64_t nwg_x = (S.nwb + TILED_NW - 1) / TILED_NW;
     const bool slabs = S.R > 1;

@@ -1,0 +1,634 @@
+// Native multi-GPU path: cells sharded over the ranks of a TEAM, the per-iteration exchange done by
+// the library itself over RCCL (xGMI), no host-side hook.
+//
+// The reference has no distribution; its nearest relative is the column-chunk list with a running
+// column offset (src/singlet.cpp:384-402).  Here rank r owns a contiguous block of
+// cells: A[:, blk_r], its transpose, H[:, blk_r]; W, its Gram and d are replicated.
+//
+// One ALS iteration on a team:
+//   every rank   h = predict(A_r, w)                                   local, src/singlet.cpp:650
+//                partials of the UNSCALED h:  B' = h A_r^T (k x m),  G' = h h^T (k x k),  s = rowsums(h) (k)
+//   exchange 1   ONE grouped collective:  reduce-scatter of B' by gene blocks  +  all-reduce of [G' | s]
+//                (unscaled partials commute with scale(h, d): with D = diag(s + 1e-15) the reference's
+//                operands are D^-1 B', D^-1 G' D^-1 -- same sums, rounding order differs by ~1 ulp)
+//   every rank   h /= D;  its gene block:  b = D^-1 B',  G = D^-1 G' D^-1 + 1e-15 I,  nnls -> w[:, block]   :654
+//   exchange 2   all-gather of the w blocks (reduce-scatter + all-gather move the bytes of one all-reduce,
+//                and the m solves are dealt out instead of replicated)
+//   every rank   scale(w, d); tol = cor(w, w_prev)                      replicated, bit-identical   :655-659
+//
+// Two ways to form a team:
+//   * sgl_multi_create: ONE process drives all devices (the R host: no launcher), communicators from
+//     ncclCommInitAll, collectives issued for all ranks inside ncclGroupStart / ncclGroupEnd;
+//   * sgl_comm_init_rank: one process per GPU (bench.py under torch.distributed.run), communicator from
+//     ncclCommInitRank with an id the host broadcast.
+// RCCL is bound at run time (dlopen): single-GPU users need no RCCL.  Ranks that share ONE device inside
+// one process cannot form an RCCL communicator (duplicate GPU); they exchange through a HIP kernel
+// that sums in rank order ("loopback") -- that is how the team logic is tested on a 1-GPU box.
+#include "sgl_internal.h"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+#include <string.h>
+#include <stdlib.h>
+#include <algorithm>
+#include <vector>
+
+// ---------------------------------------------------------------- RCCL binding --
+struct RcclApi {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*ReduceScatter)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+static RcclApi* rccl_api() {
+    static RcclApi api;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        const char* names[] = {getenv("SGL_RCCL_PATH"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : names) {
+            if (!n || !*n) continue;
+            api.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+            if (api.handle) break;
+        }
+        if (api.handle) {
+            bool ok = true;
+            auto bind = [&](const char* sym) { void* f = dlsym(api.handle, sym); if (!f) ok = false; return f; };
+            api.GetUniqueId = (decltype(api.GetUniqueId))bind("ncclGetUniqueId");
+            api.CommInitRank = (decltype(api.CommInitRank))bind("ncclCommInitRank");
+            api.CommInitAll = (decltype(api.CommInitAll))bind("ncclCommInitAll");
+            api.CommDestroy = (decltype(api.CommDestroy))bind("ncclCommDestroy");
+            api.AllReduce = (decltype(api.AllReduce))bind("ncclAllReduce");
+            api.ReduceScatter = (decltype(api.ReduceScatter))bind("ncclReduceScatter");
+            api.AllGather = (decltype(api.AllGather))bind("ncclAllGather");
+            api.GroupStart = (decltype(api.GroupStart))bind("ncclGroupStart");
+            api.GroupEnd = (decltype(api.GroupEnd))bind("ncclGroupEnd");
+            api.GetErrorString = (decltype(api.GetErrorString))bind("ncclGetErrorString");
+            if (!ok) { dlclose(api.handle); api.handle = nullptr; }
+        }
+    }
+    if (!api.handle) { sgl_set_error("RCCL (librccl.so.1) could not be loaded: %s", dlerror() ? dlerror() : "not found"); return nullptr; }
+    return &api;
+}
+
+#define NCCLCHK(expr)                                                                              \
+    do {                                                                                           \
+        ncclResult_t r__ = (expr);                                                                 \
+        if (r__ != ncclSuccess) {                                                                  \
+            sgl_set_error("%s failed: %s (%s:%d)", #expr, rccl_api()->GetErrorString(r__), __FILE__, __LINE__); \
+            return SGL_ECOMM;                                                                      \
+        }                                                                                          \
+    } while (0)
+
+// ----------------------------------------------------------------------- team --
+#define SGL_TEAM_MAX 16
+
+struct sgl_team {
+    int nranks = 1;
+    std::vector<sgl_ctx*> local;   // the ranks this process drives
+    std::vector<int> rank;         // team rank of local[i]
+    std::vector<ncclComm_t> comm;  // per local rank; empty in loopback mode
+    bool loopback = false;
+    std::vector<hipEvent_t> ev;    // loopback: stream ordering
+    hipEvent_t done = nullptr;
+    bool owns_ctx = false;         // sgl_multi_create made the contexts (sgl_multi_destroy frees them)
+    int32_t nrow = 0;
+    int64_t ncells_total = 0;
+    std::vector<int64_t> cell_lo;  // single-process form: cell block boundaries (nranks + 1)
+};
+struct sgl_multi : sgl_team {};
+
+int sgl_team_size(const sgl_ctx* c) { return (c && c->team) ? c->team->nranks : 1; }
+
+void sgl_team_detach(sgl_ctx* c) {
+    sgl_team* T = c->team;
+    if (!T) return;
+    for (size_t i = 0; i < T->local.size(); ++i)
+        if (T->local[i] == c) {
+            if (!T->loopback && i < T->comm.size() && T->comm[i] && rccl_api()) (void)rccl_api()->CommDestroy(T->comm[i]);
+            T->local.erase(T->local.begin() + i);
+            T->rank.erase(T->rank.begin() + i);
+            if (i < T->comm.size()) T->comm.erase(T->comm.begin() + i);
+            break;
+        }
+    c->team = nullptr;
+    if (T->local.empty() && !T->owns_ctx) {  // a team made by sgl_comm_init_rank dies with its context
+        for (auto e : T->ev) (void)hipEventDestroy(e);
+        if (T->done) (void)hipEventDestroy(T->done);
+        delete T;
+    }
+}
+
+// ------------------------------------------------------------ loopback kernels --
+struct PtrPack {
+    void* p[SGL_TEAM_MAX];
+};
+template <typename T_>
+__global__ void lb_allreduce_kernel(PtrPack bufs, int n, int64_t count) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (int64_t)gridDim.x * blockDim.x) {
+        T_ s = static_cast<T_*>(bufs.p[0])[e];
+        for (int r = 1; r < n; ++r) s += static_cast<T_*>(bufs.p[r])[e];
+        for (int r = 0; r < n; ++r) static_cast<T_*>(bufs.p[r])[e] = s;
+    }
+}
+// block r (cnt elements at offset r * cnt) of rank r's buffer = sum over the ranks of their block r
+__global__ void lb_reduce_scatter_kernel(PtrPack bufs, int n, int64_t cnt) {
+    const int64_t total = cnt * n;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(e / cnt);
+        double s = static_cast<double*>(bufs.p[0])[e];
+        for (int q = 1; q < n; ++q) s += static_cast<double*>(bufs.p[q])[e];
+        static_cast<double*>(bufs.p[r])[e] = s;
+    }
+}
+__global__ void lb_allgather_kernel(PtrPack bufs, int n, int64_t cnt) {
+    const int64_t total = cnt * n;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(e / cnt);
+        const double v = static_cast<double*>(bufs.p[r])[e];
+        for (int q = 0; q < n; ++q)
+            if (q != r) static_cast<double*>(bufs.p[q])[e] = v;
+    }
+}
+
+// loopback: make stream 0 wait for all ranks' streams, run `launch` there, make the others wait for it
+template <typename F>
+static int lb_run(sgl_team* T, F&& launch) {
+    const int n = (int)T->local.size();
+    for (int i = 0; i < n; ++i) HIPCHK(hipEventRecord(T->ev[i], T->local[i]->stream));
+    for (int i = 1; i < n; ++i) HIPCHK(hipStreamWaitEvent(T->local[0]->stream, T->ev[i], 0));
+    launch(T->local[0]->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(T->done, T->local[0]->stream));
+    for (int i = 1; i < n; ++i) HIPCHK(hipStreamWaitEvent(T->local[i]->stream, T->done, 0));
+    return SGL_OK;
+}
+
+static unsigned lb_blocks(int64_t n) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 2048)); }
+
+// ------------------------------------------------------------------ collectives --
+// Each takes one buffer per LOCAL rank (index i = T->local[i]); all are in place.
+struct TeamPhase {  // SGL_PH_COMM on every local context
+    sgl_team* T;
+    std::vector<PhaseEvent> pe;
+    explicit TeamPhase(sgl_team* t) : T(t), pe(t->local.size()) {
+        for (size_t i = 0; i < T->local.size(); ++i) {
+            (void)hipSetDevice(T->local[i]->device);
+            (void)sgl_phase_begin(T->local[i], SGL_PH_COMM, &pe[i]);
+        }
+    }
+    ~TeamPhase() {
+        for (size_t i = 0; i < T->local.size(); ++i) {
+            (void)hipSetDevice(T->local[i]->device);
+            (void)sgl_phase_end(T->local[i], &pe[i]);
+        }
+    }
+};
+
+static PtrPack pack(sgl_team* T, void* const* bufs) {
+    PtrPack P;
+    for (int i = 0; i < SGL_TEAM_MAX; ++i) P.p[i] = nullptr;
+    for (size_t i = 0; i < T->local.size(); ++i) P.p[T->rank[i]] = bufs[i];
+    return P;
+}
+
+// sum of `count` doubles (or int64) over the ranks
+static int team_allreduce(sgl_team* T, void* const* bufs, int64_t count, bool i64 = false) {
+    if (count <= 0) return SGL_OK;
+    if (T->loopback) {
+        const PtrPack P = pack(T, bufs);
+        const int n = T->nranks;
+        return lb_run(T, [&](hipStream_t s) {
+            if (i64) lb_allreduce_kernel<long long><<<dim3(lb_blocks(count)), dim3(256), 0, s>>>(P, n, count);
+            else lb_allreduce_kernel<double><<<dim3(lb_blocks(count)), dim3(256), 0, s>>>(P, n, count);
+        });
+    }
+    RcclApi* R = rccl_api();
+    if (!R) return SGL_ECOMM;
+    for (size_t i = 0; i < T->local.size(); ++i) {
+        HIPCHK(hipSetDevice(T->local[i]->device));
+        NCCLCHK(R->AllReduce(bufs[i], bufs[i], (size_t)count, i64 ? ncclInt64 : ncclDouble, ncclSum, T->comm[i], T->local[i]->stream));
+    }
+    return SGL_OK;
+}
+
+// block r (cnt doubles at offset r * cnt) of rank r's buffer = sum over the ranks of their block r
+static int team_reduce_scatter(sgl_team* T, void* const* bufs, int64_t cnt) {
+    if (cnt <= 0) return SGL_OK;
+    if (T->loopback) {
+        const PtrPack P = pack(T, bufs);
+        const int n = T->nranks;
+        return lb_run(T, [&](hipStream_t s) { lb_reduce_scatter_kernel<<<dim3(lb_blocks(cnt * n)), dim3(256), 0, s>>>(P, n, cnt); });
+    }
+    RcclApi* R = rccl_api();
+    if (!R) return SGL_ECOMM;
+    for (size_t i = 0; i < T->local.size(); ++i) {
+        HIPCHK(hipSetDevice(T->local[i]->device));
+        double* b = static_cast<double*>(bufs[i]);
+        NCCLCHK(R->ReduceScatter(b, b + (size_t)T->rank[i] * cnt, (size_t)cnt, ncclDouble, ncclSum, T->comm[i], T->local[i]->stream));
+    }
+    return SGL_OK;
+}
+
+static int team_allgather(sgl_team* T, void* const* bufs, int64_t cnt) {
+    if (cnt <= 0) return SGL_OK;
+    if (T->loopback) {
+        const PtrPack P = pack(T, bufs);
+        const int n = T->nranks;
+        return lb_run(T, [&](hipStream_t s) { lb_allgather_kernel<<<dim3(lb_blocks(cnt * n)), dim3(256), 0, s>>>(P, n, cnt); });
+    }
+    RcclApi* R = rccl_api();
+    if (!R) return SGL_ECOMM;
+    for (size_t i = 0; i < T->local.size(); ++i) {
+        HIPCHK(hipSetDevice(T->local[i]->device));
+        double* b = static_cast<double*>(bufs[i]);
+        NCCLCHK(R->AllGather(b + (size_t)T->rank[i] * cnt, b, (size_t)cnt, ncclDouble, T->comm[i], T->local[i]->stream));
+    }
+    return SGL_OK;
+}
+
+static int group_begin(sgl_team* T) {
+    if (T->loopback) return SGL_OK;
+    RcclApi* R = rccl_api();
+    if (!R) return SGL_ECOMM;
+    NCCLCHK(R->GroupStart());
+    return SGL_OK;
+}
+static int group_end(sgl_team* T) {
+    if (T->loopback) return SGL_OK;
+    NCCLCHK(rccl_api()->GroupEnd());
+    return SGL_OK;
+}
+
+// ---------------------------------------------------------------- team set-up --
+static int team_events(sgl_team* T) {
+    if (!T->loopback) return SGL_OK;
+    HIPCHK(hipSetDevice(T->local[0]->device));
+    T->ev.resize(T->local.size());
+    for (auto& e : T->ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&T->done, hipEventDisableTiming));
+    return SGL_OK;
+}
+
+// per-gene non-zero counts over all ranks (which W columns predict() skips, src/singlet.cpp:340)
+static int team_gene_counts(sgl_team* T) {
+    if (T->nranks <= 1) return SGL_OK;
+    std::vector<void*> bufs(T->local.size());
+    for (size_t i = 0; i < T->local.size(); ++i) {
+        sgl_ctx* c = T->local[i];
+        HIPCHK(hipSetDevice(c->device));
+        const int64_t m = c->A.nrow;
+        if (!c->col_nnz_At_global) {
+            hipError_t e = hipMalloc((void**)&c->col_nnz_At_global, sizeof(int64_t) * (size_t)std::max<int64_t>(m, 1));
+            if (e != hipSuccess) { (void)hipGetLastError(); sgl_set_error("team: out of device memory"); return SGL_ENOMEM; }
+        }
+        HIPCHK(hipMemcpyAsync(c->col_nnz_At_global, c->col_nnz_At, sizeof(int64_t) * (size_t)m, hipMemcpyDeviceToDevice, c->stream));
+        bufs[i] = c->col_nnz_At_global;
+    }
+    SGLCHK(group_begin(T));
+    int rc = team_allreduce(T, bufs.data(), T->nrow, true);
+    SGLCHK(group_end(T));
+    SGLCHK(rc);
+    for (auto c : T->local) c->gene_nnz_global = true;
+    return SGL_OK;
+}
+
+#define TEAM_GUARD(T)                                                                                 \
+    do {                                                                                              \
+        if ((T) == nullptr || (T)->local.empty()) { sgl_set_error("null or empty team"); return SGL_EINVAL; } \
+    } while (0)
+
+// -------------------------------------------------------------- the iteration --
+// One ALS iteration over the local ranks of the team (header comment).  Every enqueue of every rank
+// is asynchronous; the only host wait is the final read of tol.
+static int team_iterate(sgl_team* T, double L1_w, double L1_h, double L2_w, double L2_h, double* tol_out) {
+    const int nl = (int)T->local.size();
+    const int N = T->nranks;
+    for (auto c : T->local) {
+        if (c->k == 0) { sgl_set_error("team: no fit initialised"); return SGL_ESTATE; }
+        if (c->link_h || c->link_w || c->solve_empty) { sgl_set_error("team: linked / dense fits are not supported"); return SGL_EINVAL; }
+    }
+    const int k = T->local[0]->k;
+    const int64_t m = T->nrow;
+    const int64_t mb = N > 1 ? (m + N - 1) / N : m;       // genes per rank block
+    const int64_t mpad = mb * N;
+    std::vector<void*> red(nl), tail(nl), wbuf(nl);
+    for (int i = 0; i < nl; ++i) {
+        sgl_ctx* c = T->local[i];
+        HIPCHK(hipSetDevice(c->device));
+        SGLCHK(sgl_step_begin(c));
+        SGLCHK(sgl_step_h(c, L1_h, L2_h));
+        double* Bw = c->red;
+        double* Gh = c->red + (size_t)k * mpad;
+        double* sh = Gh + (size_t)k * k;
+        PhaseEvent pe;
+        SGLCHK(sgl_phase_begin(c, SGL_PH_SCALE, &pe));
+        SGLCHK(k_rowsum(c, c->H, k, c->A.ncol, sh));
+        SGLCHK(sgl_phase_end(c, &pe));
+        SGLCHK(sgl_phase_begin(c, SGL_PH_RHS_W, &pe));
+        if (c->use_tiled && c->TAt.roff) SGLCHK(k_acc_tiled_all(c->stream, c->TAt, c->H, Bw, k));
+        else SGLCHK(k_acc(c->stream, c->At, c->H, k, Bw, 0, 1, 0, 0, 0));
+        SGLCHK(sgl_phase_end(c, &pe));
+        SGLCHK(sgl_phase_begin(c, SGL_PH_GRAM, &pe));
+        SGLCHK(k_gram(c, c->H, k, c->A.ncol, Gh, 0.0));
+        SGLCHK(sgl_phase_end(c, &pe));
+        red[i] = Bw;
+        tail[i] = Gh;
+        wbuf[i] = c->W;
+    }
+    {   // exchange 1: one grouped collective
+        TeamPhase ph(T);
+        SGLCHK(group_begin(T));
+        int rc = team_reduce_scatter(T, red.data(), (int64_t)k * mb);
+        if (rc == SGL_OK) rc = team_allreduce(T, tail.data(), (int64_t)k * k + k);
+        SGLCHK(group_end(T));
+        SGLCHK(rc);
+    }
+    for (int i = 0; i < nl; ++i) {
+        sgl_ctx* c = T->local[i];
+        HIPCHK(hipSetDevice(c->device));
+        const int r = T->rank[i];
+        double* Gh = c->red + (size_t)k * mpad;
+        double* sh = Gh + (size_t)k * k;
+        PhaseEvent pe;
+        SGLCHK(sgl_phase_begin(c, SGL_PH_SCALE, &pe));
+        // d = rowsums + 1e-15; h /= d  (scale(h, d), src/singlet.cpp:219-225, with the GLOBAL row sums)
+        HIPCHK(hipMemcpyAsync(c->d, sh, sizeof(double) * k, hipMemcpyDeviceToDevice, c->stream));
+        SGLCHK(k_scale_apply(c->stream, c->H, k, c->A.ncol, c->d, 1));
+        SGLCHK(sgl_phase_end(c, &pe));
+        const int64_t g0 = (int64_t)r * mb;
+        const int64_t ng = std::max<int64_t>(0, std::min<int64_t>(mb, m - g0));
+        SGLCHK(sgl_phase_begin(c, SGL_PH_GRAM, &pe));
+        HIPCHK(hipMemcpyAsync(c->G, Gh, sizeof(double) * k * k, hipMemcpyDeviceToDevice, c->stream));
+        SGLCHK(k_gram_rescale(c->stream, c->G, k, c->d, 1e-15));   // AAt of the scaled h (+1e-15, l.204)
+        SGLCHK(sgl_phase_end(c, &pe));
+        SGLCHK(sgl_phase_begin(c, SGL_PH_NNLS_W, &pe));
+        if (ng > 0) {
+            double* Bblk = c->red + (size_t)g0 * k;
+            SGLCHK(k_scale_apply(c->stream, Bblk, k, ng, c->d, 0));
+            const int64_t* gene_nnz = (N > 1) ? c->col_nnz_At_global : c->col_nnz_At;
+            if (N > 1 && !c->gene_nnz_global) { sgl_set_error("team: global gene counts missing"); return SGL_ESTATE; }
+            SGLCHK(sgl_nnls_shared(c, c->G, Bblk, c->W + (size_t)g0 * k, gene_nnz + g0, ng, L1_w, L2_w, c->sweep_counters + 1));
+        }
+        SGLCHK(sgl_phase_end(c, &pe));
+    }
+    if (N > 1) {  // exchange 2
+        TeamPhase ph(T);
+        SGLCHK(group_begin(T));
+        int rc = team_allgather(T, wbuf.data(), (int64_t)k * mb);
+        SGLCHK(group_end(T));
+        SGLCHK(rc);
+    }
+    for (int i = 0; i < nl; ++i) {
+        HIPCHK(hipSetDevice(T->local[i]->device));
+        SGLCHK(sgl_scale_w_enqueue(T->local[i]));
+    }
+    double tol = 0.0;
+    for (int i = 0; i < nl; ++i) {
+        HIPCHK(hipSetDevice(T->local[i]->device));
+        double t = 0.0;
+        SGLCHK(sgl_scale_w_fetch(T->local[i], &t));
+        if (i == 0) tol = t;   // w is replicated bit for bit: every rank computes the same value
+    }
+    if (tol_out) *tol_out = tol;
+    return SGL_OK;
+}
+
+static int team_nmf_run(sgl_team* T, double tol, int32_t maxit, double L1_w, double L1_h, double L2_w, double L2_h,
+                        int32_t* n_iter, double* tol_trace, const sgl_callbacks* cb) {
+    double tol_ = 1.0;
+    int it = 0;
+    for (; it < maxit && tol_ > tol; ++it) {   // src/singlet.cpp:647
+        SGLCHK(team_iterate(T, L1_w, L1_h, L2_w, L2_h, &tol_));
+        if (tol_trace) tol_trace[it] = tol_;
+        if (cb && cb->log) cb->log(cb->user, it + 1, tol_, NAN);
+        if (cb && cb->poll && cb->poll(cb->user)) { sgl_set_error("interrupted"); return SGL_EINTR; }
+    }
+    for (auto c : T->local) {
+        HIPCHK(hipSetDevice(c->device));
+        SGLCHK(sgl_fetch_sweeps(c));
+    }
+    if (n_iter) *n_iter = it;
+    return SGL_OK;
+}
+
+// ------------------------------------------------- one process per GPU (ABI) --
+extern "C" int sgl_comm_unique_id(void* id128) {
+    if (!id128) { sgl_set_error("sgl_comm_unique_id: NULL buffer"); return SGL_EINVAL; }
+    RcclApi* R = rccl_api();
+    if (!R) return SGL_ECOMM;
+    ncclUniqueId id;
+    NCCLCHK(R->GetUniqueId(&id));
+    static_assert(sizeof(id) == SGL_COMM_ID_BYTES, "ncclUniqueId size");
+    memcpy(id128, &id, sizeof(id));
+    return SGL_OK;
+}
+
+extern "C" int sgl_comm_init_rank(sgl_ctx* c, int nranks, int rank, const void* id128) {
+    if (!c) { sgl_set_error("null context"); return SGL_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    if (nranks < 1 || nranks > SGL_TEAM_MAX || rank < 0 || rank >= nranks || !id128) { sgl_set_error("sgl_comm_init_rank: bad arguments"); return SGL_EINVAL; }
+    if (c->team || c->allreduce) { sgl_set_error("sgl_comm_init_rank: the context already has a team or an all-reduce hook"); return SGL_ESTATE; }
+    if (c->k != 0) { sgl_set_error("sgl_comm_init_rank: call before sgl_fit_init (buffer sizes depend on the team)"); return SGL_ESTATE; }
+    RcclApi* R = rccl_api();
+    if (!R) return SGL_ECOMM;
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    ncclComm_t comm = nullptr;
+    NCCLCHK(R->CommInitRank(&comm, nranks, id, rank));
+    sgl_team* T = new (std::nothrow) sgl_team();
+    if (!T) { (void)R->CommDestroy(comm); sgl_set_error("out of host memory"); return SGL_ENOMEM; }
+    T->nranks = nranks;
+    T->local.push_back(c);
+    T->rank.push_back(rank);
+    T->comm.push_back(comm);
+    c->team = T;
+    c->team_rank = rank;
+    c->gene_nnz_global = false;
+    return SGL_OK;
+}
+
+// One ALS iteration on a context, whatever its exchange: none (one shard), the all-reduce hook (two
+// all-reduces, the reference's operation order) or a native team (above).
+extern "C" int sgl_nmf_iterate(sgl_ctx* c, double L1_w, double L1_h, double L2_w, double L2_h, double* tol) {
+    if (!c) { sgl_set_error("null context"); return SGL_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    if (c->team) {
+        sgl_team* T = c->team;
+        if (T->local.size() != 1) { sgl_set_error("sgl_nmf_iterate: this context is driven by its sgl_multi; call sgl_multi_iterate"); return SGL_ESTATE; }
+        T->nrow = c->A.nrow;
+        if (T->nranks > 1 && !c->gene_nnz_global) SGLCHK(team_gene_counts(T));
+        return team_iterate(T, L1_w, L1_h, L2_w, L2_h, tol);
+    }
+    SGLCHK(sgl_step_begin(c));
+    SGLCHK(sgl_step_h(c, L1_h, L2_h));
+    SGLCHK(sgl_step_scale_h(c));
+    SGLCHK(sgl_step_w(c, L1_w, L2_w));
+    return sgl_step_scale_w(c, tol);
+}
+
+// ---------------------------------------------- one process, all devices (ABI) --
+extern "C" int sgl_multi_create(int ndev, const int* devices, sgl_multi** out) {
+    if (!out) { sgl_set_error("sgl_multi_create: out is NULL"); return SGL_EINVAL; }
+    *out = nullptr;
+    if (ndev < 1 || ndev > SGL_TEAM_MAX) { sgl_set_error("sgl_multi_create: ndev=%d out of range (1..%d)", ndev, SGL_TEAM_MAX); return SGL_EINVAL; }
+    std::vector<int> dev(ndev);
+    for (int i = 0; i < ndev; ++i) dev[i] = devices ? devices[i] : i;
+    bool all_same = true, distinct = true;
+    for (int i = 0; i < ndev; ++i)
+        for (int j = 0; j < i; ++j) {
+            if (dev[i] == dev[j]) distinct = false;
+            else all_same = false;
+        }
+    if (ndev > 1 && !distinct && !all_same) { sgl_set_error("sgl_multi_create: devices must be all distinct (RCCL) or all the same (loopback)"); return SGL_EINVAL; }
+    sgl_multi* M = new (std::nothrow) sgl_multi();
+    if (!M) { sgl_set_error("out of host memory"); return SGL_ENOMEM; }
+    M->nranks = ndev;
+    M->owns_ctx = true;
+    M->loopback = ndev > 1 && all_same;
+    int rc = SGL_OK;
+    for (int i = 0; i < ndev && rc == SGL_OK; ++i) {
+        sgl_ctx* c = nullptr;
+        rc = sgl_create(dev[i], &c);
+        if (rc == SGL_OK) {
+            c->team = M;
+            c->team_rank = i;
+            M->local.push_back(c);
+            M->rank.push_back(i);
+        }
+    }
+    if (rc == SGL_OK && !M->loopback) {
+        RcclApi* R = rccl_api();
+        if (!R) rc = SGL_ECOMM;
+        else {
+            M->comm.assign(ndev, nullptr);
+            ncclResult_t r = R->CommInitAll(M->comm.data(), ndev, dev.data());
+            if (r != ncclSuccess) { sgl_set_error("ncclCommInitAll failed: %s", R->GetErrorString(r)); M->comm.clear(); rc = SGL_ECOMM; }
+        }
+    }
+    if (rc == SGL_OK) rc = team_events(M);
+    if (rc != SGL_OK) { sgl_multi_destroy(M); return rc; }
+    *out = M;
+    return SGL_OK;
+}
+
+extern "C" int sgl_multi_destroy(sgl_multi* M) {
+    if (!M) return SGL_OK;
+    std::vector<sgl_ctx*> ctxs = M->local;
+    for (auto c : ctxs) sgl_destroy(c);   // detaches (and destroys the rank's communicator)
+    for (auto e : M->ev) (void)hipEventDestroy(e);
+    if (M->done) (void)hipEventDestroy(M->done);
+    delete M;
+    return SGL_OK;
+}
+
+extern "C" int sgl_multi_size(const sgl_multi* M) { return M ? M->nranks : 0; }
+
+extern "C" int sgl_multi_ctx(sgl_multi* M, int rank, sgl_ctx** out) {
+    TEAM_GUARD(M);
+    if (!out || rank < 0 || rank >= (int)M->local.size()) { sgl_set_error("sgl_multi_ctx: bad rank"); return SGL_EINVAL; }
+    *out = M->local[rank];
+    return SGL_OK;
+}
+
+// contiguous cell blocks with (nearly) equal non-zero counts
+static void split_by_nnz(const int32_t* p, int32_t ncol, int n, std::vector<int64_t>& b) {
+    b.assign(n + 1, 0);
+    const int64_t total = p[ncol];
+    for (int r = 1; r < n; ++r) {
+        const int64_t target = total * r / n;
+        int64_t c = std::lower_bound(p, p + ncol + 1, (int32_t)std::min<int64_t>(target, INT32_MAX)) - p;
+        c = std::min<int64_t>(std::max<int64_t>(c, b[r - 1]), ncol);
+        b[r] = c;
+    }
+    b[n] = ncol;
+}
+
+extern "C" int sgl_multi_upload_csc(sgl_multi* M, const double* Ax, const int32_t* Ai, const int32_t* Ap, int32_t nrow, int32_t ncol) {
+    TEAM_GUARD(M);
+    if (!Ax || !Ai || !Ap || nrow <= 0 || ncol <= 0) { sgl_set_error("sgl_multi_upload_csc: missing slot or empty matrix"); return SGL_EINVAL; }
+    const int n = M->nranks;
+    if (ncol < n) { sgl_set_error("sgl_multi_upload_csc: fewer cells (%d) than devices (%d)", ncol, n); return SGL_EINVAL; }
+    split_by_nnz(Ap, ncol, n, M->cell_lo);
+    for (int r = 1; r <= n; ++r)   // every rank needs at least one cell
+        if (M->cell_lo[r] <= M->cell_lo[r - 1]) M->cell_lo[r] = M->cell_lo[r - 1] + 1;
+    for (int r = n - 1; r >= 0; --r)
+        if (M->cell_lo[r] >= M->cell_lo[r + 1]) M->cell_lo[r] = M->cell_lo[r + 1] - 1;
+    M->nrow = nrow;
+    M->ncells_total = ncol;
+    std::vector<int32_t> p;
+    for (int r = 0; r < n; ++r) {
+        const int64_t lo = M->cell_lo[r], hi = M->cell_lo[r + 1];
+        p.resize((size_t)(hi - lo) + 1);
+        for (int64_t q = lo; q <= hi; ++q) p[(size_t)(q - lo)] = Ap[q] - Ap[lo];
+        // transposes are built on the device (the host's t(A) describes the whole matrix, not a block)
+        SGLCHK(sgl_upload_csc(M->local[r], Ax + Ap[lo], Ai + Ap[lo], p.data(), nullptr, nullptr, nullptr, nrow, (int32_t)(hi - lo), lo, ncol));
+    }
+    return SGL_OK;
+}
+
+extern "C" int sgl_multi_synth_csc(sgl_multi* M, uint64_t S, uint64_t inv_density, const double* levels16, int32_t ngenes,
+                                   int64_t ncells_total) {
+    TEAM_GUARD(M);
+    const int n = M->nranks;
+    if (ncells_total < n) { sgl_set_error("sgl_multi_synth_csc: fewer cells than devices"); return SGL_EINVAL; }
+    M->cell_lo.assign(n + 1, 0);
+    const int64_t base = ncells_total / n, rem = ncells_total % n;
+    for (int r = 0; r < n; ++r) M->cell_lo[r + 1] = M->cell_lo[r] + base + (r < rem ? 1 : 0);
+    M->nrow = ngenes;
+    M->ncells_total = ncells_total;
+    for (int r = 0; r < n; ++r)
+        SGLCHK(sgl_synth_csc(M->local[r], S, inv_density, levels16, ngenes, M->cell_lo[r], (int32_t)(M->cell_lo[r + 1] - M->cell_lo[r]), ncells_total));
+    return SGL_OK;
+}
+
+extern "C" int sgl_multi_fit_init(sgl_multi* M, int32_t k, const double* w_init, uint64_t synth_seed) {
+    TEAM_GUARD(M);
+    if (M->cell_lo.empty()) { sgl_set_error("sgl_multi_fit_init: no matrix resident"); return SGL_ESTATE; }
+    for (auto c : M->local) SGLCHK(sgl_fit_init(c, k, w_init, synth_seed));
+    for (auto c : M->local) c->gene_nnz_global = false;
+    return team_gene_counts(M);
+}
+
+extern "C" int sgl_multi_iterate(sgl_multi* M, double L1_w, double L1_h, double L2_w, double L2_h, double* tol) {
+    TEAM_GUARD(M);
+    return team_iterate(M, L1_w, L1_h, L2_w, L2_h, tol);
+}
+
+extern "C" int sgl_multi_nmf_run(sgl_multi* M, double tol, int32_t maxit, double L1_w, double L1_h, double L2_w, double L2_h,
+                                 int32_t* n_iter, double* tol_trace, const sgl_callbacks* cb) {
+    TEAM_GUARD(M);
+    return team_nmf_run(M, tol, maxit, L1_w, L1_h, L2_w, L2_h, n_iter, tol_trace, cb);
+}
+
+extern "C" int sgl_multi_get_factors(sgl_multi* M, double* w, double* d, double* h) {
+    TEAM_GUARD(M);
+    if (M->cell_lo.empty()) { sgl_set_error("sgl_multi_get_factors: no matrix resident"); return SGL_ESTATE; }
+    const int k = M->local[0]->k;
+    SGLCHK(sgl_get_factors(M->local[0], w, d, nullptr));
+    if (h)
+        for (int r = 0; r < M->nranks; ++r) SGLCHK(sgl_get_factors(M->local[r], nullptr, nullptr, h + (size_t)M->cell_lo[r] * k));
+    return SGL_OK;
+}
+
+// c_nmf on all devices of this process: what sgl_c_nmf runs when SINGLET_NGPU asks for more than one
+int sgl_c_nmf_multi(int ndev, const double* Ax, const int32_t* Ai, const int32_t* Ap, int32_t nrow, int32_t ncol, double tol,
+                    uint16_t maxit, double L1_w, double L1_h, double L2_w, double L2_h, const double* w_init, int32_t k,
+                    double* w_out, double* d_out, double* h_out, int32_t* n_iter, double* tol_trace, const sgl_callbacks* cb) {
+    sgl_multi* M = nullptr;
+    SGLCHK(sgl_multi_create(ndev, nullptr, &M));
+    int rc = sgl_multi_upload_csc(M, Ax, Ai, Ap, nrow, ncol);
+    if (rc == SGL_OK) rc = sgl_multi_fit_init(M, k, w_init, 0);
+    if (rc == SGL_OK) rc = sgl_multi_nmf_run(M, tol, maxit, L1_w, L1_h, L2_w, L2_h, n_iter, tol_trace, cb);
+    if (rc == SGL_OK) rc = sgl_multi_get_factors(M, w_out, d_out, h_out);
+    sgl_multi_destroy(M);
+    return rc;
+}

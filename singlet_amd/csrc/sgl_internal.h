@@ -12,7 +12,7 @@
 
 #define SGL_WAVE 64
 #define SGL_MAX_K 256          // generic (wave-per-column) NNLS handles k <= 256
-#define SGL_LANE_NNLS_MAX_K 104  // lane-per-column NNLS: k <= 64 all in registers, k <= 104 with x in a memory scratch
+#define SGL_LANE_NNLS_MAX_K 128  // lane-per-column NNLS: k <= 64 all in registers, k <= 128 with x in a memory scratch
 
 void sgl_set_error(const char* fmt, ...);
 
@@ -94,7 +94,8 @@ struct sgl_ctx {
     bool use_tiled = false;
     int64_t cell_offset = 0, ncells_total = 0;
     int64_t* col_nnz_A = nullptr;   // n_local: nnz per cell (skip rule of predict, l.340)
-    int64_t* col_nnz_At = nullptr;  // m: GLOBAL nnz per gene (after all-reduce when sharded)
+    int64_t* col_nnz_At = nullptr;  // m: nnz per gene of THIS shard
+    int64_t* col_nnz_At_global = nullptr;  // m: nnz per gene over all shards (valid while gene_nnz_global)
     bool gene_nnz_global = false;
 
     int k = 0;
@@ -108,6 +109,11 @@ struct sgl_ctx {
     double* link_h = nullptr;  // c_linked_nmf: link_rows x ncol / x nrow multipliers of the right-hand sides
     double* link_w = nullptr;
     int link_h_rows = 0, link_w_rows = 0;
+    double* Gcols = nullptr;   // masked path: per-column Grams of one chunk of columns (gcols_chunk * k * k)
+    int64_t gcols_chunk = 0;
+    double* Wd = nullptr;      // mse_test: W' = W^T diag(d) as k x m
+    struct sgl_team* team = nullptr;   // native collective (multi.hip): the team this context is a rank of
+    int team_rank = 0;
     double* ws = nullptr;   // partial-reduction workspace
     size_t ws_bytes = 0;
     double* scalars = nullptr;       // device scratch for cor / mse results
@@ -125,6 +131,20 @@ struct sgl_ctx {
     double phase_ms[SGL_PH_COUNT] = {0};
     int64_t phase_calls[SGL_PH_COUNT] = {0};
 };
+
+// native team (multi.hip): ranks of a cell-sharded fit that exchange through RCCL (or, for ranks that
+// share one device inside one process, through a HIP kernel)
+int sgl_team_size(const sgl_ctx* c);   // 1 without a team
+// internals of singlet_hip.hip used by multi.hip
+int sgl_nnls_shared(sgl_ctx* c, const double* G, double* B, double* X, const int64_t* col_nnz, int64_t ncols,
+                    double L1, double L2, unsigned long long* counter);
+int sgl_scale_w_enqueue(sgl_ctx* c);            // scale(w, d); cor(w, w_prev) -> device scalar
+int sgl_scale_w_fetch(sgl_ctx* c, double* tol); // copy it out (synchronises the stream)
+int sgl_fetch_sweeps(sgl_ctx* c);
+void sgl_team_detach(sgl_ctx* c);               // called by sgl_destroy
+int sgl_c_nmf_multi(int ndev, const double* Ax, const int32_t* Ai, const int32_t* Ap, int32_t nrow, int32_t ncol, double tol,
+                    uint16_t maxit, double L1_w, double L1_h, double L2_w, double L2_h, const double* w_init, int32_t k,
+                    double* w_out, double* d_out, double* h_out, int32_t* n_iter, double* tol_trace, const sgl_callbacks* cb);
 
 // RAII-free phase timer helpers (driver side).
 int sgl_phase_begin(sgl_ctx* c, int phase, PhaseEvent* pe);
@@ -156,6 +176,9 @@ int k_rowsum(sgl_ctx* c, const double* F, int k, int64_t cols, double* d_out);  
 int k_scale_apply(hipStream_t s, double* F, int k, int64_t cols, double* d, int add_eps);
 int k_cor(sgl_ctx* c, const double* x, const double* y, int64_t n, double* out_dev);
 int k_pad_gram(hipStream_t s, const double* G, int k, int KP, int GS, double* Gpad);
+int k_gram_rescale(hipStream_t s, double* G, int k, const double* d, double diag_add);  // G[i,j] = G[i,j] / d_i / d_j (+ diag_add)
+int k_i64_to_f64(hipStream_t s, const int64_t* in, double* out, int64_t n);
+int k_f64_to_i64(hipStream_t s, const double* in, int64_t* out, int64_t n);
 int k_transpose_dense(hipStream_t s, const double* in, int rows, int cols, double* out);
 
 // sparse accumulate: B[:, c] (+)= sum_{nz in tile t of column c} x * F[:, row]

@@ -22,7 +22,7 @@ void sgl_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* sgl_last_error(void) { return g_err; }
-extern "C" int sgl_abi_version(void) { return 1; }
+extern "C" int sgl_abi_version(void) { return 2; }
 
 static bool device_is_gfx950(int dev) {
     hipDeviceProp_t prop;
@@ -142,6 +142,9 @@ static void free_fit(sgl_ctx* c) {
     dev_free(c->red);
     dev_free(c->G);
     dev_free(c->Gpad);
+    dev_free(c->Gcols);
+    c->gcols_chunk = 0;
+    dev_free(c->Wd);
     nnls_scratch_free(c->nnls_scr);
     dev_free(c->link_h);
     dev_free(c->link_w);
@@ -160,6 +163,7 @@ static void free_matrix(sgl_ctx* c) {
     free_csc(c->At);
     dev_free(c->col_nnz_A);
     dev_free(c->col_nnz_At);
+    dev_free(c->col_nnz_At_global);
     c->gene_nnz_global = false;
 }
 
@@ -188,13 +192,17 @@ extern "C" int sgl_create(int device, sgl_ctx** out) {
     sgl_ctx* c = new (std::nothrow) sgl_ctx();
     if (!c) { sgl_set_error("out of host memory"); return SGL_ENOMEM; }
     c->device = device;
-    HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    int rc = SGL_OK;
+    hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     c->stream = c->own_stream;
-    int rc = dev_alloc(&c->scalars, 16);
-    if (rc == SGL_OK) rc = dev_alloc(&c->sweep_counters, 8);
+    if (e == hipSuccess) {
+        rc = dev_alloc(&c->scalars, 16);
+        if (rc == SGL_OK) rc = dev_alloc(&c->sweep_counters, 8);
+        if (rc == SGL_OK) e = hipMemsetAsync(c->sweep_counters, 0, 8 * sizeof(unsigned long long), c->stream);
+        if (rc == SGL_OK && e == hipSuccess) e = hipHostMalloc((void**)&c->pinned, 16 * sizeof(double), hipHostMallocDefault);
+    }
+    if (rc == SGL_OK && e != hipSuccess) { (void)hipGetLastError(); sgl_set_error("sgl_create: %s", hipGetErrorString(e)); rc = SGL_EHIP; }
     if (rc != SGL_OK) { sgl_destroy(c); return rc; }
-    HIPCHK(hipMemsetAsync(c->sweep_counters, 0, 8 * sizeof(unsigned long long), c->stream));
-    HIPCHK(hipHostMalloc((void**)&c->pinned, 16 * sizeof(double), hipHostMallocDefault));
     *out = c;
     return SGL_OK;
 }
@@ -202,9 +210,10 @@ extern "C" int sgl_create(int device, sgl_ctx** out) {
 extern "C" int sgl_destroy(sgl_ctx* c) {
     if (!c) return SGL_OK;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)drain_timing(c);
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
+    sgl_team_detach(c);
     free_fit(c);
     free_matrix(c);
     dev_free(c->ws);
@@ -226,8 +235,12 @@ extern "C" int sgl_set_stream(sgl_ctx* c, void* hip_stream) {
 
 extern "C" int sgl_set_allreduce(sgl_ctx* c, sgl_allreduce_fn fn, void* user) {
     CTX_GUARD(c);
+    if (c->team) { sgl_set_error("sgl_set_allreduce: the context belongs to a native team (sgl_multi_* / sgl_comm_init_rank)"); return SGL_ESTATE; }
     c->allreduce = fn;
     c->allreduce_user = user;
+    // which W columns predict() skips (l.340) depends on the gene counts over ALL shards: they are
+    // (re)computed through the new hook on the next W-update; without a hook the local counts apply
+    c->gene_nnz_global = false;
     return SGL_OK;
 }
 
@@ -261,14 +274,16 @@ static int upload_one(sgl_ctx* c, DevCSC& M, const double* x, const int32_t* i, 
     HIPCHK(hipMemcpyAsync(M.i, i, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice, c->stream));
     int32_t* p32 = nullptr;
     SGLCHK(dev_alloc(&p32, (size_t)ncol + 1));
-    HIPCHK(hipMemcpyAsync(p32, p, sizeof(int32_t) * ((size_t)ncol + 1), hipMemcpyHostToDevice, c->stream));
-    int rc = k_widen_p(c->stream, p32, (int64_t)ncol + 1, M.p);
+    int rc = SGL_OK;
+    if (hipMemcpyAsync(p32, p, sizeof(int32_t) * ((size_t)ncol + 1), hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = SGL_EHIP;
+    if (rc == SGL_OK) rc = k_widen_p(c->stream, p32, (int64_t)ncol + 1, M.p);
     // the kernels index factor rows by these values: refuse anything that is not a valid dgCMatrix
     int flag = 0;
     if (rc == SGL_OK) rc = k_validate_csc(c->stream, M.i, M.p, ncol, nrow, reinterpret_cast<int*>(p32));
     if (rc == SGL_OK && hipMemcpyAsync(&flag, p32, sizeof(int), hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = SGL_EHIP;
-    HIPCHK(hipStreamSynchronize(c->stream));
+    if (hipStreamSynchronize(c->stream) != hipSuccess && rc == SGL_OK) rc = SGL_EHIP;
     dev_free(p32);
+    if (rc == SGL_EHIP) { sgl_set_error("upload: a HIP call failed: %s", hipGetErrorString(hipGetLastError())); return rc; }
     if (rc == SGL_OK && flag != 0) {
         sgl_set_error("not a valid dgCMatrix: %s%s", (flag & 1) ? "row index outside [0, nrow) " : "",
                       (flag & 2) ? "row indices not strictly ascending within a column" : "");
@@ -455,32 +470,38 @@ extern "C" int sgl_weight_by_split(sgl_ctx* c, const int32_t* split_by, int32_t 
     return rc;
 }
 
-extern "C" int sgl_fit_init(sgl_ctx* c, int32_t k, const double* w_init, uint64_t synth_seed) {
-    CTX_GUARD(c);
-    if (!c->A.p || !c->At.p) { sgl_set_error("sgl_fit_init: no matrix resident"); return SGL_ESTATE; }
-    if (k <= 0 || k > SGL_MAX_K) { sgl_set_error("rank k=%d unsupported (1..%d)", k, SGL_MAX_K); return SGL_EINVAL; }
-    HIPCHK(hipStreamSynchronize(c->stream));
-    free_fit(c);
+// Genes per rank block of a native team (multi.hip): the W-side solve is dealt out in contiguous gene
+// blocks of this many columns (the last ranks' blocks may be partly or wholly past the end).
+static int64_t team_gene_block(const sgl_ctx* c) {
+    const int64_t m = c->A.nrow;
+    const int n = sgl_team_size(c);
+    return n > 1 ? (m + n - 1) / n : m;
+}
+
+static int fit_init_impl(sgl_ctx* c, int32_t k, const double* w_init, uint64_t synth_seed) {
     const int64_t m = c->A.nrow, n = c->A.ncol;
-    c->k = k;
-    SGLCHK(dev_alloc(&c->W, (size_t)k * m + 2));
+    // buffers exchanged by reduce-scatter / all-gather hold team_size equal gene blocks
+    const int64_t mpad = team_gene_block(c) * std::max(1, sgl_team_size(c));
+    SGLCHK(dev_alloc(&c->W, (size_t)k * mpad + 2));
     SGLCHK(dev_alloc(&c->Wprev, (size_t)k * m));
     SGLCHK(dev_alloc(&c->H, (size_t)k * n + 2));
     SGLCHK(dev_alloc(&c->d, (size_t)k));
     SGLCHK(dev_alloc(&c->B, (size_t)k * n));
-    SGLCHK(dev_alloc(&c->red, (size_t)k * m + (size_t)k * k + (size_t)k));
+    SGLCHK(dev_alloc(&c->red, (size_t)k * mpad + (size_t)k * k + (size_t)k));
     SGLCHK(dev_alloc(&c->G, (size_t)k * k));
-    const int KP = lane_kp(k);
-    SGLCHK(dev_alloc(&c->Gpad, (size_t)112 * 112 + 64));
+    SGLCHK(dev_alloc(&c->Gpad, (size_t)SGL_LANE_NNLS_MAX_K * (SGL_LANE_NNLS_MAX_K + 16) + 64));
     {
         const int64_t cap = std::max<int64_t>(c->A.ncol, c->A.nrow);
         if (k <= SGL_LANE_NNLS_MAX_K) SGLCHK(nnls_scratch_alloc(c->nnls_scr, cap, k));
     }
+    HIPCHK(hipMemsetAsync(c->W, 0, sizeof(double) * ((size_t)k * mpad + 2), c->stream));
+    HIPCHK(hipMemsetAsync(c->red, 0, sizeof(double) * ((size_t)k * mpad + (size_t)k * k + (size_t)k), c->stream));
     if (w_init) HIPCHK(hipMemcpyAsync(c->W, w_init, sizeof(double) * (size_t)k * m, hipMemcpyHostToDevice, c->stream));
     else SGLCHK(k_synth_winit(c->stream, synth_seed, k, (int32_t)m, c->W));
     HIPCHK(hipMemsetAsync(c->H, 0, sizeof(double) * (size_t)k * n, c->stream));
     std::vector<double> ones((size_t)k, 1.0);
     HIPCHK(hipMemcpyAsync(c->d, ones.data(), sizeof(double) * k, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));  // `ones` leaves scope
     SGLCHK(build_tiles(c, c->A, k));
     SGLCHK(build_tiles(c, c->At, k));
     // LDS-tiled accumulate (lanes over the factor rows): k <= 128
@@ -490,29 +511,49 @@ extern "C" int sgl_fit_init(sgl_ctx* c, int32_t k, const double* w_init, uint64_
         if (c->At.nnz > 0) SGLCHK(sgl_tiled_build(c, c->At, tiled_part_size(k), c->TAt));
         c->use_tiled = true;
     }
-    // global per-gene non-zero counts decide which W columns predict() skips (l.340)
-    if (c->allreduce && !c->gene_nnz_global) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SGL_OK;
+}
+
+extern "C" int sgl_fit_init(sgl_ctx* c, int32_t k, const double* w_init, uint64_t synth_seed) {
+    CTX_GUARD(c);
+    if (!c->A.p || !c->At.p) { sgl_set_error("sgl_fit_init: no matrix resident"); return SGL_ESTATE; }
+    if (k <= 0 || k > SGL_MAX_K) { sgl_set_error("rank k=%d unsupported (1..%d)", k, SGL_MAX_K); return SGL_EINVAL; }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    free_fit(c);
+    const int rc = fit_init_impl(c, k, w_init, synth_seed);
+    if (rc != SGL_OK) { free_fit(c); return rc; }   // a half-built fit must not pass FIT_GUARD
+    c->k = k;
+    return SGL_OK;
+}
+
+// Which W columns predict(At, h, w) skips (src/singlet.cpp:340) is decided by a gene's non-zero count
+// over ALL shards.  With an all-reduce hook installed the global counts are built on first use (and
+// again after every sgl_set_allreduce); without one the local counts are the global ones.
+static int gene_counts(sgl_ctx* c, const int64_t** out) {
+    *out = c->col_nnz_At;
+    if (c->team) {  // native team: multi.hip all-reduces the counts for all its ranks at once
+        if (sgl_team_size(c) > 1) {
+            if (!c->gene_nnz_global) { sgl_set_error("native team: global gene counts missing (sgl_team_gene_counts)"); return SGL_ESTATE; }
+            *out = c->col_nnz_At_global;
+        }
+        return SGL_OK;
+    }
+    if (!c->allreduce) return SGL_OK;
+    if (!c->gene_nnz_global) {
+        const int64_t m = c->A.nrow;
+        if (!c->col_nnz_At_global) SGLCHK(dev_alloc(&c->col_nnz_At_global, (size_t)m));
         double* tmp = nullptr;  // counts as doubles through the f64 all-reduce hook (exact below 2^53)
         SGLCHK(dev_alloc(&tmp, (size_t)m));
-        std::vector<int64_t> hc((size_t)m);
-        HIPCHK(hipMemcpyAsync(hc.data(), c->col_nnz_At, sizeof(int64_t) * m, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
-        std::vector<double> hd((size_t)m);
-        for (int64_t g = 0; g < m; ++g) hd[g] = (double)hc[g];
-        HIPCHK(hipMemcpyAsync(tmp, hd.data(), sizeof(double) * m, hipMemcpyHostToDevice, c->stream));
-        int rc = do_allreduce(c, tmp, m);
-        if (rc == SGL_OK) {
-            HIPCHK(hipMemcpyAsync(hd.data(), tmp, sizeof(double) * m, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(hipStreamSynchronize(c->stream));
-            for (int64_t g = 0; g < m; ++g) hc[g] = (int64_t)hd[g];
-            HIPCHK(hipMemcpyAsync(c->col_nnz_At, hc.data(), sizeof(int64_t) * m, hipMemcpyHostToDevice, c->stream));
-            HIPCHK(hipStreamSynchronize(c->stream));
-            c->gene_nnz_global = true;
-        }
+        int rc = k_i64_to_f64(c->stream, c->col_nnz_At, tmp, m);
+        if (rc == SGL_OK) rc = do_allreduce(c, tmp, m);
+        if (rc == SGL_OK) rc = k_f64_to_i64(c->stream, tmp, c->col_nnz_At_global, m);
+        if (hipStreamSynchronize(c->stream) != hipSuccess && rc == SGL_OK) { sgl_set_error("gene counts: stream error"); rc = SGL_EHIP; }
         dev_free(tmp);
         SGLCHK(rc);
+        c->gene_nnz_global = true;
     }
-    HIPCHK(hipStreamSynchronize(c->stream));
+    *out = c->col_nnz_At_global;
     return SGL_OK;
 }
 
@@ -523,7 +564,7 @@ extern "C" int sgl_fit_init(sgl_ctx* c, int32_t k, const double* w_init, uint64_
     } while (0)
 
 // NNLS dispatch for a Gram shared by all columns.
-static int nnls_shared(sgl_ctx* c, const double* G, double* B, double* X, const int64_t* col_nnz, int64_t ncols,
+int sgl_nnls_shared(sgl_ctx* c, const double* G, double* B, double* X, const int64_t* col_nnz, int64_t ncols,
                        double L1, double L2, unsigned long long* counter) {
     const int k = c->k;
     if (k <= SGL_LANE_NNLS_MAX_K) {
@@ -551,13 +592,14 @@ extern "C" int sgl_step_h(sgl_ctx* c, double L1, double L2) {
       else SGLCHK(k_acc(c->stream, c->A, c->W, k, c->B, 0, 1, 0, 0, 0));
       if (c->link_h) SGLCHK(k_link_mul(c->stream, c->B, c->link_h, k, c->link_h_rows, c->A.ncol)); }  // predict_link l.429-430
     { Phase ph(c, SGL_PH_NNLS_H);
-      SGLCHK(nnls_shared(c, c->G, c->B, c->H, c->solve_empty ? nullptr : c->col_nnz_A, c->A.ncol, L1, L2, c->sweep_counters + 0)); }
+      SGLCHK(sgl_nnls_shared(c, c->G, c->B, c->H, c->solve_empty ? nullptr : c->col_nnz_A, c->A.ncol, L1, L2, c->sweep_counters + 0)); }
     return SGL_OK;
 }
 
 // scale(h, d): src/singlet.cpp:219-225; row sums are global over all shards
 extern "C" int sgl_step_scale_h(sgl_ctx* c) {
     FIT_GUARD(c);
+    if (c->team && sgl_team_size(c) > 1) { sgl_set_error("step API on a native team: use sgl_nmf_iterate / sgl_multi_iterate"); return SGL_ESTATE; }
     { Phase ph(c, SGL_PH_SCALE); SGLCHK(k_rowsum(c, c->H, c->k, c->A.ncol, c->d)); }
     SGLCHK(do_allreduce(c, c->d, c->k));
     { Phase ph(c, SGL_PH_SCALE); SGLCHK(k_scale_apply(c->stream, c->H, c->k, c->A.ncol, c->d, 1)); }
@@ -568,10 +610,13 @@ extern "C" int sgl_step_scale_h(sgl_ctx* c) {
 // one all-reduce of [k*m | k*k] doubles when sharded.
 extern "C" int sgl_step_w(sgl_ctx* c, double L1, double L2) {
     FIT_GUARD(c);
+    if (c->team && sgl_team_size(c) > 1) { sgl_set_error("step API on a native team: use sgl_nmf_iterate / sgl_multi_iterate"); return SGL_ESTATE; }
     const int k = c->k;
     const int64_t m = c->A.nrow;
     double* Bw = c->red;
     double* Gh = c->red + (size_t)k * m;
+    const int64_t* gene_nnz = nullptr;
+    SGLCHK(gene_counts(c, &gene_nnz));
     { Phase ph(c, SGL_PH_RHS_W);
       if (c->use_tiled && c->TAt.roff) SGLCHK(k_acc_tiled_all(c->stream, c->TAt, c->H, Bw, k));
       else SGLCHK(k_acc(c->stream, c->At, c->H, k, Bw, 0, 1, 0, 0, 0)); }
@@ -583,28 +628,35 @@ extern "C" int sgl_step_w(sgl_ctx* c, double L1, double L2) {
       SGLCHK(k_gram_add_diag(c->stream, c->G, k, 1e-15)); }
     { Phase ph(c, SGL_PH_NNLS_W);
       if (c->link_w) SGLCHK(k_link_mul(c->stream, Bw, c->link_w, k, c->link_w_rows, m));  // on the complete (all-reduced) sums
-      SGLCHK(nnls_shared(c, c->G, Bw, c->W, c->solve_empty ? nullptr : c->col_nnz_At, m, L1, L2, c->sweep_counters + 1)); }
+      SGLCHK(sgl_nnls_shared(c, c->G, Bw, c->W, c->solve_empty ? nullptr : gene_nnz, m, L1, L2, c->sweep_counters + 1)); }
     return SGL_OK;
 }
 
 // scale(w, d); tol = cor(w, w_it): src/singlet.cpp:655-659
-extern "C" int sgl_step_scale_w(sgl_ctx* c, double* tol_out) {
-    FIT_GUARD(c);
+int sgl_scale_w_enqueue(sgl_ctx* c) {
     const int k = c->k;
     const int64_t m = c->A.nrow;
-    {
-        Phase ph(c, SGL_PH_SCALE);
-        SGLCHK(k_rowsum(c, c->W, k, m, c->d));
-        SGLCHK(k_scale_apply(c->stream, c->W, k, m, c->d, 1));
-        SGLCHK(k_cor(c, c->W, c->Wprev, (int64_t)k * m, c->scalars));
-    }
+    Phase ph(c, SGL_PH_SCALE);
+    SGLCHK(k_rowsum(c, c->W, k, m, c->d));
+    SGLCHK(k_scale_apply(c->stream, c->W, k, m, c->d, 1));
+    SGLCHK(k_cor(c, c->W, c->Wprev, (int64_t)k * m, c->scalars));
+    return SGL_OK;
+}
+
+int sgl_scale_w_fetch(sgl_ctx* c, double* tol_out) {
     HIPCHK(hipMemcpyAsync(c->pinned, c->scalars, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     if (tol_out) *tol_out = c->pinned[0];
     return SGL_OK;
 }
 
-static int fetch_sweeps(sgl_ctx* c) {
+extern "C" int sgl_step_scale_w(sgl_ctx* c, double* tol_out) {
+    FIT_GUARD(c);
+    SGLCHK(sgl_scale_w_enqueue(c));
+    return sgl_scale_w_fetch(c, tol_out);
+}
+
+int sgl_fetch_sweeps(sgl_ctx* c) {
     unsigned long long h[4] = {0, 0, 0, 0};
     HIPCHK(hipMemcpyAsync(h, c->sweep_counters, sizeof(h), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -623,17 +675,21 @@ extern "C" int sgl_nmf_run(sgl_ctx* c, double tol, int32_t maxit, double L1_w, d
     int it = 0;
     // for (iter_ = 0; iter_ < maxit && tol_ > tol; ++iter_)  -- src/singlet.cpp:647
     for (; it < maxit && tol_ > tol; ++it) {
-        SGLCHK(sgl_step_begin(c));
-        SGLCHK(sgl_step_h(c, L1_h, L2_h));
-        SGLCHK(sgl_step_scale_h(c));
-        if (cb && cb->poll && cb->poll(cb->user)) { sgl_set_error("interrupted"); return SGL_EINTR; }
-        SGLCHK(sgl_step_w(c, L1_w, L2_w));
-        SGLCHK(sgl_step_scale_w(c, &tol_));
+        if (c->team) {  // native team (one process per GPU): the team iteration of multi.hip
+            SGLCHK(sgl_nmf_iterate(c, L1_w, L1_h, L2_w, L2_h, &tol_));
+        } else {
+            SGLCHK(sgl_step_begin(c));
+            SGLCHK(sgl_step_h(c, L1_h, L2_h));
+            SGLCHK(sgl_step_scale_h(c));
+            if (cb && cb->poll && cb->poll(cb->user)) { sgl_set_error("interrupted"); return SGL_EINTR; }
+            SGLCHK(sgl_step_w(c, L1_w, L2_w));
+            SGLCHK(sgl_step_scale_w(c, &tol_));
+        }
         if (tol_trace) tol_trace[it] = tol_;
         if (cb && cb->log) cb->log(cb->user, it + 1, tol_, NAN);
         if (cb && cb->poll && cb->poll(cb->user)) { sgl_set_error("interrupted"); return SGL_EINTR; }
     }
-    SGLCHK(fetch_sweeps(c));
+    SGLCHK(sgl_fetch_sweeps(c));
     if (n_iter) *n_iter = it;
     return SGL_OK;
 }
@@ -667,59 +723,61 @@ extern "C" int sgl_set_factors(sgl_ctx* c, const double* w, const double* d, con
 }
 
 // ------------------------------------------------------------- masked path --
+#define SGL_MASK_MAX_K 128   // rank limit of the masked (ARD) path: the Gram downdate kernels cover k <= 128
+
+// workspace of the masked path, kept in the fit (allocated on first use, freed with the fit)
+static int mask_workspace(sgl_ctx* c) {
+    const int k = c->k;
+    if (!c->Gcols) {
+        const int64_t widest = std::max<int64_t>(c->A.ncol, c->At.ncol);
+        const int64_t chunk = std::max<int64_t>(256, std::min<int64_t>(widest, ((int64_t)256 << 20) / ((int64_t)k * k * 8)));
+        SGLCHK(dev_alloc(&c->Gcols, (size_t)chunk * k * k));
+        c->gcols_chunk = chunk;
+    }
+    if (!c->Wd) SGLCHK(dev_alloc(&c->Wd, (size_t)k * c->A.nrow));
+    return SGL_OK;
+}
+
 // predict_mask (src/singlet.cpp:436-466) for one orientation, columns in
 // chunks so the per-column Grams a_i (k*k doubles each) stay bounded.
 static int predict_mask_dev(sgl_ctx* c, const DevCSC& M, const int64_t* col_nnz, const double* F, double* X,
                             double* Bbuf, uint64_t seed, uint64_t inv_density, double L1, double L2, int mask_t,
                             int rhs_phase, int nnls_phase, unsigned long long* counter) {
     const int k = c->k;
+    SGLCHK(mask_workspace(c));
     // hash argument order: A pass draw(cell = col + cell_offset, gene = row); At pass draw(cell = row + cell_offset, gene = col)
     const int64_t col_off = mask_t ? 0 : c->cell_offset;
     const int64_t row_off = mask_t ? c->cell_offset : 0;
     { Phase ph(c, SGL_PH_GRAM); SGLCHK(k_gram(c, F, k, M.nrow, c->G, 1e-15)); }
     { Phase ph(c, rhs_phase);
       SGLCHK(k_acc(c->stream, M, F, k, Bbuf, seed, inv_density, mask_t ? 2 : 1, col_off, row_off)); }
-    const int64_t chunk = std::max<int64_t>(256, std::min<int64_t>(M.ncol, ((int64_t)256 << 20) / ((int64_t)k * k * 8)));
-    double* Gcols = nullptr;
-    SGLCHK(dev_alloc(&Gcols, (size_t)chunk * k * k));
-    int rc = SGL_OK;
-    for (int64_t c0 = 0; c0 < M.ncol && rc == SGL_OK; c0 += chunk) {
+    const int64_t chunk = c->gcols_chunk;
+    for (int64_t c0 = 0; c0 < M.ncol; c0 += chunk) {
         const int64_t nc = std::min<int64_t>(chunk, M.ncol - c0);
         { Phase ph(c, SGL_PH_MASK);
-          rc = k_mask_gram_cols(c->stream, c0, nc, M.nrow, col_nnz, F, c->G, k, seed, inv_density, mask_t, col_off, row_off, Gcols); }
-        if (rc != SGL_OK) break;
+          SGLCHK(k_mask_gram_cols(c->stream, c0, nc, M.nrow, col_nnz, F, c->G, k, seed, inv_density, mask_t, col_off, row_off, c->Gcols)); }
         { Phase ph(c, nnls_phase);
-          rc = k_nnls_wave(c->stream, Gcols, (int64_t)k * k, Bbuf + (size_t)c0 * k, X + (size_t)c0 * k,
-                           col_nnz ? col_nnz + c0 : nullptr, k, nc, L1, L2, counter); }
+          SGLCHK(k_nnls_wave(c->stream, c->Gcols, (int64_t)k * k, Bbuf + (size_t)c0 * k, X + (size_t)c0 * k,
+                             col_nnz ? col_nnz + c0 : nullptr, k, nc, L1, L2, counter)); }
     }
-    hipError_t e = hipStreamSynchronize(c->stream);
-    dev_free(Gcols);
-    if (rc == SGL_OK && e != hipSuccess) { sgl_set_error("masked predict failed: %s", hipGetErrorString(e)); rc = SGL_EHIP; }
-    return rc;
+    return SGL_OK;
 }
 
 static int mse_test_dev(sgl_ctx* c, uint64_t seed, uint64_t inv_density, double* out) {
     const int k = c->k;
     const int64_t m = c->A.nrow;
-    double* Wd = nullptr;
-    SGLCHK(dev_alloc(&Wd, (size_t)k * m));
-    int rc;
+    SGLCHK(mask_workspace(c));
     {
         Phase ph(c, SGL_PH_MASK);
-        rc = k_wd(c->stream, c->W, c->d, k, m, Wd);
-        if (rc == SGL_OK) rc = k_mse_test(c, Wd, c->H, k, seed, inv_density, c->scalars + 1);
+        SGLCHK(k_wd(c->stream, c->W, c->d, k, m, c->Wd));
+        SGLCHK(k_mse_test(c, c->Wd, c->H, k, seed, inv_density, c->scalars + 1));
     }
-    if (rc == SGL_OK) rc = do_allreduce(c, c->scalars + 1, 1);
-    if (rc == SGL_OK) {
-        hipError_t e = hipMemcpyAsync(c->pinned + 1, c->scalars + 1, sizeof(double), hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) { sgl_set_error("mse_test copy failed: %s", hipGetErrorString(e)); rc = SGL_EHIP; }
-    } else {
-        (void)hipStreamSynchronize(c->stream);
-    }
-    dev_free(Wd);
-    if (rc == SGL_OK) *out = c->pinned[1] / (double)c->ncells_total;  // losses.sum() / h.cols(), l.567
-    return rc;
+    SGLCHK(do_allreduce(c, c->scalars + 1, 1));
+    hipError_t e = hipMemcpyAsync(c->pinned + 1, c->scalars + 1, sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { (void)hipGetLastError(); sgl_set_error("mse_test copy failed: %s", hipGetErrorString(e)); return SGL_EHIP; }
+    *out = c->pinned[1] / (double)c->ncells_total;  // losses.sum() / h.cols(), l.567
+    return SGL_OK;
 }
 
 extern "C" int sgl_op_mse_test(sgl_ctx* c, uint64_t seed, uint64_t inv_density, double* out) {
@@ -734,12 +792,11 @@ extern "C" int sgl_ard_run(sgl_ctx* c, double tol, int32_t maxit, double L1, dou
                            int32_t* iter, double* tol_out, double* score_overfit, int32_t* n_trace, int32_t* n_iter,
                            const sgl_callbacks* cb) {
     FIT_GUARD(c);
-    if (c->allreduce) { sgl_set_error("the masked (ARD) path is not cell-sharded yet; run it on one shard"); return SGL_EINVAL; }
+    if (c->allreduce || c->team) { sgl_set_error("the masked (ARD) path is not cell-sharded yet; run it on one shard"); return SGL_EINVAL; }
+    if (c->k > SGL_MASK_MAX_K) { sgl_set_error("c_ard_nmf: rank %d above the masked path's limit of %d", c->k, SGL_MASK_MAX_K); return SGL_EINVAL; }
     if (trace_test_mse <= 0 || inv_density == 0 || !test_mse || !iter || !tol_out || !score_overfit || !n_trace) {
         sgl_set_error("sgl_ard_run: bad arguments"); return SGL_EINVAL;
     }
-    const int k = c->k;
-    const int64_t m = c->A.nrow;
     double tol_ = 1.0;
     int nt = 0;
     int it = 0;
@@ -764,7 +821,6 @@ extern "C" int sgl_ard_run(sgl_ctx* c, double tol, int32_t maxit, double L1, dou
         SGLCHK(predict_mask_dev(c, c->At, c->col_nnz_At, c->H, c->W, c->red, seed, inv_density, L1, L2, 1,
                                 SGL_PH_RHS_W, SGL_PH_NNLS_W, c->sweep_counters + 1));
         SGLCHK(sgl_step_scale_w(c, &tol_));
-        (void)k; (void)m;
         if (it % trace_test_mse == 0) {
             SGLCHK(push_trace(it));
             if (cb && cb->log) cb->log(cb->user, it + 1, tol_, score_overfit[nt - 1]);
@@ -775,7 +831,7 @@ extern "C" int sgl_ard_run(sgl_ctx* c, double tol, int32_t maxit, double L1, dou
         if (cb && cb->poll && cb->poll(cb->user)) { sgl_set_error("interrupted"); return SGL_EINTR; }
     }
     if (it % trace_test_mse != 0) SGLCHK(push_trace(it));
-    SGLCHK(fetch_sweeps(c));
+    SGLCHK(sgl_fetch_sweeps(c));
     *n_trace = nt;
     if (n_iter) *n_iter = it;
     return SGL_OK;
@@ -800,6 +856,15 @@ extern "C" int sgl_c_nmf(const double* Ax, const int32_t* Ai, const int32_t* Ap,
                          const sgl_callbacks* cb) {
     (void)verbose; (void)threads;
     if (!w_init || !w_out || !d_out || !h_out) { sgl_set_error("sgl_c_nmf: NULL factor buffer"); return SGL_EINVAL; }
+    // SINGLET_NGPU=N (N > 1): shard the cells over the first N devices of this process (section 2b of the
+    // header); the R side does not change.  Asking for more devices than there are is an error, not a fallback.
+    if (const char* e = getenv("SINGLET_NGPU")) {
+        const int want = atoi(e);
+        if (want > 1) {
+            if (want > sgl_device_count()) { sgl_set_error("SINGLET_NGPU=%d but only %d gfx950 device(s) are visible", want, sgl_device_count()); return SGL_ENODEV; }
+            return sgl_c_nmf_multi(want, Ax, Ai, Ap, nrow, ncol, tol, maxit, L1_w, L1_h, L2_w, L2_h, w_init, k, w_out, d_out, h_out, n_iter, tol_trace, cb);
+        }
+    }
     CtxHolder hd;
     SGLCHK(sgl_create(current_device_or_zero(), &hd.c));
     SGLCHK(sgl_upload_csc(hd.c, Ax, Ai, Ap, Atx, Ati, Atp, nrow, ncol, 0, ncol));
@@ -814,19 +879,22 @@ extern "C" int sgl_c_nmf(const double* Ax, const int32_t* Ai, const int32_t* Ap,
 extern "C" int sgl_set_links(sgl_ctx* c, const double* link_h, int32_t link_h_rows, int32_t link_h_cols, const double* link_w,
                              int32_t link_w_rows, int32_t link_w_cols) {
     FIT_GUARD(c);
+    if (c->team && (link_h || link_w)) { sgl_set_error("sgl_set_links: linked NMF is not supported on a native team; use the all-reduce hook"); return SGL_EINVAL; }
     dev_free(c->link_h);
     dev_free(c->link_w);
     c->link_h = c->link_w = nullptr;
     c->link_h_rows = c->link_w_rows = 0;
     if (link_h && link_h_cols == c->A.ncol && link_h_rows > 0) {
-        const int rows = std::min<int>(link_h_rows, c->k);
+        if (link_h_rows > c->k) { sgl_set_error("sgl_set_links: link_h has more rows (%d) than the rank (%d)", link_h_rows, c->k); return SGL_EINVAL; }
         SGLCHK(dev_alloc(&c->link_h, (size_t)link_h_rows * link_h_cols));
         HIPCHK(hipMemcpyAsync(c->link_h, link_h, sizeof(double) * (size_t)link_h_rows * link_h_cols, hipMemcpyHostToDevice, c->stream));
         c->link_h_rows = link_h_rows;
-        if (rows != link_h_rows) { sgl_set_error("sgl_set_links: link_h has more rows (%d) than the rank (%d)", link_h_rows, c->k); return SGL_EINVAL; }
     }
     if (link_w && link_w_cols == c->A.nrow && link_w_rows > 0) {
-        if (link_w_rows > c->k) { sgl_set_error("sgl_set_links: link_w has more rows (%d) than the rank (%d)", link_w_rows, c->k); return SGL_EINVAL; }
+        if (link_w_rows > c->k) {
+            dev_free(c->link_h); c->link_h_rows = 0;
+            sgl_set_error("sgl_set_links: link_w has more rows (%d) than the rank (%d)", link_w_rows, c->k); return SGL_EINVAL;
+        }
         SGLCHK(dev_alloc(&c->link_w, (size_t)link_w_rows * link_w_cols));
         HIPCHK(hipMemcpyAsync(c->link_w, link_w, sizeof(double) * (size_t)link_w_rows * link_w_cols, hipMemcpyHostToDevice, c->stream));
         c->link_w_rows = link_w_rows;
@@ -890,6 +958,7 @@ extern "C" int sgl_c_ard_nmf(const double* Ax, const int32_t* Ai, const int32_t*
                              const sgl_callbacks* cb) {
     (void)verbose; (void)threads;
     if (!w_init || !w_out || !d_out || !h_out) { sgl_set_error("sgl_c_ard_nmf: NULL factor buffer"); return SGL_EINVAL; }
+    if (k > SGL_MASK_MAX_K) { sgl_set_error("c_ard_nmf: rank %d above the masked path's limit of %d", k, SGL_MASK_MAX_K); return SGL_EINVAL; }
     CtxHolder hd;
     SGLCHK(sgl_create(current_device_or_zero(), &hd.c));
     SGLCHK(sgl_upload_csc(hd.c, Ax, Ai, Ap, Atx, Ati, Atp, nrow, ncol, 0, ncol));
@@ -954,21 +1023,33 @@ extern "C" int sgl_rcpp_predict(const double* Ax, const int32_t* Ai, const int32
 }
 
 // ------------------------------------------------------------ operators -----
+// device buffer released on every return path
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t n) { return dev_alloc(&p, n); }
+};
+// finish an operator: synchronise the stream, map a pending HIP error
+static int op_finish(sgl_ctx* c, int rc, const char* what) {
+    const hipError_t e = hipStreamSynchronize(c->stream);
+    if (rc == SGL_OK && e != hipSuccess) { (void)hipGetLastError(); sgl_set_error("%s: %s", what, hipGetErrorString(e)); return SGL_EHIP; }
+    return rc;
+}
+
 extern "C" int sgl_op_rand(sgl_ctx* c, uint64_t state, const uint64_t* i, const uint64_t* j, int64_t n, uint64_t* out) {
     CTX_GUARD(c);
     if (n < 0 || (n > 0 && (!i || !j || !out))) { sgl_set_error("sgl_op_rand: bad arguments"); return SGL_EINVAL; }
     if (n == 0) return SGL_OK;
-    uint64_t *di = nullptr, *dj = nullptr, *dout = nullptr;
-    SGLCHK(dev_alloc(&di, (size_t)n));
-    SGLCHK(dev_alloc(&dj, (size_t)n));
-    SGLCHK(dev_alloc(&dout, (size_t)n));
-    HIPCHK(hipMemcpyAsync(di, i, sizeof(uint64_t) * n, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(dj, j, sizeof(uint64_t) * n, hipMemcpyHostToDevice, c->stream));
-    int rc = k_rand(c->stream, state, di, dj, n, dout);
-    HIPCHK(hipMemcpyAsync(out, dout, sizeof(uint64_t) * n, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    dev_free(di); dev_free(dj); dev_free(dout);
-    return rc;
+    DevBuf<uint64_t> di, dj, dout;
+    SGLCHK(di.alloc((size_t)n));
+    SGLCHK(dj.alloc((size_t)n));
+    SGLCHK(dout.alloc((size_t)n));
+    HIPCHK(hipMemcpyAsync(di.p, i, sizeof(uint64_t) * n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(dj.p, j, sizeof(uint64_t) * n, hipMemcpyHostToDevice, c->stream));
+    int rc = k_rand(c->stream, state, di.p, dj.p, n, dout.p);
+    if (rc == SGL_OK) HIPCHK(hipMemcpyAsync(out, dout.p, sizeof(uint64_t) * n, hipMemcpyDeviceToHost, c->stream));
+    return op_finish(c, rc, "sgl_op_rand");
 }
 
 extern "C" int sgl_op_mask(sgl_ctx* c, uint64_t state, uint64_t inv_density, int64_t cell0, int32_t ncells,
@@ -977,27 +1058,23 @@ extern "C" int sgl_op_mask(sgl_ctx* c, uint64_t state, uint64_t inv_density, int
     if (ncells < 0 || ngenes < 0 || inv_density == 0 || !out) { sgl_set_error("sgl_op_mask: bad arguments"); return SGL_EINVAL; }
     const size_t n = (size_t)ncells * (size_t)ngenes;
     if (n == 0) return SGL_OK;
-    uint8_t* dout = nullptr;
-    SGLCHK(dev_alloc(&dout, n));
-    int rc = k_mask(c->stream, state, inv_density, cell0, ncells, ngenes, dout);
-    HIPCHK(hipMemcpyAsync(out, dout, n, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    dev_free(dout);
-    return rc;
+    DevBuf<uint8_t> dout;
+    SGLCHK(dout.alloc(n));
+    int rc = k_mask(c->stream, state, inv_density, cell0, ncells, ngenes, dout.p);
+    if (rc == SGL_OK) HIPCHK(hipMemcpyAsync(out, dout.p, n, hipMemcpyDeviceToHost, c->stream));
+    return op_finish(c, rc, "sgl_op_mask");
 }
 
 extern "C" int sgl_op_gram(sgl_ctx* c, const double* F, int32_t k, int64_t cols, double* G) {
     CTX_GUARD(c);
     if (!F || !G || k <= 0 || cols < 0) { sgl_set_error("sgl_op_gram: bad arguments"); return SGL_EINVAL; }
-    double *dF = nullptr, *dG = nullptr;
-    SGLCHK(dev_alloc(&dF, (size_t)k * cols));
-    SGLCHK(dev_alloc(&dG, (size_t)k * k));
-    HIPCHK(hipMemcpyAsync(dF, F, sizeof(double) * (size_t)k * cols, hipMemcpyHostToDevice, c->stream));
-    int rc = k_gram(c, dF, k, cols, dG, 1e-15);
-    HIPCHK(hipMemcpyAsync(G, dG, sizeof(double) * (size_t)k * k, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    dev_free(dF); dev_free(dG);
-    return rc;
+    DevBuf<double> dF, dG;
+    SGLCHK(dF.alloc((size_t)k * cols));
+    SGLCHK(dG.alloc((size_t)k * k));
+    HIPCHK(hipMemcpyAsync(dF.p, F, sizeof(double) * (size_t)k * cols, hipMemcpyHostToDevice, c->stream));
+    int rc = k_gram(c, dF.p, k, cols, dG.p, 1e-15);
+    if (rc == SGL_OK) HIPCHK(hipMemcpyAsync(G, dG.p, sizeof(double) * (size_t)k * k, hipMemcpyDeviceToHost, c->stream));
+    return op_finish(c, rc, "sgl_op_gram");
 }
 
 extern "C" int sgl_op_rhs(sgl_ctx* c, int which, const double* F, int32_t k, double* B) {
@@ -1006,30 +1083,29 @@ extern "C" int sgl_op_rhs(sgl_ctx* c, int which, const double* F, int32_t k, dou
     DevCSC& M = (which & 1) ? c->At : c->A;
     if (!M.p) { sgl_set_error("no matrix resident"); return SGL_ESTATE; }
     if (!F || !B || k <= 0 || k > SGL_MAX_K || (tiled && tiled_part_size(k) == 0)) { sgl_set_error("sgl_op_rhs: bad arguments"); return SGL_EINVAL; }
-    double *dF = nullptr, *dB = nullptr;
-    SGLCHK(dev_alloc(&dF, (size_t)k * M.nrow + 2));
-    SGLCHK(dev_alloc(&dB, (size_t)k * M.ncol));
-    HIPCHK(hipMemcpyAsync(dF, F, sizeof(double) * (size_t)k * M.nrow, hipMemcpyHostToDevice, c->stream));
+    DevBuf<double> dF, dB;
+    SGLCHK(dF.alloc((size_t)k * M.nrow + 2));
+    SGLCHK(dB.alloc((size_t)k * M.ncol));
+    HIPCHK(hipMemcpyAsync(dF.p, F, sizeof(double) * (size_t)k * M.nrow, hipMemcpyHostToDevice, c->stream));
     int rc;
     if (tiled) {
         DevTiled S;
         rc = sgl_tiled_build(c, M, tiled_part_size(k), S);
-        if (rc == SGL_OK) rc = k_acc_tiled_all(c->stream, S, dF, dB, k);
-        HIPCHK(hipMemcpyAsync(B, dB, sizeof(double) * (size_t)k * M.ncol, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
+        if (rc == SGL_OK) rc = k_acc_tiled_all(c->stream, S, dF.p, dB.p, k);
+        if (rc == SGL_OK && hipMemcpyAsync(B, dB.p, sizeof(double) * (size_t)k * M.ncol, hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = SGL_EHIP;
+        rc = op_finish(c, rc, "sgl_op_rhs");
         sgl_tiled_free(S);
     } else {
         // tiles depend on k: build a temporary table unless a fit with the same k owns one
         int64_t* saved = M.seg; int32_t str = M.tile_rows, snt = M.ntiles;
         M.seg = nullptr;
         rc = build_tiles(c, M, k);
-        if (rc == SGL_OK) rc = k_acc(c->stream, M, dF, k, dB, 0, 1, 0, 0, 0);
-        HIPCHK(hipMemcpyAsync(B, dB, sizeof(double) * (size_t)k * M.ncol, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
+        if (rc == SGL_OK) rc = k_acc(c->stream, M, dF.p, k, dB.p, 0, 1, 0, 0, 0);
+        if (rc == SGL_OK && hipMemcpyAsync(B, dB.p, sizeof(double) * (size_t)k * M.ncol, hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = SGL_EHIP;
+        rc = op_finish(c, rc, "sgl_op_rhs");
         dev_free(M.seg);
         M.seg = saved; M.tile_rows = str; M.ntiles = snt;
     }
-    dev_free(dF); dev_free(dB);
     return rc;
 }
 
@@ -1037,65 +1113,59 @@ extern "C" int sgl_op_nnls(sgl_ctx* c, const double* G, const double* B, double*
                            double L1, double L2, int32_t* sweeps_out) {
     CTX_GUARD(c);
     if (!G || !B || !X || k <= 0 || k > SGL_MAX_K || ncols < 0) { sgl_set_error("sgl_op_nnls: bad arguments"); return SGL_EINVAL; }
-    double *dG = nullptr, *dB = nullptr, *dX = nullptr, *dGp = nullptr;
-    SGLCHK(dev_alloc(&dG, (size_t)k * k));
-    SGLCHK(dev_alloc(&dB, (size_t)k * ncols));
-    SGLCHK(dev_alloc(&dX, (size_t)k * ncols));
-    HIPCHK(hipMemcpyAsync(dG, G, sizeof(double) * (size_t)k * k, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(dB, B, sizeof(double) * (size_t)k * ncols, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(dX, X, sizeof(double) * (size_t)k * ncols, hipMemcpyHostToDevice, c->stream));
+    DevBuf<double> dG, dB, dX, dGp;
+    SGLCHK(dG.alloc((size_t)k * k));
+    SGLCHK(dB.alloc((size_t)k * ncols));
+    SGLCHK(dX.alloc((size_t)k * ncols));
+    HIPCHK(hipMemcpyAsync(dG.p, G, sizeof(double) * (size_t)k * k, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(dB.p, B, sizeof(double) * (size_t)k * ncols, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(dX.p, X, sizeof(double) * (size_t)k * ncols, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemsetAsync(c->sweep_counters + 4, 0, 4 * sizeof(unsigned long long), c->stream));
     int rc;
+    NnlsScratch scr;  // re-pack passes only pay off (and are only used) for many columns
     if (k <= SGL_LANE_NNLS_MAX_K) {
         const int KP = lane_kp(k);
-        rc = dev_alloc(&dGp, (size_t)112 * 112 + 64);
-        if (rc == SGL_OK) rc = k_pad_gram(c->stream, dG, k, KP, nnls_gram_stride(KP), dGp);
-        NnlsScratch scr;  // re-pack passes only pay off (and are only used) for many columns
+        rc = dGp.alloc((size_t)SGL_LANE_NNLS_MAX_K * (SGL_LANE_NNLS_MAX_K + 16) + 64);
+        if (rc == SGL_OK) rc = k_pad_gram(c->stream, dG.p, k, KP, nnls_gram_stride(KP), dGp.p);
         if (rc == SGL_OK && (ncols >= nnls_repack_min_cols() || k > 64)) rc = nnls_scratch_alloc(scr, ncols, k);
-        if (rc == SGL_OK) rc = k_nnls_lane(c->stream, dGp, KP, dB, dX, nullptr, k, ncols, L1, L2, c->sweep_counters + 4, &scr);
-        if (rc == SGL_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = SGL_EHIP;
-        nnls_scratch_free(scr);
+        if (rc == SGL_OK) rc = k_nnls_lane(c->stream, dGp.p, KP, dB.p, dX.p, nullptr, k, ncols, L1, L2, c->sweep_counters + 4, &scr);
     } else {
-        rc = k_nnls_wave(c->stream, dG, 0, dB, dX, nullptr, k, ncols, L1, L2, c->sweep_counters + 4);
+        rc = k_nnls_wave(c->stream, dG.p, 0, dB.p, dX.p, nullptr, k, ncols, L1, L2, c->sweep_counters + 4);
     }
     unsigned long long sw = 0;
-    HIPCHK(hipMemcpyAsync(X, dX, sizeof(double) * (size_t)k * ncols, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(&sw, c->sweep_counters + 4, sizeof(sw), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    if (rc == SGL_OK && (hipMemcpyAsync(X, dX.p, sizeof(double) * (size_t)k * ncols, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                         hipMemcpyAsync(&sw, c->sweep_counters + 4, sizeof(sw), hipMemcpyDeviceToHost, c->stream) != hipSuccess)) rc = SGL_EHIP;
+    rc = op_finish(c, rc, "sgl_op_nnls");
+    nnls_scratch_free(scr);
     if (sweeps_out) *sweeps_out = (int32_t)sw;
-    dev_free(dG); dev_free(dB); dev_free(dX); dev_free(dGp);
     return rc;
 }
 
 extern "C" int sgl_op_scale(sgl_ctx* c, double* F, int32_t k, int64_t cols, double* d) {
     CTX_GUARD(c);
     if (!F || !d || k <= 0 || cols < 0) { sgl_set_error("sgl_op_scale: bad arguments"); return SGL_EINVAL; }
-    double *dF = nullptr, *dd = nullptr;
-    SGLCHK(dev_alloc(&dF, (size_t)k * cols));
-    SGLCHK(dev_alloc(&dd, (size_t)k));
-    HIPCHK(hipMemcpyAsync(dF, F, sizeof(double) * (size_t)k * cols, hipMemcpyHostToDevice, c->stream));
-    int rc = k_rowsum(c, dF, k, cols, dd);
-    if (rc == SGL_OK) rc = k_scale_apply(c->stream, dF, k, cols, dd, 1);
-    HIPCHK(hipMemcpyAsync(F, dF, sizeof(double) * (size_t)k * cols, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(d, dd, sizeof(double) * (size_t)k, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    dev_free(dF); dev_free(dd);
-    return rc;
+    DevBuf<double> dF, dd;
+    SGLCHK(dF.alloc((size_t)k * cols));
+    SGLCHK(dd.alloc((size_t)k));
+    HIPCHK(hipMemcpyAsync(dF.p, F, sizeof(double) * (size_t)k * cols, hipMemcpyHostToDevice, c->stream));
+    int rc = k_rowsum(c, dF.p, k, cols, dd.p);
+    if (rc == SGL_OK) rc = k_scale_apply(c->stream, dF.p, k, cols, dd.p, 1);
+    if (rc == SGL_OK && (hipMemcpyAsync(F, dF.p, sizeof(double) * (size_t)k * cols, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                         hipMemcpyAsync(d, dd.p, sizeof(double) * (size_t)k, hipMemcpyDeviceToHost, c->stream) != hipSuccess)) rc = SGL_EHIP;
+    return op_finish(c, rc, "sgl_op_scale");
 }
 
 extern "C" int sgl_op_cor(sgl_ctx* c, const double* x, const double* y, int64_t n, double* out) {
     CTX_GUARD(c);
     if (!x || !y || !out || n <= 0) { sgl_set_error("sgl_op_cor: bad arguments"); return SGL_EINVAL; }
-    double *dx = nullptr, *dy = nullptr;
-    SGLCHK(dev_alloc(&dx, (size_t)n));
-    SGLCHK(dev_alloc(&dy, (size_t)n));
-    HIPCHK(hipMemcpyAsync(dx, x, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(dy, y, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream));
-    int rc = k_cor(c, dx, dy, n, c->scalars + 2);
-    HIPCHK(hipMemcpyAsync(out, c->scalars + 2, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    dev_free(dx); dev_free(dy);
-    return rc;
+    DevBuf<double> dx, dy;
+    SGLCHK(dx.alloc((size_t)n));
+    SGLCHK(dy.alloc((size_t)n));
+    HIPCHK(hipMemcpyAsync(dx.p, x, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(dy.p, y, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    int rc = k_cor(c, dx.p, dy.p, n, c->scalars + 2);
+    if (rc == SGL_OK && hipMemcpyAsync(out, c->scalars + 2, sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = SGL_EHIP;
+    return op_finish(c, rc, "sgl_op_cor");
 }
 
 // --------------------------------------------------------------- timing -----
@@ -1119,7 +1189,7 @@ extern "C" int sgl_timing_get(sgl_ctx* c, double* ms, int64_t* calls, int reset)
 
 extern "C" int sgl_sweeps_get(sgl_ctx* c, int64_t* out4, int reset) {
     CTX_GUARD(c);
-    SGLCHK(fetch_sweeps(c));
+    SGLCHK(sgl_fetch_sweeps(c));
     for (int q = 0; q < 4; ++q) {
         if (out4) out4[q] = c->sweeps_acc[q];
         if (reset) c->sweeps_acc[q] = 0;

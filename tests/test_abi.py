@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol(sa):
     for n in _declared():
         assert hasattr(L, n), "libsinglet_hip.so does not export %s" % n
     assert sorted(_lib.SIGNATURES) == _declared(), "python binding and header disagree"
-    assert _lib.load().sgl_abi_version() == 1
+    assert _lib.load().sgl_abi_version() == 2
 
 
 def test_no_cpu_fallback(sa):

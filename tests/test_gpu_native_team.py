@@ -1,0 +1,111 @@
+"""The library's native multi-GPU path (include/singlet_hip.h section 2b, multi.hip): cells sharded over
+the ranks of a team, ONE grouped collective (reduce-scatter of the W-side right-hand sides by gene
+blocks + all-reduce of [Gram | row sums] of the unscaled h) and one all-gather of the w blocks per
+iteration.  On a 1-GPU box the team logic runs with the ranks sharing the device (exchange by a HIP
+kernel instead of RCCL, which refuses duplicate devices) and RCCL itself runs as a team of one."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import rel_fro, same_zero_pattern, to_dgc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("m,n,k,ranks", [(300, 1000, 8, 2), (257, 700, 30, 3), (500, 640, 50, 2), (130, 900, 70, 4), (96, 400, 5, 7)])
+def test_team_on_one_device_matches_the_oracle_and_the_single_shard(sa, ora, m, n, k, ranks):
+    A = ora.synth_csc(m, n, 20)
+    At = A.t()
+    w0 = ora.synth_winit(k, m)
+    ref = ora.c_nmf(A, At, 0.0, 4, 0.01, 0.01, 0.0, 0.0, 0, w0)
+    one = sa.c_nmf(to_dgc(sa, A), None, 0.0, 4, False, 0.01, 0.01, 0.0, 0.0, 0, w0.T)
+    with sa.Multi([0] * ranks) as M:
+        M.upload(to_dgc(sa, A))
+        M.fit_init(k, w0)
+        it, tols = M.nmf_run(0.0, 4, 0.01, 0.01, 0.0, 0.0)
+        W, d, H = M.get_factors()
+        # every rank holds the same w, d bit for bit
+        for r in range(1, ranks):
+            Wr, dr, _ = M.rank_ctx(r).get_factors(h=False)
+            assert np.array_equal(Wr, W) and np.array_equal(dr, d)
+    assert it == 4
+    assert rel_fro(W, ref["w"]) < 1e-9 and rel_fro(H, ref["h"]) < 1e-9 and rel_fro(d, ref["d"]) < 1e-9
+    assert same_zero_pattern(W, ref["w"]) and same_zero_pattern(H, ref["h"])
+    # against the one-shard GPU fit: the scaling is applied after the sums -> rounding only
+    assert rel_fro(W, one["w"].T) < 1e-11 and rel_fro(H, one["h"].T) < 1e-11
+    assert np.allclose(tols, one["tol"], rtol=1e-9, atol=0)
+
+
+def test_team_skips_genes_empty_in_all_shards_only(sa, ora):
+    """A gene with no entry in ONE shard but entries elsewhere must still be solved (global counts decide,
+    src/singlet.cpp:340); a gene empty everywhere keeps its stale column on every rank."""
+    m, n, k = 60, 400, 6
+    A = ora.synth_csc(m, n, 4)
+    x, i, p = A.x.copy(), A.i.copy(), A.p.copy()
+    keep = np.ones(x.shape[0], dtype=bool)
+    col_of = np.repeat(np.arange(n), np.diff(p))
+    keep &= ~((i == 7) & (col_of < n // 2))     # gene 7: only in the second half of the cells
+    keep &= ~(i == 11)                          # gene 11: nowhere
+    cnt = np.bincount(col_of[keep], minlength=n)
+    A2 = ora.CSC(x[keep], i[keep], np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32), m, n)
+    w0 = ora.synth_winit(k, m)
+    ref = ora.c_nmf(A2, A2.t(), 0.0, 3, 0.01, 0.01, 0.0, 0.0, 0, w0)
+    with sa.Multi([0, 0]) as M:
+        M.upload(to_dgc(sa, A2))
+        M.fit_init(k, w0)
+        M.nmf_run(0.0, 3, 0.01, 0.01, 0.0, 0.0)
+        W, d, H = M.get_factors()
+    assert rel_fro(W, ref["w"]) < 1e-9 and rel_fro(H, ref["h"]) < 1e-9
+
+
+def test_rccl_team_of_one_matches_plain_run(sa, ora):
+    """RCCL itself (ncclCommInitAll / ncclCommInitRank, grouped reduce-scatter + all-reduce, all-gather on
+    the compute stream) with the one device this box has: same factors as the plain loop to rounding."""
+    m, n, k = 400, 900, 24
+    A = ora.synth_csc(m, n, 20)
+    w0 = ora.synth_winit(k, m)
+    one = sa.c_nmf(to_dgc(sa, A), None, 0.0, 3, False, 0.01, 0.01, 0.0, 0.0, 0, w0.T)
+    with sa.Multi([0]) as M:                      # ncclCommInitAll
+        M.upload(to_dgc(sa, A))
+        M.fit_init(k, w0)
+        M.nmf_run(0.0, 3, 0.01, 0.01, 0.0, 0.0)
+        W, d, H = M.get_factors()
+    assert rel_fro(W, one["w"].T) < 1e-11 and rel_fro(H, one["h"].T) < 1e-11 and rel_fro(d, one["d"]) < 1e-11
+    c = sa.Context(0)                             # ncclCommInitRank
+    try:
+        c.comm_init_rank(1, 0, sa.comm_unique_id())
+        c.upload(to_dgc(sa, A))
+        c.fit_init(k, w0)
+        tols = [c.nmf_iterate(0.01, 0.01, 0.0, 0.0) for _ in range(3)]
+        W2, d2, H2 = c.get_factors()
+    finally:
+        c.close()
+    assert np.array_equal(W2, W) and np.array_equal(H2, H) and np.array_equal(d2, d)
+    assert np.allclose(tols, one["tol"], rtol=1e-9, atol=0)
+
+
+def test_c_nmf_honours_singlet_ngpu(sa, ora, monkeypatch):
+    """SINGLET_NGPU above the device count is an error (no silent fallback); = 1 is the plain path."""
+    A = ora.synth_csc(50, 80, 5)
+    w0 = ora.synth_winit(4, 50)
+    monkeypatch.setenv("SINGLET_NGPU", "64")
+    with pytest.raises(sa.SingletHipError):
+        sa.c_nmf(to_dgc(sa, A), None, 0.0, 2, False, 0.01, 0.01, 0.0, 0.0, 0, w0.T)
+    monkeypatch.setenv("SINGLET_NGPU", "1")
+    r = sa.c_nmf(to_dgc(sa, A), None, 0.0, 2, False, 0.01, 0.01, 0.0, 0.0, 0, w0.T)
+    assert r["iter"] == 2
+
+
+def test_team_refuses_what_it_does_not_support(sa, ora):
+    A = ora.synth_csc(40, 90, 5)
+    with sa.Multi([0, 0]) as M:
+        M.upload(to_dgc(sa, A))
+        M.fit_init(4, ora.synth_winit(4, 40))
+        c = M.rank_ctx(0)
+        with pytest.raises(sa.SingletHipError):
+            c.set_allreduce(lambda p, n: None)          # a team rank cannot take a hook
+        with pytest.raises(sa.SingletHipError):
+            c.step_w(0.0, 0.0)                          # step API is per shard; the team iterates as a whole
+        with pytest.raises(sa.SingletHipError):
+            c.ard_run(0.0, 2, 0.01, 0.0, 1, 20, 1e9, 1)  # masked path is not sharded
