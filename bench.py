@@ -8,9 +8,12 @@
 A step = one ALS iteration (H-update, scale, W-update, scale, cor) over the
 whole matrix, inputs resident in HBM (generated on the device by the hash
 generator of SURVEY.md 8(d)).  For N > 1 the cells are sharded over the ranks
-(strong scaling: the same 1M x 30k problem) with two all-reduces per iteration
-over RCCL: k row sums, then [k x genes right-hand sides | k x k Gram].
-Rank 0 prints ONE JSON line.
+(strong scaling: the same 1M x 30k problem); the exchange runs inside the
+library over RCCL (--comm native, the default for N > 1): one grouped
+collective per iteration (reduce-scatter of the k x genes right-hand sides by
+gene blocks + all-reduce of [k x k Gram | k row sums]) and one all-gather of
+the solved W blocks.  --comm hook keeps round 1's path (two all-reduces through
+torch.distributed).  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -36,65 +39,133 @@ def parse():
     ap.add_argument("--inv-density", type=int, default=20)
     ap.add_argument("--L1", type=float, default=0.01)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-cells", type=int, default=16000)
+    ap.add_argument("--cpu-sample-cells", type=int, default=200000, help="cells of the CPU baseline sample (0 = all)")
+    ap.add_argument("--comm", choices=("auto", "native", "hook", "none"), default="auto",
+                    help="exchange between the ranks: native = RCCL inside the library (sgl_comm_init_rank), hook = "
+                         "torch.distributed all-reduce through sgl_set_allreduce, auto = none for one rank, native otherwise")
+    ap.add_argument("--native-comm", action="store_true", help="same as --comm native (with one rank: an RCCL team of one)")
     ap.add_argument("--force-allreduce", action="store_true",
                     help="with one rank: still create the RCCL process group and route the two per-iteration sums through "
-                         "the all-reduce hook (plumbing check of the multi-GPU path on a 1-GPU box)")
+                         "the all-reduce hook (plumbing check of the hook path on a 1-GPU box)")
     return ap.parse_args()
 
 
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(args):
-    """The oracle (restatement of singlet's OpenMP path) timed on this host's cores on a
-    bounded sample: the first `cpu_sample_cells` cells of the same synthetic matrix, all genes,
-    same k / penalties.  Per-cell phases are scaled to the full cell count; the per-gene part
-    (the W-side NNLS, independent of the number of cells) is separated with a second,
-    half-size run and NOT scaled."""
+    """The oracle (line-by-line restatement of singlet's OpenMP path, oracle/singlet_oracle.c) MEASURED on
+    this host's cores on a bounded sample of the same workload: the first `cpu_sample_cells` cells
+    (default 200 000 = the slice SURVEY.md 8d prescribes; --cpu-sample-cells 0 = all cells) x all genes,
+    same k / penalties, A and t(A) in host memory.  One warm-up iteration, then ALS iterations 2-3 timed
+    inside the C code (omp_get_wtime per phase).  Two builds of the same source: gcc -O2 (R's default
+    level, what `value` reports) and -O3 -march=native (the generous variant).  When the sample is not
+    the whole matrix the per-cell phases are scaled to the full cell count; the part of predict(At)
+    that does not grow with the cells (the m NNLS solves of the W-update) is separated with a second,
+    half-size run and not scaled."""
+    import ctypes as C
+    import subprocess
     import numpy as np
     from oracle import oracle as ora
-    ns = min(args.cpu_sample_cells, args.cells)
+    ns = args.cells if args.cpu_sample_cells <= 0 else min(args.cpu_sample_cells, args.cells)
     t0 = time.perf_counter()
     full = ora.synth_csc(args.genes, ns, args.inv_density)
-    half = ora.CSC(full.x[:full.p[ns // 2]], full.i[:full.p[ns // 2]], full.p[:ns // 2 + 1], args.genes, ns // 2)
     w0 = ora.synth_winit(args.k, args.genes)
+    full_t = full.t()
     gen_s = time.perf_counter() - t0
-    res = {}
-    for name, A in (("full", full), ("half", half)):
-        At = A.t()
-        # 1 warm-up iteration then 2 timed (fresh call each: the oracle has no resume)
-        r1 = ora.c_nmf(A, At, 0.0, 1, args.L1, args.L1, 0.0, 0.0, 0, w0, timing=True)
-        r3 = ora.c_nmf(A, At, 0.0, 3, args.L1, args.L1, 0.0, 0.0, 0, w0, timing=True)
-        res[name] = (r3["phase_sec"] - r1["phase_sec"]) / 2.0, (r3["sweeps"] - r1["sweeps"]) / 2.0
-    (pf, sf), (ph, _) = res["full"], res["half"]
+
+    def timed_run(A, At, lib=None):
+        """-> (phase seconds per iteration [4], sweeps per iteration [2]) of ALS iterations 2-3"""
+        L = lib or ora.lib()
+        L.ora_set_timing_skip(1)
+        try:
+            if lib is None:
+                r = ora.c_nmf(A, At, 0.0, 3, args.L1, args.L1, 0.0, 0.0, 0, w0, timing=True)
+                return r["phase_sec"] / 2.0, r["sweeps"] / 2.0
+            f64p, i32p, i64p = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+            L.ora_c_nmf.restype = C.c_int
+            L.ora_c_nmf.argtypes = ora.lib().ora_c_nmf.argtypes
+            w = np.array(w0, dtype=np.float64, order="C")
+            h, d = np.empty((A.ncol, args.k)), np.empty(args.k)
+            tr, ph, sw = np.zeros(3), np.zeros(4), np.zeros(2, dtype=np.int64)
+            P = lambda a, t: a.ctypes.data_as(t)  # noqa: E731
+            L.ora_c_nmf(P(A.x, f64p), P(A.i, i32p), P(A.p, i32p), P(At.x, f64p), P(At.i, i32p), P(At.p, i32p), A.nrow,
+                        A.ncol, 0.0, 3, args.L1, args.L1, 0.0, 0.0, 0, args.k, P(w, f64p), P(h, f64p), P(d, f64p),
+                        P(tr, f64p), P(ph, f64p), P(sw, i64p))
+            return ph / 2.0, sw / 2.0
+        finally:
+            L.ora_set_timing_skip(0)
+
+    pf, sf = timed_run(full, full_t)
     scale = args.cells / ns
-    # predict(At) = a * cells + b  (b = the m NNLS solves of the W-update)
-    a = (pf[2] - ph[2]) / (ns - ns // 2)
-    b = max(pf[2] - a * ns, 0.0)
-    t_full = (pf[0] + pf[1]) * scale + a * args.cells + b + pf[3]
+    b = 0.0
+    if ns < args.cells:
+        nh = ns // 2
+        half = ora.CSC(full.x[:full.p[nh]], full.i[:full.p[nh]], full.p[:nh + 1], args.genes, nh)
+        ph, _ = timed_run(half, half.t())
+        # predict(At) = a * cells + b  (b = the m NNLS solves of the W-update)
+        a = (pf[2] - ph[2]) / (ns - nh)
+        b = min(max(pf[2] - a * ns, 0.0), pf[2])
+
+    def full_size(p, bb):
+        return (p[0] + p[1]) * scale + (p[2] - bb) * scale + bb + p[3]
+
+    t_full = full_size(pf, b)
     cores = ora.lib().ora_max_threads()
-    return {
-        "value": 1.0 / t_full, "unit": "iter/s", "cores": int(cores), "kind": "port",
-        "sample": ("oracle/singlet_oracle.c (gcc -O2 -fopenmp, restatement of singlet's OpenMP path), first %d of %d "
-                   "cells x %d genes, k=%d; ALS iterations 2-3 timed (%.2f s/iter on the sample: predict(A) %.2f, "
-                   "scale(h) %.3f, predict(At) %.2f, scale(w)+cor %.3f); per-cell phases scaled x%.1f, the W-side NNLS "
-                   "(%.2f s, from a half-size run) not scaled; mean NNLS sweeps H %.1f W %.1f; generation %.1f s not timed"
-                   % (ns, args.cells, args.genes, args.k, float(pf.sum()), pf[0], pf[1], pf[2], pf[3], scale, b,
-                      sf[0] / ns, sf[1] / args.genes, gen_s)),
+    out = {
+        "value": 1.0 / t_full, "unit": "iter/s", "cores": int(cores), "kind": "port", "cpu_model": _cpu_model(),
+        "build": "gcc -O2 -fopenmp -ffp-contract=off",
         "sample_sec_per_iter": float(pf.sum()), "est_full_sec_per_iter": float(t_full),
+        "sample_phases_sec": {"predict_A": float(pf[0]), "scale_h": float(pf[1]), "predict_At": float(pf[2]),
+                              "scale_w_cor": float(pf[3])},
+        "nnls_mean_sweeps": {"h": float(sf[0]) / ns, "w": float(sf[1]) / args.genes},
     }
+    try:  # the generous build, compiled for THIS host
+        odir = os.path.join(ROOT, "oracle")
+        subprocess.check_call(["make", "-C", odir, "libsinglet_oracle_native.so"], stdout=subprocess.DEVNULL,
+                              stderr=subprocess.DEVNULL)
+        Ln = C.CDLL(os.path.join(odir, "libsinglet_oracle_native.so"))
+        Ln.ora_set_timing_skip.argtypes = [C.c_int]
+        pn, _ = timed_run(full, full_t, Ln)
+        bn = b * (pn[2] / pf[2]) if pf[2] > 0 else 0.0
+        out["native_build"] = {"build": "gcc -O3 -march=native -fopenmp -ffp-contract=off", "value": 1.0 / full_size(pn, bn),
+                               "sample_sec_per_iter": float(pn.sum())}
+    except Exception as e:  # noqa: BLE001
+        out["native_build"] = {"error": repr(e)}
+    what = "all %d cells (full)" % ns if ns == args.cells else "%d cells (first %d of %d)" % (ns, ns, args.cells)
+    out["sample"] = ("oracle/singlet_oracle.c, restatement of singlet's OpenMP path, %d threads on %s; %s x %d genes, k=%d; "
+                     "1 warm-up + ALS iterations 2-3 timed in C: %.2f s/iter on the sample (predict(A) %.2f, scale(h) %.3f, "
+                     "predict(At) %.2f, scale(w)+cor %.3f)%s; generation + transpose %.1f s not timed"
+                     % (cores, out["cpu_model"], what, args.genes, args.k, float(pf.sum()), pf[0], pf[1], pf[2], pf[3],
+                        "" if ns == args.cells else "; per-cell phases scaled x%.1f, the W-side NNLS (%.2f s, from a "
+                        "half-size run) not scaled" % (scale, b), gen_s))
+    return out
 
 
-def measured_traffic(args, world, dom):
+def measured_traffic(args, world, dom, lay):
     """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (FETCH_SIZE and
-    WRITE_SIZE, separate runs, corrected as MI355X_MICROARCH.md prescribes): counters cannot be read
-    from inside this process, so the figure measured by scripts/prof_r1.sh on this exact workload is
-    kept in profiles/traffic.json and reported only when the workload matches; otherwise null."""
+    WRITE_SIZE, separate runs, corrected as MI355X_MICROARCH.md prescribes).  Counters cannot be read
+    from inside this process, so the figure measured by scripts/prof_r2.sh is kept in
+    profiles/traffic.json together with the workload AND the entry-stream layout it was measured on
+    (entries, tiles, tile ranges): it is reported only when both match this run, otherwise null."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             t = json.load(f)
         w = t["workload"]
-        if world == 1 and all(w[key] == getattr(args, key) for key in ("genes", "cells", "k", "inv_density")):
+        if world != 1 or not all(w[key] == getattr(args, key) for key in ("genes", "cells", "k", "inv_density")):
+            return None
+        want = t["layout"][dom]
+        if all(int(want[key]) == int(lay[key]) for key in ("entries", "tiles", "tile_rows", "tile_ranges")):
             return t["bytes_per_launch"][dom]
-    except (OSError, KeyError, ValueError):
+    except (OSError, KeyError, ValueError, TypeError):
         pass
     return None
 
@@ -113,8 +184,17 @@ def main():
     import singlet_amd as sa
 
     torch.cuda.set_device(local_rank)
+    mode = args.comm
+    if args.native_comm:
+        mode = "native"
+    if args.force_allreduce:
+        mode = "hook"
+    if mode == "auto":
+        mode = "native" if world > 1 else "none"
+    if world > 1 and mode == "none":
+        raise SystemExit("--comm none needs a single rank")
     dist = None
-    if world > 1 or args.force_allreduce:
+    if world > 1 or mode == "hook":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29541")
@@ -135,7 +215,34 @@ def main():
     ctx.set_stream(stream.cuda_stream)
 
     from singlet_amd.sharded import shard_by_count, torch_allreduce_hook
-    if dist is not None:
+    comm_note = None
+    if mode == "native":
+        # rank 0 makes the RCCL id, the host side broadcasts its 128 bytes, every rank joins with its context;
+        # a rank that cannot (RCCL missing ...) makes ALL ranks take the hook path, and the JSON line says so
+        err = None
+        try:
+            ids = [sa.comm_unique_id() if rank == 0 else None]
+            if dist is not None:
+                dist.broadcast_object_list(ids, src=0)
+            ctx.comm_init_rank(world, rank, ids[0])
+        except Exception as e:  # noqa: BLE001
+            err = repr(e)
+        failed = 1 if err else 0
+        if dist is not None:
+            flag = torch.tensor([failed], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            failed = int(flag[0])
+        if failed:
+            if world == 1:
+                raise SystemExit("native comm failed: %s" % err)
+            print("bench.py: native comm failed on some rank (%s): ALL ranks use the torch all-reduce hook" % err,
+                  file=sys.stderr, flush=True)
+            comm_note = "native init failed (%s)" % (err or "on another rank")
+            ctx.close()
+            ctx = sa.Context(local_rank)
+            ctx.set_stream(stream.cuda_stream)
+            mode = "hook"
+    if mode == "hook":
         ctx.set_allreduce(torch_allreduce_hook(dist, torch.device("cuda", local_rank)))
 
     # contiguous equal-count cell blocks: the synthetic columns are i.i.d., so equal counts are equal
@@ -149,11 +256,7 @@ def main():
     ctx.fit_init(args.k, None)
 
     def step():
-        ctx.step_begin()
-        ctx.step_h(args.L1, 0.0)
-        ctx.step_scale_h()
-        ctx.step_w(args.L1, 0.0)
-        return ctx.step_scale_w()
+        return ctx.nmf_iterate(args.L1, args.L1, 0.0, 0.0)
 
     for _ in range(args.warmup):
         step()
@@ -203,7 +306,7 @@ def main():
         stream_bytes = lay["entries"] * 12 + lay["col_blocks"] * lay["tiles"] * (32 + 8)
         out_bytes = 8 * k * ncols_dom * (lay["tile_ranges"] + (2 if lay["tile_ranges"] > 1 else 0))
         staged_bytes = 8 * k * nrows_dom * ((lay["col_blocks"] + 7) // 8)
-        traffic = measured_traffic(args, world, dom)
+        traffic = measured_traffic(args, world, dom, lay)
         out = {
             "metric": "ALS iterations/sec (1M cells x 30k genes, 5% nnz, k=50)",
             "value": args.steps / elapsed, "unit": "iter/s", "n_gpus": world, "steps": args.steps,
@@ -222,6 +325,11 @@ def main():
                          "whole_iteration": {"algorithmic_bytes": bytes_iter, "achieved": bytes_iter / (ms_step * 1e-3) / 1e9 / world,
                                              "frac": bytes_iter / (ms_step * 1e-3) / 1e9 / world / HBM_PEAK_GBS}},
             "phases_ms_per_step": ph_ms,
+            "comm": {"mode": mode, "note": comm_note,
+                     "per_iteration": {"none": "no exchange (one shard)",
+                                       "native": "RCCL inside the library: 1 grouped collective (reduce-scatter k x genes by gene "
+                                                 "blocks + all-reduce [k x k | k]) + 1 all-gather of the W blocks",
+                                       "hook": "2 all-reduces through torch.distributed (k row sums; [k x genes | k x k])"}[mode]},
             "tol_last": tols[-1], "generate_s": gen_s,
         }
         # mean sweeps per column, and mean sweeps each 64-column wave actually ran (its slowest column)

@@ -11,7 +11,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libsinglet_oracle.so")
+# ORACLE_SO selects another build of the same source (bench.py's -O3 -march=native timing variant)
+_SO = os.environ.get("ORACLE_SO", os.path.join(_HERE, "libsinglet_oracle.so"))
 
 _f64p = C.POINTER(C.c_double)
 _i32p = C.POINTER(C.c_int32)
@@ -21,7 +22,8 @@ _u8p = C.POINTER(C.c_uint8)
 
 def build(force=False):
     src = os.path.join(_HERE, "singlet_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    default = os.path.join(_HERE, "libsinglet_oracle.so")
+    if force or not os.path.exists(default) or os.path.getmtime(default) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", _HERE, "-B", "libsinglet_oracle.so"], stdout=subprocess.DEVNULL)
     return _SO
 
@@ -91,6 +93,8 @@ def lib():
         L.ora_transpose.restype = None
         L.ora_transpose.argtypes = csc + [C.c_int32, C.c_int32, _f64p, _i32p, _i32p]
         L.ora_max_threads.restype = C.c_int
+        L.ora_set_timing_skip.restype = None
+        L.ora_set_timing_skip.argtypes = [C.c_int]
         _lib = L
     return _lib
 

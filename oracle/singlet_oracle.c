@@ -355,6 +355,10 @@ ORA_API double ora_mse_test(const double* Ax, const int32_t* Ai, const int32_t* 
  * per iteration; returns the number of iterations run.  phase_sec (optional,
  * 4 entries) accumulates wall time of: predict(A), scale(h), predict(At),
  * scale(w)+cor.  sweeps (optional, 2 entries): NNLS sweep totals H / W. */
+/* timing only: the first n iterations of ora_c_nmf are left out of phase_sec / sweeps (warm-up) */
+static int g_timing_skip = 0;
+ORA_API void ora_set_timing_skip(int n) { g_timing_skip = n > 0 ? n : 0; }
+
 ORA_API int ora_c_nmf(const double* Ax, const int32_t* Ai, const int32_t* Ap, const double* Atx, const int32_t* Ati,
                       const int32_t* Atp, int32_t m, int32_t n, double tol, int maxit, double L1_w, double L1_h,
                       double L2_w, double L2_h, int threads, int k, double* w, double* h, double* d,
@@ -368,17 +372,18 @@ ORA_API int ora_c_nmf(const double* Ax, const int32_t* Ai, const int32_t* Ap, co
     int iter_ = 0;
     for (; iter_ < maxit && tol_ > tol; ++iter_) {
         memcpy(w_it, w, sizeof(double) * (size_t)k * (size_t)m);
+        const int timed = iter_ >= g_timing_skip;
         double t0 = now_sec();
-        predict(A, w, h, k, L1_h, L2_h, threads, sweeps ? &sweeps[0] : NULL);
+        predict(A, w, h, k, L1_h, L2_h, threads, (sweeps && timed) ? &sweeps[0] : NULL);
         double t1 = now_sec();
         ora_scale(h, k, n, d);
         double t2 = now_sec();
-        predict(At, h, w, k, L1_w, L2_w, threads, sweeps ? &sweeps[1] : NULL);
+        predict(At, h, w, k, L1_w, L2_w, threads, (sweeps && timed) ? &sweeps[1] : NULL);
         double t3 = now_sec();
         ora_scale(w, k, m, d);
         tol_ = ora_cor(w, w_it, (size_t)k * (size_t)m);
         double t4 = now_sec();
-        if (phase_sec) {
+        if (phase_sec && timed) {
             phase_sec[0] += t1 - t0;
             phase_sec[1] += t2 - t1;
             phase_sec[2] += t3 - t2;
