@@ -283,6 +283,72 @@ def project_model(A, w, L1=0.01, L2=0, threads=0):
     return c_project_model(A, w, L1, L2, threads)
 
 
+class _ResidentFits:
+    """One matrix kept in HBM across many fits (include/singlet_hip.h section 2): what R's ard_nmf /
+    cross_validate_nmf do by calling c_ard_nmf / c_nmf again and again on the same A (R/ard_nmf.R:95-160,
+    R/cross_validate_nmf.R:69-97), without re-uploading, re-transposing and re-validating it per call.
+    Same arguments and return lists as c_ard_nmf / c_nmf; results are identical to the one-shot calls."""
+
+    def __init__(self, A, device=0):
+        from .context import Context
+        self.A = as_dgCMatrix(A)
+        self.ctx = Context(device)
+        try:
+            self.ctx.upload(self.A, None)
+        except Exception:
+            self.ctx.close()
+            raise
+
+    def close(self):
+        self.ctx.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def c_ard_nmf(self, tol, maxit, verbose, L1, L2, threads, w, seed, inv_density, overfit_threshold, trace_test_mse):
+        wb = _w_in(w, self.A.nrow)
+        k = wb.shape[1]
+        self.ctx.fit_init(k, wb)
+        r = self.ctx.ard_run(float(tol), int(maxit), L1, L2, int(seed), int(inv_density), float(overfit_threshold),
+                             int(trace_test_mse), log=_verbose_log(verbose, ard=True))
+        W, d, H = self.ctx.get_factors()
+        return {"w": W.T, "d": d, "h": H.T, "test_mse": r["test_mse"], "iter": r["iter"], "tol": r["tol"],
+                "score_overfit": r["score_overfit"]}
+
+    def c_nmf(self, tol, maxit, verbose, L1_w, L1_h, L2_w, L2_h, threads, w):
+        wb = _w_in(w, self.A.nrow)
+        k = wb.shape[1]
+        self.ctx.fit_init(k, wb)
+        n_iter, tr = self.ctx.nmf_run(float(tol), int(maxit), L1_w, L1_h, L2_w, L2_h, log=_verbose_log(verbose))
+        W, d, H = self.ctx.get_factors()
+        return {"w": W.T, "d": d, "h": H.T, "iter": n_iter, "tol": tr}
+
+
+class _OneShotFits:
+    """The same interface through the one-shot entry points (every call uploads A again)."""
+
+    def __init__(self, A):
+        self.A = as_dgCMatrix(A)
+
+    def close(self):
+        pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        pass
+
+    def c_ard_nmf(self, *args):
+        return c_ard_nmf(self.A, None, *args)
+
+    def c_nmf(self, *args):
+        return c_nmf(self.A, None, *args)
+
+
 class CVData(list):
     """cv_data rows: dicts with k, rep, test_error, iter, tol (+ overfit_score from ard_nmf);
     the column sets match R/ard_nmf.R:93,118 and R/cross_validate_nmf.R:90."""
@@ -336,8 +402,10 @@ def GetBestRank(df, tol_overfit=1e-4):
 
 
 def ard_nmf(A, k_init=2, k_max=100, k_min=2, n_replicates=1, tol=1e-5, cv_tol=1e-4, maxit=100, verbose=1, L1=0.01,
-            L2=0, threads=0, test_density=0.05, learning_rate=1, tol_overfit=1e-3, trace_test_mse=1, seed=None):
-    """R/ard_nmf.R:31-193 (sparse, single-matrix branch): automatic rank search, then the final fit."""
+            L2=0, threads=0, test_density=0.05, learning_rate=1, tol_overfit=1e-3, trace_test_mse=1, seed=None,
+            resident=True):
+    """R/ard_nmf.R:31-193 (sparse, single-matrix branch): automatic rank search, then the final fit.
+    resident = True keeps A in HBM across all fits of the search (False: one-shot calls, as the R code does)."""
     if not L1 < 1:
         raise ValueError("L1 penalty must be strictly in the range (0, 1]")
     if k_init is None or (isinstance(k_init, float) and math.isnan(k_init)) or k_init < k_min:
@@ -353,6 +421,16 @@ def ard_nmf(A, k_init=2, k_max=100, k_min=2, n_replicates=1, tol=1e-5, cv_tol=1e
     test_seed = int(rng.integers(1, 2 ** 31 - 1))  # abs(.Random.seed[[3]])
     inv_density = int(round(1 / test_density))
     df = CVData()
+    fits = _ResidentFits(A) if resident else _OneShotFits(A)
+    try:
+        return _ard_nmf_search(fits, A, df, w_init, test_seed, inv_density, k_init, k_max, k_min, n_replicates, tol, cv_tol,
+                               maxit, verbose, L1, L2, threads, learning_rate, tol_overfit, trace_test_mse)
+    finally:
+        fits.close()
+
+
+def _ard_nmf_search(fits, A, df, w_init, test_seed, inv_density, k_init, k_max, k_min, n_replicates, tol, cv_tol, maxit,
+                    verbose, L1, L2, threads, learning_rate, tol_overfit, trace_test_mse):
     for curr_rep in range(1, n_replicates + 1):
         if verbose >= 1 and n_replicates > 1:
             print("\nREPLICATE ", curr_rep, "/", n_replicates)
@@ -362,8 +440,8 @@ def ard_nmf(A, k_init=2, k_max=100, k_min=2, n_replicates=1, tol=1e-5, cv_tol=1e
             if verbose > 0:
                 print("k =", curr_rank, ", rep =", curr_rep)
             w_init_this = w_init[curr_rep - 1][:curr_rank, :]
-            model = c_ard_nmf(A, None, cv_tol, maxit, verbose > 2, L1, L2, threads, w_init_this, test_seed + curr_rep,
-                              inv_density, tol_overfit, trace_test_mse)
+            model = fits.c_ard_nmf(cv_tol, maxit, verbose > 2, L1, L2, threads, w_init_this, test_seed + curr_rep,
+                                   inv_density, tol_overfit, trace_test_mse)
             overfit_score = float(model["score_overfit"][-1])
             for q in range(len(model["test_mse"])):
                 df.append({"k": int(curr_rank), "rep": int(curr_rep), "test_error": float(model["test_mse"][q]),
@@ -403,14 +481,15 @@ def ard_nmf(A, k_init=2, k_max=100, k_min=2, n_replicates=1, tol=1e-5, cv_tol=1e
     if verbose > 0:
         print("\nFitting final model at k =", best_rank)
     w_init_this = w_init[0][:best_rank, :]
-    model = c_nmf(A, None, tol, maxit, verbose > 2, L1, L1, L2, L2, threads, w_init_this)
+    model = fits.c_nmf(tol, maxit, verbose > 2, L1, L1, L2, L2, threads, w_init_this)
     model["cv_data"] = df
     return _sort_model(model, A.Dimnames[0], A.Dimnames[1])
 
 
 def cross_validate_nmf(A, ranks, n_replicates=3, tol=1e-4, maxit=100, verbose=1, L1=0.01, L2=0, threads=0,
-                       test_density=0.05, tol_overfit=1e-4, trace_test_mse=5, seed=None):
-    """R/cross_validate_nmf.R:18-105 (sparse, single-matrix branch) -> cv table with k, rep, test_error, iter, tol."""
+                       test_density=0.05, tol_overfit=1e-4, trace_test_mse=5, seed=None, resident=True):
+    """R/cross_validate_nmf.R:18-105 (sparse, single-matrix branch) -> cv table with k, rep, test_error, iter, tol.
+    resident = True keeps A in HBM across the whole (rank, replicate) grid."""
     if L1 >= 1:
         raise ValueError("L1 penalty must be strictly in the range (0, 1]")
     A = as_dgCMatrix(A)
@@ -421,16 +500,20 @@ def cross_validate_nmf(A, ranks, n_replicates=3, tol=1e-4, maxit=100, verbose=1,
     inv_density = int(round(1 / test_density))
     df2 = CVData()
     grid = [(k, rep) for rep in range(1, n_replicates + 1) for k in ranks]  # expand.grid(k = ranks, rep = 1:n)
-    for q, (k, rep) in enumerate(grid):
-        if verbose > 1:
-            print("k = %d, rep = %d (%d/%d):" % (k, rep, q + 1, len(grid)))
-        model = c_ard_nmf(A, None, tol, maxit, verbose > 1, L1, L2, threads, w_init[rep - 1][:k, :], seeds[rep - 1],
-                          inv_density, tol_overfit, trace_test_mse)
-        for t in range(len(model["test_mse"])):
-            df2.append({"k": k, "rep": rep, "test_error": float(model["test_mse"][t]), "iter": int(model["iter"][t]),
-                        "tol": float(model["tol"][t])})
-        if verbose > 1:
-            print("test set error: %#.4e\n" % model["test_mse"][-1])
-            if model["test_mse"][-1] / model["test_mse"][0] > (1 + tol_overfit):
-                print("overfitting detected, lower rank recommended")
+    fits = _ResidentFits(A) if resident else _OneShotFits(A)
+    try:
+        for q, (k, rep) in enumerate(grid):
+            if verbose > 1:
+                print("k = %d, rep = %d (%d/%d):" % (k, rep, q + 1, len(grid)))
+            model = fits.c_ard_nmf(tol, maxit, verbose > 1, L1, L2, threads, w_init[rep - 1][:k, :], seeds[rep - 1],
+                                   inv_density, tol_overfit, trace_test_mse)
+            for t in range(len(model["test_mse"])):
+                df2.append({"k": k, "rep": rep, "test_error": float(model["test_mse"][t]), "iter": int(model["iter"][t]),
+                            "tol": float(model["tol"][t])})
+            if verbose > 1:
+                print("test set error: %#.4e\n" % model["test_mse"][-1])
+                if model["test_mse"][-1] / model["test_mse"][0] > (1 + tol_overfit):
+                    print("overfitting detected, lower rank recommended")
+    finally:
+        fits.close()
     return df2

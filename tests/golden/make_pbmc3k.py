@@ -118,9 +118,14 @@ def main():
     di[1:] -= i[:-1]
     di[p[:-1]] = i[p[:-1]]
     assert di.min() >= 0 and di.max() < 65536 and x.max() < 65536 and x.min() >= 1
+    # rows of the mitochondrial genes (names "MT-..."): what the vignette's QC filter percent.mt needs
+    # (docs/articles/Guided_Clustering_with_NMF.html: PercentageFeatureSet(pattern = "^MT-"))
+    genes = obj["Dimnames"][0]
+    mt_rows = np.array([q for q, g in enumerate(genes) if g.startswith("MT-")], dtype=np.int32)
+    assert len(genes) == 13714 and 5 <= mt_rows.size <= 40, mt_rows.size
     np.savez_compressed(os.path.join(HERE, "pbmc3k_counts.npz"), di=di.astype(np.uint16), p=p.astype(np.int32),
-                        x=x.astype(np.uint16), dim=np.asarray(dim, dtype=np.int32))
-    print("pbmc3k: dim", tuple(dim), "nnz", i.size, "max count", int(x.max()))
+                        x=x.astype(np.uint16), dim=np.asarray(dim, dtype=np.int32), mt_rows=mt_rows)
+    print("pbmc3k: dim", tuple(dim), "nnz", i.size, "max count", int(x.max()), "MT genes", mt_rows.size)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,103 @@
+"""BASELINE config 5 (ard_nmf + cross_validate_nmf rank sweep on the 30 000-gene matrix) on ONE GPU:
+the masked (c_ard_nmf) path at the real gene count and >= 200 000 cells, where the CPU oracle cannot
+follow, checked through properties; oracle parity on a slice of the same matrix that it can follow;
+and the resident sweep (A uploaded once for the whole (rank, replicate) grid) against the one-shot
+calls the R drivers make (R/ard_nmf.R:95-160, R/cross_validate_nmf.R:69-97)."""
+import numpy as np
+import pytest
+
+from conftest import rel_fro, to_dgc
+
+pytestmark = pytest.mark.gpu
+
+GENES, CELLS = 30000, 200000
+SEED, INV = 4711, 20
+
+
+@pytest.fixture(scope="module")
+def big(sa):
+    c = sa.Context(0)
+    c.synth(GENES, CELLS, 20)
+    yield c
+    c.close()
+
+
+def test_mask_draw_rate_at_config5_offsets(big):
+    """draw(cell, gene) at inv_density 20 marks ~5 % of the entries, also for cell indices near 1e6."""
+    for cell0 in (0, 199000, 999000):
+        m = big.op_mask(SEED, INV, cell0, 1000, GENES)
+        rate = m.mean()
+        assert abs(rate - 0.05) < 0.001, (cell0, rate)
+        per_cell = m.mean(axis=1)
+        assert per_cell.min() > 0.04 and per_cell.max() < 0.06
+
+
+@pytest.mark.parametrize("k,iters", [(10, 3), (50, 3), (100, 2)])
+def test_ard_run_at_config5_shape_is_finite_and_bit_reproducible(big, k, iters):
+    res = []
+    for _ in range(2):
+        big.fit_init(k, None)
+        r = big.ard_run(0.0, iters, 0.01, 0.0, SEED, INV, 1e9, 1)
+        W, d, H = big.get_factors(h=False)
+        res.append((r, W, d))
+    (r0, W0, d0), (r1, W1, d1) = res
+    assert r0["n_iter"] == iters and list(r0["iter"]) == list(range(iters))
+    assert np.all(np.isfinite(r0["test_mse"])) and np.all(r0["test_mse"] > 0) and np.all(r0["test_mse"] < 10)
+    assert np.all(np.diff(r0["test_mse"]) < 0)            # the first iterations of a fit reduce the test error
+    assert np.all(np.isfinite(W0)) and np.all(W0 >= 0) and np.all(d0 > 0)
+    assert abs(W0.sum(axis=0) - 1.0).max() < 1e-9         # scale(w): every factor sums to 1 over the genes
+    # same inputs, same kernels, fixed-order reductions: bit-identical
+    assert np.array_equal(r0["test_mse"], r1["test_mse"]) and np.array_equal(W0, W1) and np.array_equal(d0, d1)
+    assert np.array_equal(r0["tol"], r1["tol"])
+
+
+def test_never_drawn_mask_reduces_to_the_plain_fit(big):
+    """With a divisor no hash value is a multiple of, predict_mask is predict up to the 1e-15 ridge the
+    downdate cancels (src/singlet.cpp:461-462): the masked path (plain CSC kernel + per-column Grams +
+    wave NNLS) must then reproduce the LDS-tiled / lane-NNLS path of c_nmf at the full size."""
+    k = 20
+    big.fit_init(k, None)
+    big.nmf_run(0.0, 2, 0.01, 0.01, 0.0, 0.0)
+    Wp, dp, Hp = big.get_factors()
+    big.fit_init(k, None)
+    r = big.ard_run(0.0, 2, 0.01, 0.0, SEED, (1 << 63) - 25, 1e9, 1)   # odd 63-bit divisor: never divides a hash here
+    Wm, dm, Hm = big.get_factors()
+    assert list(r["test_mse"]) == [0.0, 0.0]             # empty test set: losses are 0 by definition (l.563)
+    assert rel_fro(Wm, Wp) < 1e-9 and rel_fro(Hm, Hp) < 1e-9 and rel_fro(dm, dp) < 1e-9
+
+
+@pytest.mark.parametrize("k", [10, 50])
+def test_oracle_parity_on_a_slice_with_all_genes(sa, ora, k):
+    """The first 600 cells of the same synthetic matrix, all 30 000 genes, against the CPU restatement."""
+    n = 600
+    A = ora.synth_csc(GENES, n, 20)
+    At = A.t()
+    w0 = ora.synth_winit(k, GENES)
+    ref = ora.c_ard_nmf(A, At, 0.0, 3, 0.01, 0.0, 0, w0, SEED, INV, 1e9, 1)
+    got = sa.c_ard_nmf(to_dgc(sa, A), to_dgc(sa, At), 0.0, 3, False, 0.01, 0.0, 0, w0.T, SEED, INV, 1e9, 1)
+    assert list(got["iter"]) == list(ref["iter"])
+    assert rel_fro(got["test_mse"], ref["test_mse"]) < 1e-9
+    assert rel_fro(got["w"].T, ref["w"]) < 1e-9 and rel_fro(got["h"].T, ref["h"]) < 1e-9
+
+
+def test_resident_sweep_equals_one_shot_calls(sa, ora):
+    """cross_validate_nmf / ard_nmf with A uploaded once return exactly what the per-call uploads return."""
+    A = to_dgc(sa, ora.synth_csc(400, 900, 10))
+    kw = dict(n_replicates=2, maxit=6, verbose=0, trace_test_mse=2, seed=5)
+    a = sa.cross_validate_nmf(A, [3, 5, 8], resident=True, **kw)
+    b = sa.cross_validate_nmf(A, [3, 5, 8], resident=False, **kw)
+    assert a.columns() == b.columns() == ["k", "rep", "test_error", "iter", "tol"]
+    assert len(a) == len(b) and all(ra == rb for ra, rb in zip(a, b))      # bit-identical rows
+    kw = dict(k_init=2, k_max=12, n_replicates=1, maxit=8, verbose=0, seed=7, tol_overfit=1e-3)
+    ma = sa.ard_nmf(A, resident=True, **kw)
+    mb = sa.ard_nmf(A, resident=False, **kw)
+    assert all(ra == rb for ra, rb in zip(ma["cv_data"], mb["cv_data"])) and len(ma["cv_data"]) == len(mb["cv_data"])
+    assert np.array_equal(ma["w"], mb["w"]) and np.array_equal(ma["h"], mb["h"]) and np.array_equal(ma["d"], mb["d"])
+
+
+def test_ard_rank_limit_is_checked_before_the_upload(sa, ora):
+    A = ora.synth_csc(200, 150, 10)
+    w0 = ora.synth_winit(130, 200)
+    with pytest.raises(sa.SingletHipError) as e:
+        sa.c_ard_nmf(to_dgc(sa, A), None, 0.0, 2, False, 0.01, 0.0, 0, w0.T, 1, 20, 1e9, 1)
+    assert "128" in str(e.value)

@@ -58,7 +58,7 @@ def test_ard_nmf_rank_search_control_flow(sa, monkeypatch):
         w=np.asarray(w), d=np.arange(np.asarray(w).shape[0], dtype=float), h=np.zeros((np.asarray(w).shape[0], A.ncol)),
         iter=1, tol=np.array([0.0])))
     A = sa.dgCMatrix.from_dense(np.eye(6))
-    model = api.ard_nmf(A, k_init=2, k_max=40, n_replicates=2, verbose=0, learning_rate=1, seed=3)
+    model = api.ard_nmf(A, k_init=2, k_max=40, n_replicates=2, verbose=0, learning_rate=1, seed=3, resident=False)
     ks = [c[0] for c in calls]
     # replicate 1 (traced by hand through R/ard_nmf.R:121-158): step doubling 2, 4, 8, 16 (overfit ->
     # k_max = 16), 12 (overfit -> k_max = 12), then bisection 6, 10, 9, 11 and stop (neighbours 10 / 12)
@@ -85,7 +85,7 @@ def test_cross_validate_nmf_grid_and_columns(sa, monkeypatch):
     fake, calls = _fake_c_ard(curve)
     monkeypatch.setattr(api, "c_ard_nmf", fake)
     A = sa.dgCMatrix.from_dense(np.eye(5))
-    df = api.cross_validate_nmf(A, [2, 3, 5], n_replicates=2, verbose=0, seed=1)
+    df = api.cross_validate_nmf(A, [2, 3, 5], n_replicates=2, verbose=0, seed=1, resident=False)
     assert [c[0] for c in calls] == [2, 3, 5, 2, 3, 5]          # expand.grid(k, rep): k varies fastest
     assert df.columns() == ["k", "rep", "test_error", "iter", "tol"]   # no overfit_score (R/cross_validate_nmf.R:90)
     assert len(df) == 12 and sa.GetBestRank(df) == 5
