@@ -263,11 +263,12 @@ SGL_API int sgl_nmf_iterate(sgl_ctx* ctx, double L1_w, double L1_h, double L2_w,
  *     (they commute with scale(h, d), src/singlet.cpp:651) -- then every rank solves its block of
  *     genes and the blocks of w are all-gathered.  W, d and tol come out identical on all ranks.
  *     Results equal the one-GPU fit to rounding (the scaling is applied after the sums).
- *     Limits: c_nmf only (no links, no dense front-end, no masked path), k as for one GPU.
+ *     Limits: c_nmf and c_ard_nmf (no links, no dense front-end), k as for one GPU.
  *     RCCL is loaded at run time (librccl.so.1; SGL_RCCL_PATH overrides); SGL_ECOMM if absent.
  * ---------------------------------------------------------------------- */
 /* (a) ONE process drives all devices -- the form an R session uses.  sgl_c_nmf itself takes this
- *     path when the environment variable SINGLET_NGPU is set to a number > 1.
+ *     path (and sgl_c_ard_nmf its masked counterpart) when the environment variable SINGLET_NGPU
+ *     is set to a number > 1.
  *     devices: ndev device ids (NULL: 0 .. ndev-1), all distinct -> RCCL (ncclCommInitAll); all
  *     equal -> the ranks share one device and exchange through a HIP kernel (test configuration). */
 typedef struct sgl_multi sgl_multi;
@@ -285,6 +286,15 @@ SGL_API int sgl_multi_fit_init(sgl_multi* m, int32_t k, const double* w_init, ui
 SGL_API int sgl_multi_iterate(sgl_multi* m, double L1_w, double L1_h, double L2_w, double L2_h, double* tol);
 SGL_API int sgl_multi_nmf_run(sgl_multi* m, double tol, int32_t maxit, double L1_w, double L1_h, double L2_w, double L2_h,
                               int32_t* n_iter, double* tol_trace, const sgl_callbacks* cb);
+/* c_ard_nmf_base on the team (arguments as sgl_ard_run).  The W-update needs, per gene, sums over ALL cells of
+ * the right-hand side and of the Gram downdate over the cells masked for that gene: one grouped collective
+ * reduce-scatters [k x genes | k x k x genes] by gene blocks (600 MB at k = 50, 30 000 genes -- as a
+ * reduce-scatter each rank moves (N-1)/N of it once) and all-reduces the k x k Gram; mse_test adds one
+ * all-reduced double per trace.  scale(h, d) keeps the reference's order (k row sums all-reduced first). */
+SGL_API int sgl_multi_ard_run(sgl_multi* m, double tol, int32_t maxit, double L1, double L2,
+                              uint64_t seed, uint64_t inv_density, double overfit_threshold, int32_t trace_test_mse,
+                              double* test_mse, int32_t* iter, double* tol_out, double* score_overfit, int32_t* n_trace,
+                              int32_t* n_iter, const sgl_callbacks* cb);
 /* w k x nrow, d k, h k x ncol (all cells, in matrix order); any may be NULL. */
 SGL_API int sgl_multi_get_factors(sgl_multi* m, double* w, double* d, double* h);
 /* (b) one process per GPU (torch.distributed.run, MPI ...): rank 0 makes an id, the host broadcasts

@@ -90,6 +90,8 @@ SIGNATURES = {
     "sgl_multi_iterate": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, f64p]),
     "sgl_multi_nmf_run": (C.c_int, [C.c_void_p, C.c_double, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double,
                                     i32p, f64p, _CB]),
+    "sgl_multi_ard_run": (C.c_int, [C.c_void_p, C.c_double, C.c_int32, C.c_double, C.c_double, C.c_uint64, C.c_uint64,
+                                    C.c_double, C.c_int32, f64p, i32p, f64p, f64p, i32p, i32p, _CB]),
     "sgl_multi_get_factors": (C.c_int, [C.c_void_p, f64p, f64p, f64p]),
     "sgl_comm_unique_id": (C.c_int, [C.c_void_p]),
     "sgl_comm_init_rank": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),

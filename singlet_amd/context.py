@@ -376,6 +376,19 @@ class Multi:
                                         C.byref(cb)))
         return n_iter.value, tr[:n_iter.value].copy()
 
+    def ard_run(self, tol, maxit, L1, L2, seed, inv_density, overfit_threshold, trace_test_mse, log=None, poll=None):
+        cap = int(maxit) + 2
+        tm, ft, so = np.zeros(cap), np.zeros(cap), np.zeros(cap)
+        itv = np.zeros(cap, dtype=np.int32)
+        nt, nit = C.c_int32(), C.c_int32()
+        cb = make_callbacks(log, poll)
+        check(self._L.sgl_multi_ard_run(self._h, tol, int(maxit), L1, L2, int(seed), int(inv_density), overfit_threshold,
+                                        int(trace_test_mse), ptr(tm, f64p), ptr(itv, i32p), ptr(ft, f64p), ptr(so, f64p),
+                                        C.byref(nt), C.byref(nit), C.byref(cb)))
+        q = nt.value
+        return dict(test_mse=tm[:q].copy(), iter=itv[:q].copy(), tol=ft[:q].copy(), score_overfit=so[:q].copy(),
+                    n_iter=nit.value)
+
     def get_factors(self):
         nr, nc = self._dims
         W, D, H = np.empty((nr, self.k)), np.empty(self.k), np.empty((nc, self.k))

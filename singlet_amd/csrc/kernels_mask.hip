@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void mask_gram_kernel(int64_t col0, int64_t nc
                                                         const int64_t* __restrict__ col_nnz,
                                                         const double* __restrict__ F, const double* __restrict__ G,
                                                         int k, uint64_t seed, SglDiv inv_density, int mask_t,
-                                                        int64_t col_off, int64_t row_off, double* __restrict__ Gout) {
+                                                        int64_t col_off, int64_t row_off, double* __restrict__ Gout, int raw) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     int* list = reinterpret_cast<int*>(smem_raw);                 // [256] drawn rows of the current chunk
     int* wcount = list + 256;                                      // [4] per-wave counts (+pad to 8 ints)
@@ -83,8 +83,8 @@ __global__ __launch_bounds__(256) void mask_gram_kernel(int64_t col0, int64_t nc
         if (tid + 256 * q < npairs) {
             const int i = pi[q], j = pj[q];
             double sub = acc[q];
-            if (i == j) sub += 1e-15;  // AAt(wsub) adds it too (quirk 8)
-            const double v = G[(size_t)j * k + i] - sub;
+            if (i == j && !raw) sub += 1e-15;  // AAt(wsub) adds it too (quirk 8)
+            const double v = raw ? sub : G[(size_t)j * k + i] - sub;
             out[(size_t)j * k + i] = v;
             out[(size_t)i * k + j] = v;
         }
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void mask_gram_mfma_kernel(int64_t col0, int64
                                                              const int64_t* __restrict__ col_nnz,
                                                              const double* __restrict__ F, const double* __restrict__ G,
                                                              int k, uint64_t seed, SglDiv inv_density, int mask_t,
-                                                             int64_t col_off, int64_t row_off, double* __restrict__ Gout) {
+                                                             int64_t col_off, int64_t row_off, double* __restrict__ Gout, int raw) {
     constexpr int NTILES_ALL = NT * (NT + 1) / 2;
     constexpr int NTILES = (NTILES_ALL - PART + NPARTS - 1) / NPARTS;  // tiles of this part
     constexpr int DEPTH = (NT <= 4) ? 4 : 2;                             // row groups in flight
@@ -218,8 +218,8 @@ __global__ __launch_bounds__(256) void mask_gram_mfma_kernel(int64_t col0, int64
                     const int row = bi * 16 + kk + 4 * r;  // D row (lane >> 4) + 4 r
                     const int cc = bj * 16 + r16;          // D col lane & 15
                     if (row < k && cc < k) {
-                        if (row == cc) sub += 1e-15;
-                        const double v = G[(size_t)cc * k + row] - sub;
+                        if (row == cc && !raw) sub += 1e-15;
+                        const double v = raw ? sub : G[(size_t)cc * k + row] - sub;
                         out[(size_t)cc * k + row] = v;
                         if (row != cc) out[(size_t)row * k + cc] = v;
                     }
@@ -229,13 +229,16 @@ __global__ __launch_bounds__(256) void mask_gram_mfma_kernel(int64_t col0, int64
         }
 }
 
+// G == nullptr: "raw" mode -- Gcols[c] = the plain sum of f f^T over the masked rows of column c (no Gram,
+// no ridge): the partial a cell shard contributes to a gene's downdate (multi.hip sums them over the ranks)
 int k_mask_gram_cols(hipStream_t s, int64_t col0, int64_t ncols, int32_t nrow, const int64_t* col_nnz,
                      const double* F, const double* G, int k, uint64_t seed, uint64_t inv_density, int mask_t,
                      int64_t col_offset, int64_t row_offset, double* Gcols) {
     if (ncols <= 0) return SGL_OK;
+    const int raw = G == nullptr ? 1 : 0;
     dim3 g((unsigned)ncols), b(256);
     if (k <= 128 && !getenv("SGL_MASK_GRAM_VALU")) {  // env: keep the VALU kernel reachable for A/B tests
-#define SGL_MGM(...) mask_gram_mfma_kernel<__VA_ARGS__><<<g, b, 0, s>>>(col0, ncols, nrow, col_nnz, F, G, k, seed, sgl_div_make(inv_density), mask_t, col_offset, row_offset, Gcols)
+#define SGL_MGM(...) mask_gram_mfma_kernel<__VA_ARGS__><<<g, b, 0, s>>>(col0, ncols, nrow, col_nnz, F, G, k, seed, sgl_div_make(inv_density), mask_t, col_offset, row_offset, Gcols, raw)
         switch ((k + 15) / 16) {
             case 1: SGL_MGM(1); break;
             case 2: SGL_MGM(2); break;
@@ -253,13 +256,34 @@ int k_mask_gram_cols(hipStream_t s, int64_t col0, int64_t ncols, int32_t nrow, c
     const int npairs = k * (k + 1) / 2;
     const int P = (npairs + 255) / 256;
     const size_t smem = 264 * 4 + sizeof(double) * 16 * (size_t)k;
-#define SGL_MG(PM) mask_gram_kernel<PM><<<g, b, smem, s>>>(col0, ncols, nrow, col_nnz, F, G, k, seed, sgl_div_make(inv_density), mask_t, col_offset, row_offset, Gcols)
+#define SGL_MG(PM) mask_gram_kernel<PM><<<g, b, smem, s>>>(col0, ncols, nrow, col_nnz, F, G, k, seed, sgl_div_make(inv_density), mask_t, col_offset, row_offset, Gcols, raw)
     if (P <= 4) SGL_MG(4);
     else if (P <= 9) SGL_MG(9);
     else if (P <= 20) SGL_MG(20);
     else if (P <= 33) SGL_MG(33);
     else { sgl_set_error("masked path supports k <= 128 (got %d)", k); return SGL_EINVAL; }
 #undef SGL_MG
+    HIPCHK(hipGetLastError());
+    return SGL_OK;
+}
+
+// a_i = G - (S_i + 1e-15 I) for ncols columns from their summed downdates S (src/singlet.cpp:460-462:
+// AAt(wsub) carries the 1e-15 ridge too, so it cancels the one inside G)
+__global__ void mask_gram_finalize_kernel(const double* __restrict__ G, const double* __restrict__ S, int k, int64_t ncols,
+                                          double* __restrict__ out) {
+    const int64_t kk = (int64_t)k * k, n = kk * ncols;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const int q = (int)(e % kk);
+        double sub = S[e];
+        if (q / k == q % k) sub += 1e-15;
+        out[e] = G[q] - sub;
+    }
+}
+
+int k_mask_gram_finalize(hipStream_t s, const double* G, const double* S, int k, int64_t ncols, double* out) {
+    if (ncols <= 0) return SGL_OK;
+    const int64_t n = (int64_t)k * k * ncols;
+    mask_gram_finalize_kernel<<<dim3((unsigned)std::min<int64_t>((n + 255) / 256, 8192)), dim3(256), 0, s>>>(G, S, k, ncols, out);
     HIPCHK(hipGetLastError());
     return SGL_OK;
 }

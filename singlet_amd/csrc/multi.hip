@@ -420,6 +420,230 @@ static int team_nmf_run(sgl_team* T, double tol, int32_t maxit, double L1_w, dou
     return SGL_OK;
 }
 
+// ---------------------------------------------------- the masked (ARD) loop --
+// c_ard_nmf_base (src/singlet.cpp:1090-1152) over a team.  The H-update is local (w replicated, hash on
+// global cell indices, :485).  For the W-update every gene needs sums over ALL cells: its right-hand side
+// b_g and its Gram downdate S_g = sum over the cells masked for g of h_c h_c^T (:458-463 with the
+// offset of :590).  Each rank forms the partials of its cells for every gene; ONE grouped collective
+// reduce-scatters [b (k x genes) | S (k x k x genes)] by gene blocks and all-reduces the k x k Gram of
+// h; each rank then solves its block of genes against a_g = (h h^T + 1e-15 I) - (S_g + 1e-15 I), and
+// the w blocks are all-gathered.  k x k x genes doubles is 600 MB at k = 50 -- moved as a
+// reduce-scatter it costs each rank (N - 1) / N of that once, not the 2 x of an all-reduce.
+// scale(h, d) keeps the reference's order here (row sums all-reduced first): k doubles.
+static int team_mask_workspace(sgl_team* T) {
+    const int N = T->nranks;
+    for (auto c : T->local) {
+        HIPCHK(hipSetDevice(c->device));
+        SGLCHK(sgl_mask_workspace(c));
+        if (N > 1 && !c->Sbuf) {
+            const int64_t mb = (T->nrow + N - 1) / N;
+            hipError_t e = hipMalloc((void**)&c->Sbuf, sizeof(double) * (size_t)mb * N * c->k * c->k);
+            if (e != hipSuccess) { (void)hipGetLastError(); sgl_set_error("team: out of device memory for the per-gene downdates"); return SGL_ENOMEM; }
+        }
+    }
+    return SGL_OK;
+}
+
+static int team_ard_iterate(sgl_team* T, double L1, double L2, uint64_t seed, uint64_t inv_density, double* tol_out) {
+    const int nl = (int)T->local.size();
+    const int N = T->nranks;
+    const int k = T->local[0]->k;
+    const int64_t m = T->nrow;
+    const int64_t mb = N > 1 ? (m + N - 1) / N : m;
+    const int64_t mpad = mb * N;
+    std::vector<void*> dv(nl), red(nl), sb(nl), tail(nl), wbuf(nl);
+    for (int i = 0; i < nl; ++i) {   // H-update: local
+        sgl_ctx* c = T->local[i];
+        HIPCHK(hipSetDevice(c->device));
+        SGLCHK(sgl_step_begin(c));
+        SGLCHK(sgl_predict_mask_dev(c, c->A, c->col_nnz_A, c->W, c->H, c->B, seed, inv_density, L1, L2, 0, SGL_PH_RHS_H,
+                                    SGL_PH_NNLS_H, c->sweep_counters + 0));
+        PhaseEvent pe;
+        SGLCHK(sgl_phase_begin(c, SGL_PH_SCALE, &pe));
+        SGLCHK(k_rowsum(c, c->H, k, c->A.ncol, c->d));
+        SGLCHK(sgl_phase_end(c, &pe));
+        dv[i] = c->d;
+    }
+    if (N > 1) {
+        TeamPhase ph(T);
+        SGLCHK(group_begin(T));
+        int rc = team_allreduce(T, dv.data(), k);
+        SGLCHK(group_end(T));
+        SGLCHK(rc);
+    }
+    for (int i = 0; i < nl; ++i) {   // scale(h, d); partials of the W-update
+        sgl_ctx* c = T->local[i];
+        HIPCHK(hipSetDevice(c->device));
+        PhaseEvent pe;
+        SGLCHK(sgl_phase_begin(c, SGL_PH_SCALE, &pe));
+        SGLCHK(k_scale_apply(c->stream, c->H, k, c->A.ncol, c->d, 1));
+        SGLCHK(sgl_phase_end(c, &pe));
+        if (N == 1) {
+            const int64_t* gene_nnz = c->col_nnz_At;
+            SGLCHK(sgl_predict_mask_dev(c, c->At, gene_nnz, c->H, c->W, c->red, seed, inv_density, L1, L2, 1, SGL_PH_RHS_W,
+                                        SGL_PH_NNLS_W, c->sweep_counters + 1));
+            continue;
+        }
+        double* Bw = c->red;
+        double* Gh = c->red + (size_t)k * mpad;
+        SGLCHK(sgl_phase_begin(c, SGL_PH_GRAM, &pe));
+        SGLCHK(k_gram(c, c->H, k, c->A.ncol, Gh, 0.0));
+        SGLCHK(sgl_phase_end(c, &pe));
+        SGLCHK(sgl_phase_begin(c, SGL_PH_RHS_W, &pe));
+        // hash argument order of the At pass: draw(cell = row + cell_offset, gene = column)
+        SGLCHK(k_acc(c->stream, c->At, c->H, k, Bw, seed, inv_density, 2, 0, c->cell_offset));
+        SGLCHK(sgl_phase_end(c, &pe));
+        SGLCHK(sgl_phase_begin(c, SGL_PH_MASK, &pe));
+        HIPCHK(hipMemsetAsync(c->Sbuf, 0, sizeof(double) * (size_t)mpad * k * k, c->stream));
+        if (!c->gene_nnz_global) { sgl_set_error("team: global gene counts missing"); return SGL_ESTATE; }
+        SGLCHK(k_mask_gram_cols(c->stream, 0, m, c->At.nrow, c->col_nnz_At_global, c->H, nullptr, k, seed, inv_density, 1, 0,
+                                c->cell_offset, c->Sbuf));
+        SGLCHK(sgl_phase_end(c, &pe));
+        red[i] = Bw;
+        sb[i] = c->Sbuf;
+        tail[i] = Gh;
+        wbuf[i] = c->W;
+    }
+    if (N > 1) {
+        {
+            TeamPhase ph(T);
+            SGLCHK(group_begin(T));
+            int rc = team_reduce_scatter(T, red.data(), (int64_t)k * mb);
+            if (rc == SGL_OK) rc = team_reduce_scatter(T, sb.data(), (int64_t)k * k * mb);
+            if (rc == SGL_OK) rc = team_allreduce(T, tail.data(), (int64_t)k * k);
+            SGLCHK(group_end(T));
+            SGLCHK(rc);
+        }
+        for (int i = 0; i < nl; ++i) {   // every rank: its block of genes
+            sgl_ctx* c = T->local[i];
+            HIPCHK(hipSetDevice(c->device));
+            const int r = T->rank[i];
+            const int64_t g0 = (int64_t)r * mb;
+            const int64_t ng = std::max<int64_t>(0, std::min<int64_t>(mb, m - g0));
+            double* Gh = c->red + (size_t)k * mpad;
+            PhaseEvent pe;
+            SGLCHK(sgl_phase_begin(c, SGL_PH_GRAM, &pe));
+            HIPCHK(hipMemcpyAsync(c->G, Gh, sizeof(double) * k * k, hipMemcpyDeviceToDevice, c->stream));
+            SGLCHK(k_gram_add_diag(c->stream, c->G, k, 1e-15));
+            SGLCHK(sgl_phase_end(c, &pe));
+            for (int64_t q0 = 0; q0 < ng; q0 += c->gcols_chunk) {
+                const int64_t nq = std::min<int64_t>(c->gcols_chunk, ng - q0);
+                SGLCHK(sgl_phase_begin(c, SGL_PH_MASK, &pe));
+                SGLCHK(k_mask_gram_finalize(c->stream, c->G, c->Sbuf + (size_t)(g0 + q0) * k * k, k, nq, c->Gcols));
+                SGLCHK(sgl_phase_end(c, &pe));
+                SGLCHK(sgl_phase_begin(c, SGL_PH_NNLS_W, &pe));
+                SGLCHK(k_nnls_wave(c->stream, c->Gcols, (int64_t)k * k, c->red + (size_t)(g0 + q0) * k, c->W + (size_t)(g0 + q0) * k,
+                                   c->col_nnz_At_global + g0 + q0, k, nq, L1, L2, c->sweep_counters + 1));
+                SGLCHK(sgl_phase_end(c, &pe));
+            }
+        }
+        TeamPhase ph(T);
+        SGLCHK(group_begin(T));
+        int rc = team_allgather(T, wbuf.data(), (int64_t)k * mb);
+        SGLCHK(group_end(T));
+        SGLCHK(rc);
+    }
+    for (int i = 0; i < nl; ++i) {
+        HIPCHK(hipSetDevice(T->local[i]->device));
+        SGLCHK(sgl_scale_w_enqueue(T->local[i]));
+    }
+    double tol = 0.0;
+    for (int i = 0; i < nl; ++i) {
+        HIPCHK(hipSetDevice(T->local[i]->device));
+        double t = 0.0;
+        SGLCHK(sgl_scale_w_fetch(T->local[i], &t));
+        if (i == 0) tol = t;
+    }
+    if (tol_out) *tol_out = tol;
+    return SGL_OK;
+}
+
+// mse_test (src/singlet.cpp:536-568) over the team: local sums of the per-cell losses, one double all-reduced
+static int team_mse_test(sgl_team* T, uint64_t seed, uint64_t inv_density, double* out) {
+    const int nl = (int)T->local.size();
+    std::vector<void*> sc(nl);
+    for (int i = 0; i < nl; ++i) {
+        sgl_ctx* c = T->local[i];
+        HIPCHK(hipSetDevice(c->device));
+        SGLCHK(sgl_mse_test_enqueue(c, seed, inv_density));
+        sc[i] = c->scalars + 1;
+    }
+    if (T->nranks > 1) {
+        TeamPhase ph(T);
+        SGLCHK(group_begin(T));
+        int rc = team_allreduce(T, sc.data(), 1);
+        SGLCHK(group_end(T));
+        SGLCHK(rc);
+    }
+    sgl_ctx* c0 = T->local[0];
+    HIPCHK(hipSetDevice(c0->device));
+    HIPCHK(hipMemcpyAsync(c0->pinned + 1, c0->scalars + 1, sizeof(double), hipMemcpyDeviceToHost, c0->stream));
+    HIPCHK(hipStreamSynchronize(c0->stream));
+    *out = c0->pinned[1] / (double)c0->ncells_total;   // losses.sum() / h.cols(), l.567
+    return SGL_OK;
+}
+
+static int team_ard_run(sgl_team* T, double tol, int32_t maxit, double L1, double L2, uint64_t seed, uint64_t inv_density,
+                        double overfit_threshold, int32_t trace_test_mse, double* test_mse, int32_t* iter, double* tol_out,
+                        double* score_overfit, int32_t* n_trace, int32_t* n_iter, const sgl_callbacks* cb) {
+    if (trace_test_mse <= 0 || inv_density == 0 || !test_mse || !iter || !tol_out || !score_overfit || !n_trace) {
+        sgl_set_error("ard_run: bad arguments"); return SGL_EINVAL;
+    }
+    for (auto c : T->local) {
+        if (c->k == 0) { sgl_set_error("team: no fit initialised"); return SGL_ESTATE; }
+        if (c->k > SGL_MASK_MAX_K) { sgl_set_error("c_ard_nmf: rank %d above the masked path's limit of %d", c->k, SGL_MASK_MAX_K); return SGL_EINVAL; }
+    }
+    if (T->nranks > 1) {
+        bool have = true;
+        for (auto c : T->local) have = have && c->gene_nnz_global;
+        if (!have) SGLCHK(team_gene_counts(T));
+    }
+    SGLCHK(team_mask_workspace(T));
+    double tol_ = 1.0;
+    int nt = 0, it = 0;
+    auto push_trace = [&](int iter_now) -> int {   // l.1112-1121 / 1130-1141
+        double err = 0.0;
+        SGLCHK(team_mse_test(T, seed, inv_density, &err));
+        test_mse[nt] = err;
+        iter[nt] = iter_now;
+        tol_out[nt] = tol_;
+        double min_err = test_mse[0];
+        for (int t = 1; t <= nt; ++t) min_err = std::min(min_err, test_mse[t]);
+        score_overfit[nt] = (err - min_err) / (err + min_err);
+        ++nt;
+        return SGL_OK;
+    };
+    for (; it < maxit && tol_ > tol; ++it) {
+        SGLCHK(team_ard_iterate(T, L1, L2, seed, inv_density, &tol_));
+        if (it % trace_test_mse == 0) {
+            SGLCHK(push_trace(it));
+            if (cb && cb->log) cb->log(cb->user, it + 1, tol_, score_overfit[nt - 1]);
+            if (score_overfit[nt - 1] > overfit_threshold) break;
+        } else if (cb && cb->log) {
+            cb->log(cb->user, it + 1, tol_, NAN);
+        }
+        if (cb && cb->poll && cb->poll(cb->user)) { sgl_set_error("interrupted"); return SGL_EINTR; }
+    }
+    if (it % trace_test_mse != 0) SGLCHK(push_trace(it));
+    for (auto c : T->local) {
+        HIPCHK(hipSetDevice(c->device));
+        SGLCHK(sgl_fetch_sweeps(c));
+    }
+    *n_trace = nt;
+    if (n_iter) *n_iter = it;
+    return SGL_OK;
+}
+
+int sgl_ard_run_team(sgl_ctx* c, double tol, int32_t maxit, double L1, double L2, uint64_t seed, uint64_t inv_density,
+                     double overfit_threshold, int32_t trace_test_mse, double* test_mse, int32_t* iter, double* tol_out,
+                     double* score_overfit, int32_t* n_trace, int32_t* n_iter, const sgl_callbacks* cb) {
+    sgl_team* T = c->team;
+    if (!T || T->local.size() != 1) { sgl_set_error("sgl_ard_run: this context is driven by its sgl_multi; call sgl_multi_ard_run"); return SGL_ESTATE; }
+    T->nrow = c->A.nrow;
+    return team_ard_run(T, tol, maxit, L1, L2, seed, inv_density, overfit_threshold, trace_test_mse, test_mse, iter, tol_out,
+                        score_overfit, n_trace, n_iter, cb);
+}
+
 // ------------------------------------------------- one process per GPU (ABI) --
 extern "C" int sgl_comm_unique_id(void* id128) {
     if (!id128) { sgl_set_error("sgl_comm_unique_id: NULL buffer"); return SGL_EINVAL; }
@@ -609,6 +833,15 @@ extern "C" int sgl_multi_nmf_run(sgl_multi* M, double tol, int32_t maxit, double
     return team_nmf_run(M, tol, maxit, L1_w, L1_h, L2_w, L2_h, n_iter, tol_trace, cb);
 }
 
+extern "C" int sgl_multi_ard_run(sgl_multi* M, double tol, int32_t maxit, double L1, double L2, uint64_t seed, uint64_t inv_density,
+                                 double overfit_threshold, int32_t trace_test_mse, double* test_mse, int32_t* iter,
+                                 double* tol_out, double* score_overfit, int32_t* n_trace, int32_t* n_iter,
+                                 const sgl_callbacks* cb) {
+    TEAM_GUARD(M);
+    return team_ard_run(M, tol, maxit, L1, L2, seed, inv_density, overfit_threshold, trace_test_mse, test_mse, iter, tol_out,
+                        score_overfit, n_trace, n_iter, cb);
+}
+
 extern "C" int sgl_multi_get_factors(sgl_multi* M, double* w, double* d, double* h) {
     TEAM_GUARD(M);
     if (M->cell_lo.empty()) { sgl_set_error("sgl_multi_get_factors: no matrix resident"); return SGL_ESTATE; }
@@ -628,6 +861,23 @@ int sgl_c_nmf_multi(int ndev, const double* Ax, const int32_t* Ai, const int32_t
     int rc = sgl_multi_upload_csc(M, Ax, Ai, Ap, nrow, ncol);
     if (rc == SGL_OK) rc = sgl_multi_fit_init(M, k, w_init, 0);
     if (rc == SGL_OK) rc = sgl_multi_nmf_run(M, tol, maxit, L1_w, L1_h, L2_w, L2_h, n_iter, tol_trace, cb);
+    if (rc == SGL_OK) rc = sgl_multi_get_factors(M, w_out, d_out, h_out);
+    sgl_multi_destroy(M);
+    return rc;
+}
+
+int sgl_c_ard_nmf_multi(int ndev, const double* Ax, const int32_t* Ai, const int32_t* Ap, int32_t nrow, int32_t ncol, double tol,
+                        uint16_t maxit, double L1, double L2, const double* w_init, int32_t k, uint64_t seed, uint64_t inv_density,
+                        double overfit_threshold, uint16_t trace_test_mse, double* w_out, double* d_out, double* h_out,
+                        double* test_mse, int32_t* iter, double* tol_out, double* score_overfit, int32_t* n_trace,
+                        const sgl_callbacks* cb) {
+    sgl_multi* M = nullptr;
+    SGLCHK(sgl_multi_create(ndev, nullptr, &M));
+    int32_t nit = 0;
+    int rc = sgl_multi_upload_csc(M, Ax, Ai, Ap, nrow, ncol);
+    if (rc == SGL_OK) rc = sgl_multi_fit_init(M, k, w_init, 0);
+    if (rc == SGL_OK) rc = sgl_multi_ard_run(M, tol, maxit, L1, L2, seed, inv_density, overfit_threshold, trace_test_mse, test_mse,
+                                             iter, tol_out, score_overfit, n_trace, &nit, cb);
     if (rc == SGL_OK) rc = sgl_multi_get_factors(M, w_out, d_out, h_out);
     sgl_multi_destroy(M);
     return rc;

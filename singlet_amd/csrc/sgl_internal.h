@@ -112,6 +112,7 @@ struct sgl_ctx {
     double* Gcols = nullptr;   // masked path: per-column Grams of one chunk of columns (gcols_chunk * k * k)
     int64_t gcols_chunk = 0;
     double* Wd = nullptr;      // mse_test: W' = W^T diag(d) as k x m
+    double* Sbuf = nullptr;    // team masked W-update: per-gene downdate partials, (gene blocks x team size) x k x k
     struct sgl_team* team = nullptr;   // native collective (multi.hip): the team this context is a rank of
     int team_rank = 0;
     double* ws = nullptr;   // partial-reduction workspace
@@ -141,6 +142,21 @@ int sgl_nnls_shared(sgl_ctx* c, const double* G, double* B, double* X, const int
 int sgl_scale_w_enqueue(sgl_ctx* c);            // scale(w, d); cor(w, w_prev) -> device scalar
 int sgl_scale_w_fetch(sgl_ctx* c, double* tol); // copy it out (synchronises the stream)
 int sgl_fetch_sweeps(sgl_ctx* c);
+// masked path pieces (singlet_hip.hip) used by the team's sharded c_ard_nmf (multi.hip)
+int sgl_mask_workspace(sgl_ctx* c);
+int sgl_predict_mask_dev(sgl_ctx* c, const DevCSC& M, const int64_t* col_nnz, const double* F, double* X, double* Bbuf,
+                         uint64_t seed, uint64_t inv_density, double L1, double L2, int mask_t, int rhs_phase, int nnls_phase,
+                         unsigned long long* counter);
+int sgl_mse_test_enqueue(sgl_ctx* c, uint64_t seed, uint64_t inv_density);   // local loss sum -> c->scalars[1]
+int sgl_ard_run_team(sgl_ctx* c, double tol, int32_t maxit, double L1, double L2, uint64_t seed, uint64_t inv_density,
+                     double overfit_threshold, int32_t trace_test_mse, double* test_mse, int32_t* iter, double* tol_out,
+                     double* score_overfit, int32_t* n_trace, int32_t* n_iter, const sgl_callbacks* cb);
+int sgl_c_ard_nmf_multi(int ndev, const double* Ax, const int32_t* Ai, const int32_t* Ap, int32_t nrow, int32_t ncol, double tol,
+                        uint16_t maxit, double L1, double L2, const double* w_init, int32_t k, uint64_t seed, uint64_t inv_density,
+                        double overfit_threshold, uint16_t trace_test_mse, double* w_out, double* d_out, double* h_out,
+                        double* test_mse, int32_t* iter, double* tol_out, double* score_overfit, int32_t* n_trace,
+                        const sgl_callbacks* cb);
+#define SGL_MASK_MAX_K 128   // rank limit of the masked (ARD) path: the Gram downdate kernels cover k <= 128
 void sgl_team_detach(sgl_ctx* c);               // called by sgl_destroy
 int sgl_c_nmf_multi(int ndev, const double* Ax, const int32_t* Ai, const int32_t* Ap, int32_t nrow, int32_t ncol, double tol,
                     uint16_t maxit, double L1_w, double L1_h, double L2_w, double L2_h, const double* w_init, int32_t k,
@@ -215,6 +231,7 @@ int k_nnls_wave(hipStream_t s, const double* G, int64_t gstride, const double* B
 int k_mask_gram_cols(hipStream_t s, int64_t col0, int64_t ncols, int32_t nrow, const int64_t* col_nnz,
                      const double* F, const double* G, int k, uint64_t seed, uint64_t inv_density, int mask_t,
                      int64_t col_offset, int64_t row_offset, double* Gcols);
+int k_mask_gram_finalize(hipStream_t s, const double* G, const double* S, int k, int64_t ncols, double* out);
 int k_mse_test(sgl_ctx* c, const double* Wd, const double* H, int k, uint64_t seed, uint64_t inv_density,
                double* out_dev);
 int k_wd(hipStream_t s, const double* W, const double* d, int k, int64_t cols, double* Wd);

@@ -145,6 +145,7 @@ static void free_fit(sgl_ctx* c) {
     dev_free(c->Gcols);
     c->gcols_chunk = 0;
     dev_free(c->Wd);
+    dev_free(c->Sbuf);
     nnls_scratch_free(c->nnls_scr);
     dev_free(c->link_h);
     dev_free(c->link_w);
@@ -723,10 +724,8 @@ extern "C" int sgl_set_factors(sgl_ctx* c, const double* w, const double* d, con
 }
 
 // ------------------------------------------------------------- masked path --
-#define SGL_MASK_MAX_K 128   // rank limit of the masked (ARD) path: the Gram downdate kernels cover k <= 128
-
 // workspace of the masked path, kept in the fit (allocated on first use, freed with the fit)
-static int mask_workspace(sgl_ctx* c) {
+int sgl_mask_workspace(sgl_ctx* c) {
     const int k = c->k;
     if (!c->Gcols) {
         const int64_t widest = std::max<int64_t>(c->A.ncol, c->At.ncol);
@@ -740,11 +739,11 @@ static int mask_workspace(sgl_ctx* c) {
 
 // predict_mask (src/singlet.cpp:436-466) for one orientation, columns in
 // chunks so the per-column Grams a_i (k*k doubles each) stay bounded.
-static int predict_mask_dev(sgl_ctx* c, const DevCSC& M, const int64_t* col_nnz, const double* F, double* X,
+int sgl_predict_mask_dev(sgl_ctx* c, const DevCSC& M, const int64_t* col_nnz, const double* F, double* X,
                             double* Bbuf, uint64_t seed, uint64_t inv_density, double L1, double L2, int mask_t,
                             int rhs_phase, int nnls_phase, unsigned long long* counter) {
     const int k = c->k;
-    SGLCHK(mask_workspace(c));
+    SGLCHK(sgl_mask_workspace(c));
     // hash argument order: A pass draw(cell = col + cell_offset, gene = row); At pass draw(cell = row + cell_offset, gene = col)
     const int64_t col_off = mask_t ? 0 : c->cell_offset;
     const int64_t row_off = mask_t ? c->cell_offset : 0;
@@ -763,15 +762,17 @@ static int predict_mask_dev(sgl_ctx* c, const DevCSC& M, const int64_t* col_nnz,
     return SGL_OK;
 }
 
-static int mse_test_dev(sgl_ctx* c, uint64_t seed, uint64_t inv_density, double* out) {
+int sgl_mse_test_enqueue(sgl_ctx* c, uint64_t seed, uint64_t inv_density) {
     const int k = c->k;
     const int64_t m = c->A.nrow;
-    SGLCHK(mask_workspace(c));
-    {
-        Phase ph(c, SGL_PH_MASK);
-        SGLCHK(k_wd(c->stream, c->W, c->d, k, m, c->Wd));
-        SGLCHK(k_mse_test(c, c->Wd, c->H, k, seed, inv_density, c->scalars + 1));
-    }
+    SGLCHK(sgl_mask_workspace(c));
+    Phase ph(c, SGL_PH_MASK);
+    SGLCHK(k_wd(c->stream, c->W, c->d, k, m, c->Wd));
+    return k_mse_test(c, c->Wd, c->H, k, seed, inv_density, c->scalars + 1);
+}
+
+static int mse_test_dev(sgl_ctx* c, uint64_t seed, uint64_t inv_density, double* out) {
+    SGLCHK(sgl_mse_test_enqueue(c, seed, inv_density));
     SGLCHK(do_allreduce(c, c->scalars + 1, 1));
     hipError_t e = hipMemcpyAsync(c->pinned + 1, c->scalars + 1, sizeof(double), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -792,11 +793,14 @@ extern "C" int sgl_ard_run(sgl_ctx* c, double tol, int32_t maxit, double L1, dou
                            int32_t* iter, double* tol_out, double* score_overfit, int32_t* n_trace, int32_t* n_iter,
                            const sgl_callbacks* cb) {
     FIT_GUARD(c);
-    if (c->allreduce || c->team) { sgl_set_error("the masked (ARD) path is not cell-sharded yet; run it on one shard"); return SGL_EINVAL; }
+    if (c->allreduce) { sgl_set_error("the masked (ARD) path is cell-sharded on a native team only (sgl_multi_* / sgl_comm_init_rank), not through the all-reduce hook"); return SGL_EINVAL; }
     if (c->k > SGL_MASK_MAX_K) { sgl_set_error("c_ard_nmf: rank %d above the masked path's limit of %d", c->k, SGL_MASK_MAX_K); return SGL_EINVAL; }
     if (trace_test_mse <= 0 || inv_density == 0 || !test_mse || !iter || !tol_out || !score_overfit || !n_trace) {
         sgl_set_error("sgl_ard_run: bad arguments"); return SGL_EINVAL;
     }
+    if (c->team)   // native team, one process per GPU: the sharded loop of multi.hip
+        return sgl_ard_run_team(c, tol, maxit, L1, L2, seed, inv_density, overfit_threshold, trace_test_mse, test_mse, iter,
+                                tol_out, score_overfit, n_trace, n_iter, cb);
     double tol_ = 1.0;
     int nt = 0;
     int it = 0;
@@ -814,11 +818,11 @@ extern "C" int sgl_ard_run(sgl_ctx* c, double tol, int32_t maxit, double L1, dou
     };
     for (; it < maxit && tol_ > tol; ++it) {
         SGLCHK(sgl_step_begin(c));
-        SGLCHK(predict_mask_dev(c, c->A, c->col_nnz_A, c->W, c->H, c->B, seed, inv_density, L1, L2, 0, SGL_PH_RHS_H,
+        SGLCHK(sgl_predict_mask_dev(c, c->A, c->col_nnz_A, c->W, c->H, c->B, seed, inv_density, L1, L2, 0, SGL_PH_RHS_H,
                                 SGL_PH_NNLS_H, c->sweep_counters + 0));
         SGLCHK(sgl_step_scale_h(c));
         if (cb && cb->poll && cb->poll(cb->user)) { sgl_set_error("interrupted"); return SGL_EINTR; }
-        SGLCHK(predict_mask_dev(c, c->At, c->col_nnz_At, c->H, c->W, c->red, seed, inv_density, L1, L2, 1,
+        SGLCHK(sgl_predict_mask_dev(c, c->At, c->col_nnz_At, c->H, c->W, c->red, seed, inv_density, L1, L2, 1,
                                 SGL_PH_RHS_W, SGL_PH_NNLS_W, c->sweep_counters + 1));
         SGLCHK(sgl_step_scale_w(c, &tol_));
         if (it % trace_test_mse == 0) {
@@ -959,6 +963,14 @@ extern "C" int sgl_c_ard_nmf(const double* Ax, const int32_t* Ai, const int32_t*
     (void)verbose; (void)threads;
     if (!w_init || !w_out || !d_out || !h_out) { sgl_set_error("sgl_c_ard_nmf: NULL factor buffer"); return SGL_EINVAL; }
     if (k > SGL_MASK_MAX_K) { sgl_set_error("c_ard_nmf: rank %d above the masked path's limit of %d", k, SGL_MASK_MAX_K); return SGL_EINVAL; }
+    if (const char* e = getenv("SINGLET_NGPU")) {   // as in sgl_c_nmf
+        const int want = atoi(e);
+        if (want > 1) {
+            if (want > sgl_device_count()) { sgl_set_error("SINGLET_NGPU=%d but only %d gfx950 device(s) are visible", want, sgl_device_count()); return SGL_ENODEV; }
+            return sgl_c_ard_nmf_multi(want, Ax, Ai, Ap, nrow, ncol, tol, maxit, L1, L2, w_init, k, seed, inv_density, overfit_threshold,
+                                       trace_test_mse, w_out, d_out, h_out, test_mse, iter, tol_out, score_overfit, n_trace, cb);
+        }
+    }
     CtxHolder hd;
     SGLCHK(sgl_create(current_device_or_zero(), &hd.c));
     SGLCHK(sgl_upload_csc(hd.c, Ax, Ai, Ap, Atx, Ati, Atp, nrow, ncol, 0, ncol));

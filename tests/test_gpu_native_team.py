@@ -108,4 +108,43 @@ def test_team_refuses_what_it_does_not_support(sa, ora):
         with pytest.raises(sa.SingletHipError):
             c.step_w(0.0, 0.0)                          # step API is per shard; the team iterates as a whole
         with pytest.raises(sa.SingletHipError):
-            c.ard_run(0.0, 2, 0.01, 0.0, 1, 20, 1e9, 1)  # masked path is not sharded
+            c.ard_run(0.0, 2, 0.01, 0.0, 1, 20, 1e9, 1)  # a rank of a one-process team does not run the loop alone
+
+
+@pytest.mark.parametrize("m,n,k,ranks,inv", [(300, 900, 8, 2, 20), (257, 700, 30, 3, 10), (400, 520, 50, 2, 20), (420, 640, 70, 4, 10)])
+def test_sharded_masked_path_matches_the_oracle_and_the_single_shard(sa, ora, m, n, k, ranks, inv):
+    """c_ard_nmf with the cells sharded (src/singlet.cpp:469-503, 571-607 are the reference's own chunked
+    forms, `i + offset` at :485, `j + offset` at :590): per-gene right-hand sides and Gram downdates are
+    reduce-scattered by gene blocks, the loss sum all-reduced.  Same trace rows, same factors."""
+    A = ora.synth_csc(m, n, 10)
+    At = A.t()
+    w0 = ora.synth_winit(k, m)
+    seed = 977
+    ref = ora.c_ard_nmf(A, At, 0.0, 5, 0.01, 0.0, 0, w0, seed, inv, 1e9, 2)
+    one = sa.c_ard_nmf(to_dgc(sa, A), None, 0.0, 5, False, 0.01, 0.0, 0, w0.T, seed, inv, 1e9, 2)
+    with sa.Multi([0] * ranks) as M:
+        M.upload(to_dgc(sa, A))
+        M.fit_init(k, w0)
+        r = M.ard_run(0.0, 5, 0.01, 0.0, seed, inv, 1e9, 2)
+        W, d, H = M.get_factors()
+    assert list(r["iter"]) == list(ref["iter"]) == [0, 2, 4, 5]
+    assert rel_fro(r["test_mse"], ref["test_mse"]) < 1e-9 and rel_fro(r["tol"], ref["tol"]) < 1e-7
+    assert rel_fro(W, ref["w"]) < 1e-9 and rel_fro(H, ref["h"]) < 1e-9 and rel_fro(d, ref["d"]) < 1e-9
+    assert rel_fro(W, one["w"].T) < 1e-10 and rel_fro(H, one["h"].T) < 1e-10
+    assert rel_fro(r["test_mse"], one["test_mse"]) < 1e-11
+
+
+def test_sharded_masked_overfit_break_and_rccl_team_of_one(sa, ora):
+    """The overfit break (score > threshold, l.1124) happens at the same iteration on the team; and the masked
+    loop runs through RCCL itself as a team of one."""
+    m, n, k = 200, 500, 12
+    A = ora.synth_csc(m, n, 10)
+    w0 = ora.synth_winit(k, m)
+    one = sa.c_ard_nmf(to_dgc(sa, A), None, 0.0, 30, False, 0.0, 0.0, 0, w0.T, 5, 10, 1e-5, 1)
+    for devs in ([0, 0], [0]):
+        with sa.Multi(devs) as M:
+            M.upload(to_dgc(sa, A))
+            M.fit_init(k, w0)
+            r = M.ard_run(0.0, 30, 0.0, 0.0, 5, 10, 1e-5, 1)
+        assert list(r["iter"]) == list(one["iter"]) and rel_fro(r["test_mse"], one["test_mse"]) < 1e-10
+        assert rel_fro(r["score_overfit"], one["score_overfit"]) < 1e-6
