@@ -115,6 +115,45 @@ SGL_API int sgl_c_nmf_dense(const double* A, int32_t nrow, int32_t ncol,
                     double* w_out, double* d_out, double* h_out,
                     int32_t* n_iter, double* tol_trace, const sgl_callbacks* cb);
 
+/* c_ard_nmf_dense (src/singlet.cpp:1357-1361; dense predict_mask :506-533, mse_test :608-632), the branch
+ * R/ard_nmf.R:109 and R/cross_validate_nmf.R:82 take for a dense matrix.  Replaces _singlet_c_ard_nmf_dense
+ * (13 args; At is not needed).  Every column is solved, as in sgl_c_nmf_dense. */
+SGL_API int sgl_c_ard_nmf_dense(const double* A, int32_t nrow, int32_t ncol,
+                        double tol, uint16_t maxit, int verbose,
+                        double L1, double L2, uint16_t threads,
+                        const double* w_init, int32_t k,
+                        uint64_t seed, uint64_t inv_density, double overfit_threshold, uint16_t trace_test_mse,
+                        double* w_out, double* d_out, double* h_out,
+                        double* test_mse, int32_t* iter, double* tol_out, double* score_overfit, int32_t* n_trace,
+                        const sgl_callbacks* cb);
+
+/* c_nmf_sparse_list (src/singlet.cpp:715-743) and c_ard_nmf_sparse_list (:1162-1234): A as a LIST of column
+ * chunks (each nrow x chunk_ncol[q], dgCMatrix slots), as R/ard_nmf.R:114,181 passes it; the reference walks
+ * the chunks with a running column offset (:384-402, :485, :590).  Replace _singlet_c_nmf_sparse_list (9 args)
+ * and _singlet_c_ard_nmf_sparse_list (13 args).  The chunks are joined on the device into one resident matrix
+ * (64-bit column pointers: the total may exceed one dgCMatrix's 2^31 - 1 non-zeros).  At_: the list of column
+ * chunks of t(A) (each ncol_total x t_chunk_ncol[q]); n_t_chunks = 0 builds the transpose on the device. */
+SGL_API int sgl_c_nmf_sparse_list(int32_t n_chunks, const double* const* Ax, const int32_t* const* Ai, const int32_t* const* Ap,
+                          const int32_t* chunk_ncol,
+                          int32_t n_t_chunks, const double* const* Atx, const int32_t* const* Ati, const int32_t* const* Atp,
+                          const int32_t* t_chunk_ncol,
+                          int32_t nrow,
+                          double tol, uint16_t maxit, int verbose, double L1, double L2, uint16_t threads,
+                          const double* w_init, int32_t k,
+                          double* w_out, double* d_out, double* h_out,
+                          int32_t* n_iter, double* tol_trace, const sgl_callbacks* cb);
+SGL_API int sgl_c_ard_nmf_sparse_list(int32_t n_chunks, const double* const* Ax, const int32_t* const* Ai, const int32_t* const* Ap,
+                              const int32_t* chunk_ncol,
+                              int32_t n_t_chunks, const double* const* Atx, const int32_t* const* Ati, const int32_t* const* Atp,
+                              const int32_t* t_chunk_ncol,
+                              int32_t nrow,
+                              double tol, uint16_t maxit, int verbose, double L1, double L2, uint16_t threads,
+                              const double* w_init, int32_t k,
+                              uint64_t seed, uint64_t inv_density, double overfit_threshold, uint16_t trace_test_mse,
+                              double* w_out, double* d_out, double* h_out,
+                              double* test_mse, int32_t* iter, double* tol_out, double* score_overfit, int32_t* n_trace,
+                              const sgl_callbacks* cb);
+
 /* c_linked_nmf (src/singlet.cpp:1059-1086; predict_link :416-433), the linked
  * NMF behind R/RunLNMF.R:60.  Replaces _singlet_c_linked_nmf (11 args).  link_h
  * (link_h_rows x link_h_cols, column-major) multiplies the first link_h_rows
@@ -173,6 +212,13 @@ SGL_API int sgl_set_stream(sgl_ctx* ctx, void* hip_stream);
 SGL_API int sgl_upload_csc(sgl_ctx* ctx, const double* Ax, const int32_t* Ai, const int32_t* Ap,
                    const double* Atx, const int32_t* Ati, const int32_t* Atp,
                    int32_t nrow, int32_t ncol, int64_t cell_offset, int64_t ncells_total);
+
+/* The same from a list of column chunks (sgl_c_nmf_sparse_list above): the chunks become ONE resident shard. */
+SGL_API int sgl_upload_csc_list(sgl_ctx* ctx, int32_t n_chunks, const double* const* Ax, const int32_t* const* Ai,
+                        const int32_t* const* Ap, const int32_t* chunk_ncol,
+                        int32_t n_t_chunks, const double* const* Atx, const int32_t* const* Ati, const int32_t* const* Atp,
+                        const int32_t* t_chunk_ncol,
+                        int32_t nrow, int64_t cell_offset, int64_t ncells_total);
 
 /* Generate the synthetic benchmark shard on the device:
  * entry (gene g, cell c) non-zero iff rand_S(c,g) % inv_density == 0, value

@@ -79,6 +79,19 @@ def lib():
         L.ora_c_ard_nmf.argtypes = csc + csc + [C.c_int32, C.c_int32, C.c_double, C.c_int, C.c_double, C.c_double,
                                                 C.c_int, C.c_int, _f64p, _f64p, _f64p, C.c_uint64, C.c_uint64,
                                                 C.c_double, C.c_int, _f64p, _i32p, _f64p, _f64p, _i32p]
+        pp_f, pp_i = C.POINTER(_f64p), C.POINTER(_i32p)
+        lst = [C.c_int, pp_f, pp_i, pp_i, _i32p]
+        L.ora_c_nmf_sparse_list.restype = C.c_int
+        L.ora_c_nmf_sparse_list.argtypes = lst + lst + [C.c_int32, C.c_int32, C.c_double, C.c_int, C.c_double, C.c_double,
+                                                        C.c_int, C.c_int, _f64p, _f64p, _f64p, _f64p]
+        L.ora_c_ard_nmf_sparse_list.restype = C.c_int
+        L.ora_c_ard_nmf_sparse_list.argtypes = lst + lst + [C.c_int32, C.c_int32, C.c_double, C.c_int, C.c_double, C.c_double,
+                                                            C.c_int, C.c_int, _f64p, _f64p, _f64p, C.c_uint64, C.c_uint64,
+                                                            C.c_double, C.c_int, _f64p, _i32p, _f64p, _f64p, _i32p]
+        L.ora_c_ard_nmf_dense.restype = C.c_int
+        L.ora_c_ard_nmf_dense.argtypes = [_f64p, _f64p, C.c_int32, C.c_int32, C.c_double, C.c_int, C.c_double, C.c_double,
+                                          C.c_int, C.c_int, _f64p, _f64p, _f64p, C.c_uint64, C.c_uint64, C.c_double, C.c_int,
+                                          _f64p, _i32p, _f64p, _f64p, _i32p]
         L.ora_log_normalize.restype = None
         L.ora_log_normalize.argtypes = [_f64p, _i32p, C.c_int32, C.c_double]
         L.ora_weight_by_split.restype = None
@@ -326,6 +339,65 @@ def c_ard_nmf(A, At, tol, maxit, L1, L2, threads, w, seed, inv_density, overfit_
     q = nt.value
     return dict(w=w, d=d, h=h, test_mse=tm[:q].copy(), iter=itv[:q].copy(), tol=ft[:q].copy(),
                 score_overfit=so[:q].copy(), n_iter=it)
+
+
+def _csc_list(chunks):
+    """ctypes view of a list of CSC chunks: (count, x**, i**, p**, ncol*) + keep-alive objects"""
+    n = len(chunks)
+    xs = (_f64p * n)(*[_p(c.x, _f64p) for c in chunks])
+    is_ = (_i32p * n)(*[_p(c.i, _i32p) for c in chunks])
+    ps = (_i32p * n)(*[_p(c.p, _i32p) for c in chunks])
+    nc = np.array([c.ncol for c in chunks], dtype=np.int32)
+    return (n, xs, is_, ps, _p(nc, _i32p)), (xs, is_, ps, nc, chunks)
+
+
+def c_nmf_sparse_list(A_, At_, tol, maxit, L1, L2, threads, w):
+    """c_nmf_sparse_list (src/singlet.cpp:715-743): A_ column chunks of A, At_ column chunks of t(A)."""
+    a, keep_a = _csc_list(A_)
+    t, keep_t = _csc_list(At_)
+    w = np.array(w, dtype=np.float64, order="C")
+    m, k = w.shape
+    n = At_[0].nrow
+    h, d, tr = np.empty((n, k)), np.empty(k), np.zeros(max(int(maxit), 1))
+    it = lib().ora_c_nmf_sparse_list(*a, *t, m, n, tol, int(maxit), L1, L2, threads, k, _p(w, _f64p), _p(h, _f64p),
+                                     _p(d, _f64p), _p(tr, _f64p))
+    return dict(w=w, d=d, h=h, iter=it, tol=tr[:it].copy())
+
+
+def c_ard_nmf_sparse_list(A_, At_, tol, maxit, L1, L2, threads, w, seed, inv_density, overfit_threshold, trace_test_mse):
+    """c_ard_nmf_sparse_list (src/singlet.cpp:1162-1234)."""
+    a, keep_a = _csc_list(A_)
+    t, keep_t = _csc_list(At_)
+    w = np.array(w, dtype=np.float64, order="C")
+    m, k = w.shape
+    n = At_[0].nrow
+    h, d = np.empty((n, k)), np.empty(k)
+    cap = maxit + 2
+    tm, ft, so, itv, nt = np.zeros(cap), np.zeros(cap), np.zeros(cap), np.zeros(cap, dtype=np.int32), C.c_int32(0)
+    it = lib().ora_c_ard_nmf_sparse_list(*a, *t, m, n, tol, int(maxit), L1, L2, threads, k, _p(w, _f64p), _p(h, _f64p),
+                                         _p(d, _f64p), seed, inv_density, overfit_threshold, trace_test_mse, _p(tm, _f64p),
+                                         _p(itv, _i32p), _p(ft, _f64p), _p(so, _f64p), C.byref(nt))
+    q = nt.value
+    return dict(w=w, d=d, h=h, test_mse=tm[:q].copy(), iter=itv[:q].copy(), tol=ft[:q].copy(), score_overfit=so[:q].copy(),
+                n_iter=it)
+
+
+def c_ard_nmf_dense(A, tol, maxit, L1, L2, threads, w, seed, inv_density, overfit_threshold, trace_test_mse):
+    """c_ard_nmf_dense (src/singlet.cpp:1357-1361).  A: dense (m, n) array."""
+    A = np.asarray(A, dtype=np.float64)
+    m, n = A.shape
+    Af, Atf = np.ascontiguousarray(A.T), np.ascontiguousarray(A)
+    w = np.array(w, dtype=np.float64, order="C")
+    k = w.shape[1]
+    h, d = np.empty((n, k)), np.empty(k)
+    cap = maxit + 2
+    tm, ft, so, itv, nt = np.zeros(cap), np.zeros(cap), np.zeros(cap), np.zeros(cap, dtype=np.int32), C.c_int32(0)
+    it = lib().ora_c_ard_nmf_dense(_p(Af, _f64p), _p(Atf, _f64p), m, n, tol, int(maxit), L1, L2, threads, k, _p(w, _f64p),
+                                   _p(h, _f64p), _p(d, _f64p), seed, inv_density, overfit_threshold, trace_test_mse,
+                                   _p(tm, _f64p), _p(itv, _i32p), _p(ft, _f64p), _p(so, _f64p), C.byref(nt))
+    q = nt.value
+    return dict(w=w, d=d, h=h, test_mse=tm[:q].copy(), iter=itv[:q].copy(), tol=ft[:q].copy(), score_overfit=so[:q].copy(),
+                n_iter=it)
 
 
 def log_normalize(A, scale_factor=10000.0):

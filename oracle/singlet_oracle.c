@@ -552,6 +552,292 @@ ORA_API int ora_c_ard_nmf(const double* Ax, const int32_t* Ai, const int32_t* Ap
     return iter_;
 }
 
+/* ------------------------------------------------ column-chunk lists --
+ * The reference's `std::vector<Rcpp::SparseMatrix>` overloads walk a list of column chunks with a running
+ * `offset` added to the column index (predict :384-402, predict_mask :469-503 with `i + offset` at :485,
+ * mse_test :571-607 with `j + offset` at :590).  A_ holds column chunks of A (all m rows), At_ column
+ * chunks of t(A) (all n rows). */
+typedef struct {
+    int n;
+    const double* const* x;
+    const int32_t* const* i;
+    const int32_t* const* p;
+    const int32_t* ncol;
+    int32_t nrow;
+} csc_list_t;
+
+static void predict_list(csc_list_t L, const double* F, double* X, int k, double L1, double L2, int threads) {
+    double* a = (double*)malloc(sizeof(double) * k * k);
+    ora_aat(F, k, L.nrow, a);
+    size_t offset = 0;
+    for (int chunk = 0; chunk < L.n; ++chunk) {
+        const int32_t* p = L.p[chunk];
+#pragma omp parallel for num_threads(pick_threads(threads))
+        for (int64_t c = 0; c < L.ncol[chunk]; ++c) {
+            if (p[c] == p[c + 1]) continue;
+            double b[k];
+            for (int j = 0; j < k; ++j) b[j] = 0.0;
+            for (int32_t q = p[c]; q < p[c + 1]; ++q) {
+                const double v = L.x[chunk][q];
+                const double* f = F + (size_t)L.i[chunk][q] * k;
+                for (int j = 0; j < k; ++j) b[j] += v * f[j];
+            }
+            nnls_col(a, b, X + ((size_t)c + offset) * k, k, L1, L2);   /* nnls(a, b, h, i + offset, L1, L2) */
+        }
+        offset += (size_t)L.ncol[chunk];
+    }
+    free(a);
+}
+
+static void predict_mask_list(csc_list_t L, uint64_t seed, uint64_t inv_density, const double* F, double* X, int k,
+                              double L1, double L2, int threads, int mask_t) {
+    size_t offset = 0;
+    for (int chunk = 0; chunk < L.n; ++chunk) {
+        csc_t A = {L.x[chunk], L.i[chunk], L.p[chunk], L.nrow, L.ncol[chunk]};
+        /* the chunk's columns are the global columns offset .. offset + ncol: hash on i + offset (l.485),
+         * solve into column i + offset of h (l.498) */
+        predict_mask(A, seed, inv_density, F, X + offset * k, k, L1, L2, threads, mask_t, (uint64_t)offset, 0);
+        offset += (size_t)L.ncol[chunk];
+    }
+}
+
+static double mse_test_list(csc_list_t L, const double* w, const double* d, const double* h, int k, uint64_t seed,
+                            uint64_t inv_density, int threads, int64_t n_total) {
+    const int64_t m = L.nrow;
+    double* w_ = (double*)malloc(sizeof(double) * (size_t)m * k);
+    for (int64_t i = 0; i < m; ++i)
+        for (int j = 0; j < k; ++j) w_[(size_t)i * k + j] = w[(size_t)i * k + j] * d[j];
+    double* losses = (double*)malloc(sizeof(double) * (size_t)(n_total > 0 ? n_total : 1));
+    size_t offset = 0;
+    for (int chunk = 0; chunk < L.n; ++chunk) {
+        const int32_t* p = L.p[chunk];
+#pragma omp parallel for num_threads(pick_threads(threads))
+        for (int64_t j = 0; j < L.ncol[chunk]; ++j) {
+            uint64_t cnt = 0;
+            double s = 0;
+            int32_t q = p[j];
+            const int32_t qend = p[j + 1];
+            const double* hj = h + ((size_t)j + offset) * k;
+            for (int64_t i = 0; i < m; ++i) {
+                if (ora_rng_draw(seed, (uint64_t)j + offset, (uint64_t)i, inv_density)) {
+                    ++cnt;
+                    double pred = 0;
+                    const double* wi = w_ + (size_t)i * k;
+                    for (int t = 0; t < k; ++t) pred += wi[t] * hj[t];
+                    if (q < qend && i == L.i[chunk][q]) {
+                        const double e = pred - L.x[chunk][q];
+                        s += e * e;
+                        ++q;
+                    } else {
+                        s += pred * pred;
+                    }
+                } else if (q < qend && i == L.i[chunk][q]) {
+                    ++q;
+                }
+            }
+            losses[(size_t)j + offset] = (cnt > 0) ? s / (double)cnt : 0;
+        }
+        offset += (size_t)L.ncol[chunk];
+    }
+    double tot = 0;
+    for (int64_t j = 0; j < n_total; ++j) tot += losses[j];
+    free(losses);
+    free(w_);
+    return tot / (double)n_total;
+}
+
+/* c_nmf_sparse_list -- src/singlet.cpp:715-743.  m = A[0].rows(), n = At[0].rows(). */
+ORA_API int ora_c_nmf_sparse_list(int nA, const double* const* Ax, const int32_t* const* Ai, const int32_t* const* Ap,
+                                  const int32_t* Ancol, int nAt, const double* const* Atx, const int32_t* const* Ati,
+                                  const int32_t* const* Atp, const int32_t* Atncol, int32_t m, int32_t n, double tol, int maxit,
+                                  double L1, double L2, int threads, int k, double* w, double* h, double* d,
+                                  double* tol_trace) {
+    csc_list_t A = {nA, Ax, Ai, Ap, Ancol, m};
+    csc_list_t At = {nAt, Atx, Ati, Atp, Atncol, n};
+    memset(h, 0, sizeof(double) * (size_t)k * (size_t)n);
+    for (int i = 0; i < k; ++i) d[i] = 1.0;
+    double tol_ = 1;
+    double* w_it = (double*)malloc(sizeof(double) * (size_t)k * (size_t)m);
+    int iter_ = 0;
+    for (; iter_ < maxit && tol_ > tol; ++iter_) {
+        memcpy(w_it, w, sizeof(double) * (size_t)k * (size_t)m);
+        predict_list(A, w, h, k, L1, L2, threads);
+        ora_scale(h, k, n, d);
+        predict_list(At, h, w, k, L1, L2, threads);
+        ora_scale(w, k, m, d);
+        tol_ = ora_cor(w, w_it, (size_t)k * (size_t)m);
+        if (tol_trace) tol_trace[iter_] = tol_;
+    }
+    free(w_it);
+    return iter_;
+}
+
+/* c_ard_nmf_sparse_list -- src/singlet.cpp:1162-1234 */
+ORA_API int ora_c_ard_nmf_sparse_list(int nA, const double* const* Ax, const int32_t* const* Ai, const int32_t* const* Ap,
+                                      const int32_t* Ancol, int nAt, const double* const* Atx, const int32_t* const* Ati,
+                                      const int32_t* const* Atp, const int32_t* Atncol, int32_t m, int32_t n, double tol,
+                                      int maxit, double L1, double L2, int threads, int k, double* w, double* h, double* d,
+                                      uint64_t rng_seed, uint64_t inv_density, double overfit_threshold, int trace_test_mse,
+                                      double* test_mse, int32_t* iter, double* fit_tol, double* score_overfit,
+                                      int32_t* n_trace) {
+    csc_list_t A = {nA, Ax, Ai, Ap, Ancol, m};
+    csc_list_t At = {nAt, Atx, Ati, Atp, Atncol, n};
+    memset(h, 0, sizeof(double) * (size_t)k * (size_t)n);
+    for (int i = 0; i < k; ++i) d[i] = 1.0;
+    double tol_ = 1;
+    int nt = 0;
+    double* w_it = (double*)malloc(sizeof(double) * (size_t)k * (size_t)m);
+    int iter_ = 0;
+    for (; iter_ < maxit && tol_ > tol; ++iter_) {
+        memcpy(w_it, w, sizeof(double) * (size_t)k * (size_t)m);
+        predict_mask_list(A, rng_seed, inv_density, w, h, k, L1, L2, threads, 0);
+        ora_scale(h, k, n, d);
+        predict_mask_list(At, rng_seed, inv_density, h, w, k, L1, L2, threads, 1);
+        ora_scale(w, k, m, d);
+        tol_ = ora_cor(w, w_it, (size_t)k * (size_t)m);
+        if (iter_ % trace_test_mse == 0) {
+            test_mse[nt] = mse_test_list(A, w, d, h, k, rng_seed, inv_density, threads, n);
+            iter[nt] = iter_;
+            fit_tol[nt] = tol_;
+            const double this_err = test_mse[nt];
+            double min_err = test_mse[0];
+            for (int t = 1; t <= nt; ++t)
+                if (test_mse[t] < min_err) min_err = test_mse[t];
+            score_overfit[nt] = (this_err - min_err) / (this_err + min_err);
+            ++nt;
+            if (score_overfit[nt - 1] > overfit_threshold) break;
+        }
+    }
+    if (iter_ % trace_test_mse != 0) {
+        test_mse[nt] = mse_test_list(A, w, d, h, k, rng_seed, inv_density, threads, n);
+        iter[nt] = iter_;
+        fit_tol[nt] = tol_;
+        double min_err = test_mse[0];
+        for (int t = 1; t <= nt; ++t)
+            if (test_mse[t] < min_err) min_err = test_mse[t];
+        const double this_err = test_mse[nt];
+        score_overfit[nt] = (this_err - min_err) / (this_err + min_err);
+        ++nt;
+    }
+    *n_trace = nt;
+    free(w_it);
+    return iter_;
+}
+
+/* ------------------------------------------------ dense masked path --
+ * predict_mask for a dense matrix -- src/singlet.cpp:506-533: EVERY column is solved, every row j that is not
+ * drawn adds A(j, i) * w.col(j) (zeros add exact zeros).  A: rows x cols column-major. */
+static void predict_mask_dense(const double* A, int64_t rows, int64_t cols, uint64_t seed, uint64_t inv_density,
+                               const double* F, double* X, int k, double L1, double L2, int threads, int mask_t) {
+    double* a = (double*)malloc(sizeof(double) * k * k);
+    ora_aat(F, k, rows, a);
+#pragma omp parallel for num_threads(pick_threads(threads))
+    for (int64_t c = 0; c < cols; ++c) {
+        double b[k];
+        for (int j = 0; j < k; ++j) b[j] = 0.0;
+        int64_t* idx = (int64_t*)malloc(sizeof(int64_t) * (size_t)(rows > 0 ? rows : 1));
+        int64_t nidx = 0;
+        for (int64_t j = 0; j < rows; ++j) {
+            const int drawn = mask_t ? ora_rng_draw(seed, (uint64_t)j, (uint64_t)c, inv_density)
+                                     : ora_rng_draw(seed, (uint64_t)c, (uint64_t)j, inv_density);
+            if (drawn) {
+                idx[nidx++] = j;
+            } else {
+                const double v = A[(size_t)c * rows + j];
+                const double* f = F + (size_t)j * k;
+                for (int jj = 0; jj < k; ++jj) b[jj] += v * f[jj];
+            }
+        }
+        double* wsub = (double*)malloc(sizeof(double) * (size_t)k * (size_t)(nidx > 0 ? nidx : 1));
+        for (int64_t t = 0; t < nidx; ++t) memcpy(wsub + (size_t)t * k, F + (size_t)idx[t] * k, sizeof(double) * k);
+        double asub[k * k], a_i[k * k];
+        ora_aat(wsub, k, nidx, asub);
+        for (int t = 0; t < k * k; ++t) a_i[t] = a[t] - asub[t];
+        nnls_col(a_i, b, X + (size_t)c * k, k, L1, L2);
+        free(wsub);
+        free(idx);
+    }
+    free(a);
+}
+
+/* mse_test for a dense matrix -- src/singlet.cpp:608-632 */
+static double mse_test_dense(const double* A, int64_t m, int64_t n, const double* w, const double* d, const double* h, int k,
+                             uint64_t seed, uint64_t inv_density, int threads) {
+    double* w_ = (double*)malloc(sizeof(double) * (size_t)m * k);
+    for (int64_t i = 0; i < m; ++i)
+        for (int j = 0; j < k; ++j) w_[(size_t)i * k + j] = w[(size_t)i * k + j] * d[j];
+    double* losses = (double*)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+#pragma omp parallel for num_threads(pick_threads(threads))
+    for (int64_t j = 0; j < n; ++j) {
+        uint64_t cnt = 0;
+        double s = 0;
+        const double* hj = h + (size_t)j * k;
+        for (int64_t i = 0; i < m; ++i) {
+            if (ora_rng_draw(seed, (uint64_t)j, (uint64_t)i, inv_density)) {
+                ++cnt;
+                double pred = 0;
+                const double* wi = w_ + (size_t)i * k;
+                for (int t = 0; t < k; ++t) pred += wi[t] * hj[t];
+                const double e = pred - A[(size_t)j * m + i];
+                s += e * e;
+            }
+        }
+        losses[j] = (cnt > 0) ? s / (double)cnt : 0;
+    }
+    double tot = 0;
+    for (int64_t j = 0; j < n; ++j) tot += losses[j];
+    free(losses);
+    free(w_);
+    return tot / (double)n;
+}
+
+/* c_ard_nmf_dense -- src/singlet.cpp:1357-1361 (c_ard_nmf_base on Eigen::MatrixXd).  A: m x n, At: n x m, column-major. */
+ORA_API int ora_c_ard_nmf_dense(const double* A, const double* At, int32_t m, int32_t n, double tol, int maxit, double L1,
+                                double L2, int threads, int k, double* w, double* h, double* d, uint64_t rng_seed,
+                                uint64_t inv_density, double overfit_threshold, int trace_test_mse, double* test_mse,
+                                int32_t* iter, double* fit_tol, double* score_overfit, int32_t* n_trace) {
+    memset(h, 0, sizeof(double) * (size_t)k * (size_t)n);
+    for (int i = 0; i < k; ++i) d[i] = 1.0;
+    double tol_ = 1;
+    int nt = 0;
+    double* w_it = (double*)malloc(sizeof(double) * (size_t)k * (size_t)m);
+    int iter_ = 0;
+    for (; iter_ < maxit && tol_ > tol; ++iter_) {
+        memcpy(w_it, w, sizeof(double) * (size_t)k * (size_t)m);
+        predict_mask_dense(A, m, n, rng_seed, inv_density, w, h, k, L1, L2, threads, 0);
+        ora_scale(h, k, n, d);
+        predict_mask_dense(At, n, m, rng_seed, inv_density, h, w, k, L1, L2, threads, 1);
+        ora_scale(w, k, m, d);
+        tol_ = ora_cor(w, w_it, (size_t)k * (size_t)m);
+        if (iter_ % trace_test_mse == 0) {
+            test_mse[nt] = mse_test_dense(A, m, n, w, d, h, k, rng_seed, inv_density, threads);
+            iter[nt] = iter_;
+            fit_tol[nt] = tol_;
+            const double this_err = test_mse[nt];
+            double min_err = test_mse[0];
+            for (int t = 1; t <= nt; ++t)
+                if (test_mse[t] < min_err) min_err = test_mse[t];
+            score_overfit[nt] = (this_err - min_err) / (this_err + min_err);
+            ++nt;
+            if (score_overfit[nt - 1] > overfit_threshold) break;
+        }
+    }
+    if (iter_ % trace_test_mse != 0) {
+        test_mse[nt] = mse_test_dense(A, m, n, w, d, h, k, rng_seed, inv_density, threads);
+        iter[nt] = iter_;
+        fit_tol[nt] = tol_;
+        double min_err = test_mse[0];
+        for (int t = 1; t <= nt; ++t)
+            if (test_mse[t] < min_err) min_err = test_mse[t];
+        const double this_err = test_mse[nt];
+        score_overfit[nt] = (this_err - min_err) / (this_err + min_err);
+        ++nt;
+    }
+    *n_trace = nt;
+    free(w_it);
+    return iter_;
+}
+
 /* ------------------------------------------------ synthetic generator --
  * Not reference code: the deterministic benchmark input of SURVEY.md 8(d),
  * restated here so CPU baseline and HIP path see bit-identical matrices.

@@ -36,6 +36,8 @@ class SingletHipError(RuntimeError):
 
 # every symbol include/singlet_hip.h declares: name -> (restype, argtypes)
 _CSC = [f64p, i32p, i32p]
+_PPF, _PPI = C.POINTER(f64p), C.POINTER(i32p)
+_LIST = [C.c_int32, _PPF, _PPI, _PPI, i32p]
 _CB = C.POINTER(Callbacks)
 SIGNATURES = {
     "sgl_last_error": (C.c_char_p, []),
@@ -50,6 +52,15 @@ SIGNATURES = {
                                               _CB]),
     "sgl_c_nmf_dense": (C.c_int, [f64p, C.c_int32, C.c_int32, C.c_double, C.c_uint16, C.c_int, C.c_double, C.c_double,
                                   C.c_double, C.c_double, C.c_uint16, f64p, C.c_int32, f64p, f64p, f64p, i32p, f64p, _CB]),
+    "sgl_c_ard_nmf_dense": (C.c_int, [f64p, C.c_int32, C.c_int32, C.c_double, C.c_uint16, C.c_int, C.c_double, C.c_double,
+                                      C.c_uint16, f64p, C.c_int32, C.c_uint64, C.c_uint64, C.c_double, C.c_uint16, f64p, f64p,
+                                      f64p, f64p, i32p, f64p, f64p, i32p, _CB]),
+    "sgl_c_nmf_sparse_list": (C.c_int, _LIST + _LIST + [C.c_int32, C.c_double, C.c_uint16, C.c_int, C.c_double, C.c_double,
+                                                        C.c_uint16, f64p, C.c_int32, f64p, f64p, f64p, i32p, f64p, _CB]),
+    "sgl_c_ard_nmf_sparse_list": (C.c_int, _LIST + _LIST + [C.c_int32, C.c_double, C.c_uint16, C.c_int, C.c_double, C.c_double,
+                                                            C.c_uint16, f64p, C.c_int32, C.c_uint64, C.c_uint64, C.c_double,
+                                                            C.c_uint16, f64p, f64p, f64p, f64p, i32p, f64p, f64p, i32p, _CB]),
+    "sgl_upload_csc_list": (C.c_int, [C.c_void_p] + _LIST + _LIST + [C.c_int32, C.c_int64, C.c_int64]),
     "sgl_c_linked_nmf": (C.c_int, _CSC + _CSC + [C.c_int32, C.c_int32, C.c_double, C.c_uint16, C.c_int, C.c_double,
                                                  C.c_double, C.c_uint16, f64p, C.c_int32, f64p, C.c_int32, C.c_int32, f64p,
                                                  C.c_int32, C.c_int32, f64p, f64p, f64p, i32p, f64p, _CB]),

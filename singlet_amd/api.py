@@ -94,23 +94,97 @@ def c_nmf_dense(A, At, tol, maxit, verbose, L1_w, L1_h, L2_w, L2_h, threads, w):
     return {"w": w_out.T, "d": d_out, "h": h_out.T, "iter": n_iter.value, "tol": tr[:n_iter.value].copy()}
 
 
-def c_nmf_sparse_list(A_, At_, tol, maxit, verbose, L1, L2, threads, w):
-    """.Call(`_singlet_c_nmf_sparse_list`, ...)  (src/singlet.cpp:715-743): A_ is a list of column chunks
-    of A (the predict over chunks carries a running column offset, :384-402), At_ a list of column
-    chunks of t(A).  The chunks are concatenated on the host and run as one matrix: same sums, same
-    solves, same order."""
-    chunks = [as_dgCMatrix(a) for a in A_]
-    if not chunks:
+def _chunk_list(chunks):
+    """ctypes image of a list of dgCMatrix column chunks: (n, x**, i**, p**, ncol*) and what must stay alive"""
+    chunks = [as_dgCMatrix(a) for a in chunks]
+    n = len(chunks)
+    xs = (f64p * n)(*[ptr(a.x, f64p) for a in chunks])
+    is_ = (i32p * n)(*[ptr(a.i, i32p) for a in chunks])
+    ps = (i32p * n)(*[ptr(a.p, i32p) for a in chunks])
+    nc = np.array([a.ncol for a in chunks], dtype=np.int32)
+    return (n, xs, is_, ps, ptr(nc, i32p)), (chunks, xs, is_, ps, nc)
+
+
+def _list_args(A_, At_):
+    A_ = list(A_)
+    if not A_:
         raise ValueError("A_ must hold at least one matrix")
-    nrow = chunks[0].nrow
-    if any(a.nrow != nrow for a in chunks):
+    a, keep_a = _chunk_list(A_)
+    nrow = keep_a[0][0].nrow
+    if any(c.nrow != nrow for c in keep_a[0]):
         raise ValueError("all chunks of A_ must have the same number of rows")
-    x = np.concatenate([a.x for a in chunks])
-    i = np.concatenate([a.i for a in chunks])
-    off = np.cumsum([0] + [a.nnz for a in chunks[:-1]])
-    p = np.concatenate([chunks[0].p[:1]] + [a.p[1:] + o for a, o in zip(chunks, off)])
-    A = dgCMatrix(x, i, p, (nrow, sum(a.ncol for a in chunks)))
-    return c_nmf(A, None, tol, maxit, verbose, L1, L1, L2, L2, threads, w)
+    if At_ is None or len(At_) == 0:
+        t, keep_t = (0, None, None, None, None), None
+    else:
+        t, keep_t = _chunk_list(At_)
+    n = sum(c.ncol for c in keep_a[0])
+    return a, t, nrow, n, (keep_a, keep_t)
+
+
+def c_nmf_sparse_list(A_, At_, tol, maxit, verbose, L1, L2, threads, w):
+    """.Call(`_singlet_c_nmf_sparse_list`, ...)  (src/singlet.cpp:715-743): A_ is a list of column chunks of A
+    (the predict over chunks carries a running column offset, :384-402), At_ a list of column chunks of t(A)
+    (None / empty: the transpose is built on the device).  The chunks are joined on the device."""
+    L = _lib.load()
+    a, t, nrow, n, keep = _list_args(A_, At_)
+    wb = _w_in(w, nrow)
+    m, k = wb.shape
+    w_out, h_out, d_out = np.empty((m, k)), np.empty((n, k)), np.empty(k)
+    n_iter = C.c_int32()
+    tr = np.zeros(max(int(maxit), 1))
+    cb = make_callbacks(_verbose_log(verbose))
+    check(L.sgl_c_nmf_sparse_list(*a, *t, nrow, float(tol), int(maxit), int(bool(verbose)), L1, L2, int(threads), ptr(wb, f64p), k,
+                                  ptr(w_out, f64p), ptr(d_out, f64p), ptr(h_out, f64p), C.byref(n_iter), ptr(tr, f64p),
+                                  C.byref(cb)))
+    return {"w": w_out.T, "d": d_out, "h": h_out.T, "iter": n_iter.value, "tol": tr[:n_iter.value].copy()}
+
+
+def c_ard_nmf_sparse_list(A_, At_, tol, maxit, verbose, L1, L2, threads, w, rng_seed, inv_density, overfit_threshold,
+                          trace_test_mse):
+    """.Call(`_singlet_c_ard_nmf_sparse_list`, ...)  (src/singlet.cpp:1162-1234)."""
+    L = _lib.load()
+    a, t, nrow, n, keep = _list_args(A_, At_)
+    wb = _w_in(w, nrow)
+    m, k = wb.shape
+    w_out, h_out, d_out = np.empty((m, k)), np.empty((n, k)), np.empty(k)
+    cap = int(maxit) + 2
+    tm, ft, so = np.zeros(cap), np.zeros(cap), np.zeros(cap)
+    itv = np.zeros(cap, dtype=np.int32)
+    nt = C.c_int32()
+    cb = make_callbacks(_verbose_log(verbose, ard=True))
+    check(L.sgl_c_ard_nmf_sparse_list(*a, *t, nrow, float(tol), int(maxit), int(bool(verbose)), L1, L2, int(threads),
+                                      ptr(wb, f64p), k, int(rng_seed), int(inv_density), float(overfit_threshold),
+                                      int(trace_test_mse), ptr(w_out, f64p), ptr(d_out, f64p), ptr(h_out, f64p), ptr(tm, f64p),
+                                      ptr(itv, i32p), ptr(ft, f64p), ptr(so, f64p), C.byref(nt), C.byref(cb)))
+    q = nt.value
+    return {"w": w_out.T, "d": d_out, "h": h_out.T, "test_mse": tm[:q].copy(), "iter": itv[:q].copy(),
+            "tol": ft[:q].copy(), "score_overfit": so[:q].copy()}
+
+
+def c_ard_nmf_dense(A, At, tol, maxit, verbose, L1, L2, threads, w, seed, inv_density, overfit_threshold, trace_test_mse):
+    """.Call(`_singlet_c_ard_nmf_dense`, ...)  (src/singlet.cpp:1357-1361).  A: dense m x n array; At is accepted
+    for signature parity and ignored."""
+    L = _lib.load()
+    A = np.asarray(A, dtype=np.float64)
+    if A.ndim != 2:
+        raise ValueError("A must be a matrix")
+    m, n = A.shape
+    Af = np.ascontiguousarray(A.T)
+    wb = _w_in(w, m)
+    k = wb.shape[1]
+    w_out, h_out, d_out = np.empty((m, k)), np.empty((n, k)), np.empty(k)
+    cap = int(maxit) + 2
+    tm, ft, so = np.zeros(cap), np.zeros(cap), np.zeros(cap)
+    itv = np.zeros(cap, dtype=np.int32)
+    nt = C.c_int32()
+    cb = make_callbacks(_verbose_log(verbose, ard=True))
+    check(L.sgl_c_ard_nmf_dense(ptr(Af, f64p), m, n, float(tol), int(maxit), int(bool(verbose)), L1, L2, int(threads),
+                                ptr(wb, f64p), k, int(seed), int(inv_density), float(overfit_threshold), int(trace_test_mse),
+                                ptr(w_out, f64p), ptr(d_out, f64p), ptr(h_out, f64p), ptr(tm, f64p), ptr(itv, i32p),
+                                ptr(ft, f64p), ptr(so, f64p), C.byref(nt), C.byref(cb)))
+    q = nt.value
+    return {"w": w_out.T, "d": d_out, "h": h_out.T, "test_mse": tm[:q].copy(), "iter": itv[:q].copy(),
+            "tol": ft[:q].copy(), "score_overfit": so[:q].copy()}
 
 
 def c_linked_nmf(A, At, tol, maxit, verbose, L1, L2, threads, w, link_h, link_w):

@@ -293,6 +293,58 @@ static int upload_one(sgl_ctx* c, DevCSC& M, const double* x, const int32_t* i, 
     return rc;
 }
 
+// A list of column chunks (the reference's std::vector<Rcpp::SparseMatrix>, src/singlet.cpp:384-402: a running
+// `offset` over the chunks' columns) becomes ONE resident matrix: every chunk's x / i slots are copied straight
+// to their place in the device arrays, only the (small) column pointers are joined on the host -- as 64-bit
+// offsets, so the total may exceed the 2^31 - 1 non-zeros one dgCMatrix can hold.
+static int upload_chunks(sgl_ctx* c, DevCSC& M, int32_t n_chunks, const double* const* x, const int32_t* const* i,
+                         const int32_t* const* p, const int32_t* chunk_ncol, int32_t nrow) {
+    int64_t ncol = 0, nnz = 0;
+    for (int32_t q = 0; q < n_chunks; ++q) {
+        if (!x[q] || !i[q] || !p[q] || chunk_ncol[q] < 0) { sgl_set_error("chunk %d: missing slot", q); return SGL_EINVAL; }
+        if (p[q][0] != 0) { sgl_set_error("chunk %d: p[0] = %d", q, p[q][0]); return SGL_EINVAL; }
+        for (int32_t cc = 0; cc < chunk_ncol[q]; ++cc)
+            if (p[q][cc + 1] < p[q][cc]) { sgl_set_error("chunk %d: p decreases at column %d", q, cc); return SGL_EINVAL; }
+        ncol += chunk_ncol[q];
+        nnz += p[q][chunk_ncol[q]];
+    }
+    if (ncol <= 0 || ncol > INT32_MAX) { sgl_set_error("chunk list: %lld columns in total", (long long)ncol); return SGL_EINVAL; }
+    M.nrow = nrow;
+    M.ncol = (int32_t)ncol;
+    M.nnz = nnz;
+    SGLCHK(dev_alloc(&M.x, (size_t)nnz));
+    SGLCHK(dev_alloc(&M.i, (size_t)nnz));
+    SGLCHK(dev_alloc(&M.p, (size_t)ncol + 1));
+    std::vector<int64_t> p64((size_t)ncol + 1);
+    int64_t col0 = 0, off = 0;
+    p64[0] = 0;
+    for (int32_t q = 0; q < n_chunks; ++q) {
+        const int64_t nz = p[q][chunk_ncol[q]];
+        for (int32_t cc = 0; cc < chunk_ncol[q]; ++cc) p64[(size_t)(col0 + cc + 1)] = off + p[q][cc + 1];
+        if (nz > 0) {
+            HIPCHK(hipMemcpyAsync(M.x + off, x[q], sizeof(double) * (size_t)nz, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(hipMemcpyAsync(M.i + off, i[q], sizeof(int32_t) * (size_t)nz, hipMemcpyHostToDevice, c->stream));
+        }
+        col0 += chunk_ncol[q];
+        off += nz;
+    }
+    HIPCHK(hipMemcpyAsync(M.p, p64.data(), sizeof(int64_t) * ((size_t)ncol + 1), hipMemcpyHostToDevice, c->stream));
+    int* dflag = nullptr;
+    SGLCHK(dev_alloc(&dflag, 1));
+    int flag = 0;
+    int rc = k_validate_csc(c->stream, M.i, M.p, ncol, nrow, dflag);
+    if (rc == SGL_OK && hipMemcpyAsync(&flag, dflag, sizeof(int), hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = SGL_EHIP;
+    if (hipStreamSynchronize(c->stream) != hipSuccess && rc == SGL_OK) rc = SGL_EHIP;   // also: p64 leaves scope
+    dev_free(dflag);
+    if (rc == SGL_EHIP) { sgl_set_error("chunk upload: a HIP call failed: %s", hipGetErrorString(hipGetLastError())); return rc; }
+    if (rc == SGL_OK && flag != 0) {
+        sgl_set_error("not a valid dgCMatrix list: %s%s", (flag & 1) ? "row index outside [0, nrow) " : "",
+                      (flag & 2) ? "row indices not strictly ascending within a column" : "");
+        return SGL_EINVAL;
+    }
+    return rc;
+}
+
 static int finish_matrix(sgl_ctx* c) {
     SGLCHK(dev_alloc(&c->col_nnz_A, (size_t)c->A.ncol));
     SGLCHK(dev_alloc(&c->col_nnz_At, (size_t)c->At.ncol));
@@ -318,6 +370,31 @@ extern "C" int sgl_upload_csc(sgl_ctx* c, const double* Ax, const int32_t* Ai, c
     if (Atx) {
         if ((int64_t)Atp[nrow] != c->A.nnz) { sgl_set_error("At has %d non-zeros, A has %lld", Atp[nrow], (long long)c->A.nnz); return SGL_EINVAL; }
         SGLCHK(upload_one(c, c->At, Atx, Ati, Atp, ncol, nrow));
+    } else {
+        SGLCHK(sgl_device_transpose(c));
+    }
+    return finish_matrix(c);
+}
+
+extern "C" int sgl_upload_csc_list(sgl_ctx* c, int32_t n_chunks, const double* const* Ax, const int32_t* const* Ai,
+                                   const int32_t* const* Ap, const int32_t* chunk_ncol, int32_t n_t_chunks,
+                                   const double* const* Atx, const int32_t* const* Ati, const int32_t* const* Atp,
+                                   const int32_t* t_chunk_ncol, int32_t nrow, int64_t cell_offset, int64_t ncells_total) {
+    CTX_GUARD(c);
+    if (n_chunks <= 0 || !Ax || !Ai || !Ap || !chunk_ncol || nrow <= 0) { sgl_set_error("sgl_upload_csc_list: missing chunk list"); return SGL_EINVAL; }
+    if (n_t_chunks > 0 && (!Atx || !Ati || !Atp || !t_chunk_ncol)) { sgl_set_error("sgl_upload_csc_list: incomplete At chunk list"); return SGL_EINVAL; }
+    free_fit(c);
+    free_matrix(c);
+    SGLCHK(upload_chunks(c, c->A, n_chunks, Ax, Ai, Ap, chunk_ncol, nrow));
+    c->cell_offset = cell_offset;
+    c->ncells_total = ncells_total > 0 ? ncells_total : c->A.ncol;
+    if (n_t_chunks > 0) {
+        SGLCHK(upload_chunks(c, c->At, n_t_chunks, Atx, Ati, Atp, t_chunk_ncol, c->A.ncol));
+        if (c->At.ncol != nrow || c->At.nnz != c->A.nnz) {
+            sgl_set_error("At list describes a %d-column matrix with %lld non-zeros; t(A) has %d columns and %lld", c->At.ncol,
+                          (long long)c->At.nnz, nrow, (long long)c->A.nnz);
+            return SGL_EINVAL;
+        }
     } else {
         SGLCHK(sgl_device_transpose(c));
     }
@@ -818,11 +895,11 @@ extern "C" int sgl_ard_run(sgl_ctx* c, double tol, int32_t maxit, double L1, dou
     };
     for (; it < maxit && tol_ > tol; ++it) {
         SGLCHK(sgl_step_begin(c));
-        SGLCHK(sgl_predict_mask_dev(c, c->A, c->col_nnz_A, c->W, c->H, c->B, seed, inv_density, L1, L2, 0, SGL_PH_RHS_H,
-                                SGL_PH_NNLS_H, c->sweep_counters + 0));
+        SGLCHK(sgl_predict_mask_dev(c, c->A, c->solve_empty ? nullptr : c->col_nnz_A, c->W, c->H, c->B, seed, inv_density, L1, L2,
+                                    0, SGL_PH_RHS_H, SGL_PH_NNLS_H, c->sweep_counters + 0));
         SGLCHK(sgl_step_scale_h(c));
         if (cb && cb->poll && cb->poll(cb->user)) { sgl_set_error("interrupted"); return SGL_EINTR; }
-        SGLCHK(sgl_predict_mask_dev(c, c->At, c->col_nnz_At, c->H, c->W, c->red, seed, inv_density, L1, L2, 1,
+        SGLCHK(sgl_predict_mask_dev(c, c->At, c->solve_empty ? nullptr : c->col_nnz_At, c->H, c->W, c->red, seed, inv_density, L1, L2, 1,
                                 SGL_PH_RHS_W, SGL_PH_NNLS_W, c->sweep_counters + 1));
         SGLCHK(sgl_step_scale_w(c, &tol_));
         if (it % trace_test_mse == 0) {
@@ -924,6 +1001,9 @@ extern "C" int sgl_c_linked_nmf(const double* Ax, const int32_t* Ai, const int32
     return sgl_get_factors(hd.c, w_out, d_out, h_out);
 }
 
+static int dense_to_csc(const double* A, int32_t nrow, int32_t ncol, std::vector<double>& x, std::vector<int32_t>& idx,
+                        std::vector<int32_t>& p);
+
 // c_nmf_dense (src/singlet.cpp:1052-1054): a dense matrix runs through the same kernels as its CSC image
 // (zeros add exact zeros to the right-hand sides); the one semantic difference of the dense predict
 // (:370-381) is that it solves EVERY column, all-zero ones included.
@@ -934,16 +1014,8 @@ extern "C" int sgl_c_nmf_dense(const double* A, int32_t nrow, int32_t ncol, doub
     (void)verbose; (void)threads;
     if (!A || !w_init || !w_out || !d_out || !h_out || nrow <= 0 || ncol <= 0) { sgl_set_error("sgl_c_nmf_dense: bad arguments"); return SGL_EINVAL; }
     std::vector<double> x;
-    std::vector<int32_t> idx, p((size_t)ncol + 1, 0);
-    for (int64_t c = 0; c < ncol; ++c) {
-        for (int64_t r = 0; r < nrow; ++r) {
-            const double v = A[(size_t)c * nrow + r];
-            if (v != 0.0) { x.push_back(v); idx.push_back((int32_t)r); }
-        }
-        if (x.size() > (size_t)INT32_MAX) { sgl_set_error("sgl_c_nmf_dense: more than 2^31 non-zeros"); return SGL_EINVAL; }
-        p[(size_t)c + 1] = (int32_t)x.size();
-    }
-    if (x.empty()) { x.push_back(0.0); idx.push_back(0); }  // keep the slot pointers valid for an all-zero matrix
+    std::vector<int32_t> idx, p;
+    SGLCHK(dense_to_csc(A, nrow, ncol, x, idx, p));
     CtxHolder hd;
     SGLCHK(sgl_create(current_device_or_zero(), &hd.c));
     SGLCHK(sgl_upload_csc(hd.c, x.data(), idx.data(), p.data(), nullptr, nullptr, nullptr, nrow, ncol, 0, ncol));
@@ -978,6 +1050,84 @@ extern "C" int sgl_c_ard_nmf(const double* Ax, const int32_t* Ai, const int32_t*
     int32_t nit = 0;
     SGLCHK(sgl_ard_run(hd.c, tol, maxit, L1, L2, seed, inv_density, overfit_threshold, trace_test_mse, test_mse, iter,
                        tol_out, score_overfit, n_trace, &nit, cb));
+    return sgl_get_factors(hd.c, w_out, d_out, h_out);
+}
+
+// dense matrix -> the slots of its CSC image (zeros dropped)
+static int dense_to_csc(const double* A, int32_t nrow, int32_t ncol, std::vector<double>& x, std::vector<int32_t>& idx,
+                        std::vector<int32_t>& p) {
+    p.assign((size_t)ncol + 1, 0);
+    for (int64_t cc = 0; cc < ncol; ++cc) {
+        for (int64_t r = 0; r < nrow; ++r) {
+            const double v = A[(size_t)cc * nrow + r];
+            if (v != 0.0) { x.push_back(v); idx.push_back((int32_t)r); }
+        }
+        if (x.size() > (size_t)INT32_MAX) { sgl_set_error("dense front-end: more than 2^31 non-zeros"); return SGL_EINVAL; }
+        p[(size_t)cc + 1] = (int32_t)x.size();
+    }
+    if (x.empty()) { x.push_back(0.0); idx.push_back(0); }  // keep the slot pointers valid for an all-zero matrix
+    return SGL_OK;
+}
+
+// c_ard_nmf_dense (src/singlet.cpp:1357-1361; dense predict_mask :506-533, mse_test :608-632): the CSC image through
+// the masked path, every column solved (the dense predict_mask has no empty-column skip).
+extern "C" int sgl_c_ard_nmf_dense(const double* A, int32_t nrow, int32_t ncol, double tol, uint16_t maxit, int verbose,
+                                   double L1, double L2, uint16_t threads, const double* w_init, int32_t k, uint64_t seed,
+                                   uint64_t inv_density, double overfit_threshold, uint16_t trace_test_mse, double* w_out,
+                                   double* d_out, double* h_out, double* test_mse, int32_t* iter, double* tol_out,
+                                   double* score_overfit, int32_t* n_trace, const sgl_callbacks* cb) {
+    (void)verbose; (void)threads;
+    if (!A || !w_init || !w_out || !d_out || !h_out || nrow <= 0 || ncol <= 0) { sgl_set_error("sgl_c_ard_nmf_dense: bad arguments"); return SGL_EINVAL; }
+    if (k > SGL_MASK_MAX_K) { sgl_set_error("c_ard_nmf: rank %d above the masked path's limit of %d", k, SGL_MASK_MAX_K); return SGL_EINVAL; }
+    std::vector<double> x;
+    std::vector<int32_t> idx, p;
+    SGLCHK(dense_to_csc(A, nrow, ncol, x, idx, p));
+    CtxHolder hd;
+    SGLCHK(sgl_create(current_device_or_zero(), &hd.c));
+    SGLCHK(sgl_upload_csc(hd.c, x.data(), idx.data(), p.data(), nullptr, nullptr, nullptr, nrow, ncol, 0, ncol));
+    SGLCHK(sgl_fit_init(hd.c, k, w_init, 0));
+    hd.c->solve_empty = true;
+    int32_t nit = 0;
+    SGLCHK(sgl_ard_run(hd.c, tol, maxit, L1, L2, seed, inv_density, overfit_threshold, trace_test_mse, test_mse, iter, tol_out,
+                       score_overfit, n_trace, &nit, cb));
+    return sgl_get_factors(hd.c, w_out, d_out, h_out);
+}
+
+// c_nmf_sparse_list (src/singlet.cpp:715-743) and c_ard_nmf_sparse_list (:1162-1234)
+extern "C" int sgl_c_nmf_sparse_list(int32_t n_chunks, const double* const* Ax, const int32_t* const* Ai, const int32_t* const* Ap,
+                                     const int32_t* chunk_ncol, int32_t n_t_chunks, const double* const* Atx,
+                                     const int32_t* const* Ati, const int32_t* const* Atp, const int32_t* t_chunk_ncol,
+                                     int32_t nrow, double tol, uint16_t maxit, int verbose, double L1, double L2, uint16_t threads,
+                                     const double* w_init, int32_t k, double* w_out, double* d_out, double* h_out, int32_t* n_iter,
+                                     double* tol_trace, const sgl_callbacks* cb) {
+    (void)verbose; (void)threads;
+    if (!w_init || !w_out || !d_out || !h_out) { sgl_set_error("sgl_c_nmf_sparse_list: NULL factor buffer"); return SGL_EINVAL; }
+    CtxHolder hd;
+    SGLCHK(sgl_create(current_device_or_zero(), &hd.c));
+    SGLCHK(sgl_upload_csc_list(hd.c, n_chunks, Ax, Ai, Ap, chunk_ncol, n_t_chunks, Atx, Ati, Atp, t_chunk_ncol, nrow, 0, 0));
+    SGLCHK(sgl_fit_init(hd.c, k, w_init, 0));
+    SGLCHK(sgl_nmf_run(hd.c, tol, maxit, L1, L1, L2, L2, n_iter, tol_trace, cb));
+    return sgl_get_factors(hd.c, w_out, d_out, h_out);
+}
+
+extern "C" int sgl_c_ard_nmf_sparse_list(int32_t n_chunks, const double* const* Ax, const int32_t* const* Ai,
+                                         const int32_t* const* Ap, const int32_t* chunk_ncol, int32_t n_t_chunks,
+                                         const double* const* Atx, const int32_t* const* Ati, const int32_t* const* Atp,
+                                         const int32_t* t_chunk_ncol, int32_t nrow, double tol, uint16_t maxit, int verbose,
+                                         double L1, double L2, uint16_t threads, const double* w_init, int32_t k, uint64_t seed,
+                                         uint64_t inv_density, double overfit_threshold, uint16_t trace_test_mse, double* w_out,
+                                         double* d_out, double* h_out, double* test_mse, int32_t* iter, double* tol_out,
+                                         double* score_overfit, int32_t* n_trace, const sgl_callbacks* cb) {
+    (void)verbose; (void)threads;
+    if (!w_init || !w_out || !d_out || !h_out) { sgl_set_error("sgl_c_ard_nmf_sparse_list: NULL factor buffer"); return SGL_EINVAL; }
+    if (k > SGL_MASK_MAX_K) { sgl_set_error("c_ard_nmf: rank %d above the masked path's limit of %d", k, SGL_MASK_MAX_K); return SGL_EINVAL; }
+    CtxHolder hd;
+    SGLCHK(sgl_create(current_device_or_zero(), &hd.c));
+    SGLCHK(sgl_upload_csc_list(hd.c, n_chunks, Ax, Ai, Ap, chunk_ncol, n_t_chunks, Atx, Ati, Atp, t_chunk_ncol, nrow, 0, 0));
+    SGLCHK(sgl_fit_init(hd.c, k, w_init, 0));
+    int32_t nit = 0;
+    SGLCHK(sgl_ard_run(hd.c, tol, maxit, L1, L2, seed, inv_density, overfit_threshold, trace_test_mse, test_mse, iter, tol_out,
+                       score_overfit, n_trace, &nit, cb));
     return sgl_get_factors(hd.c, w_out, d_out, h_out);
 }
 

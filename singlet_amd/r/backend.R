@@ -1,7 +1,7 @@
 # backend.R -- opt-in switch for the HIP back end (source()d or added to the package's R/).
 #
-# With options(singlet.backend = "hip") (or SINGLET_BACKEND=hip in the environment) the four
-# wrappers of R/RcppExports.R:20-30, 78-80 are rebound to the shim's .Call symbols; with the option
+# With options(singlet.backend = "hip") (or SINGLET_BACKEND=hip in the environment) the
+# wrappers of R/RcppExports.R:20-38, 78-88 are rebound to the shim's .Call symbols; with the option
 # unset nothing changes and the package's own OpenMP code runs.  run_nmf / ard_nmf /
 # cross_validate_nmf / RunNMF / project_model call these wrappers by name, so they need no edit.
 
@@ -22,6 +22,16 @@ singlet_hip_enable <- function(shim = Sys.getenv("SINGLET_HIP_SHIM", "singlet_hi
     .Call(dll[["_singlet_c_linked_nmf"]], A, At, tol, maxit, verbose, L1, L2, threads, w, link_h, link_w))
   rebind("c_nmf_dense", function(A, At, tol, maxit, verbose, L1_w, L1_h, L2_w, L2_h, threads, w)
     .Call(dll[["_singlet_c_nmf_dense"]], A, At, tol, maxit, verbose, L1_w, L1_h, L2_w, L2_h, threads, w))
+  rebind("c_nmf_sparse_list", function(A_, At_, tol, maxit, verbose, L1, L2, threads, w)
+    .Call(dll[["_singlet_c_nmf_sparse_list"]], A_, At_, tol, maxit, verbose, L1, L2, threads, w))
+  rebind("c_ard_nmf_sparse_list", function(A_, At_, tol, maxit, verbose, L1, L2, threads, w, rng_seed, inv_density,
+                                            overfit_threshold, trace_test_mse)
+    .Call(dll[["_singlet_c_ard_nmf_sparse_list"]], A_, At_, tol, maxit, verbose, L1, L2, threads, w, rng_seed, inv_density,
+          overfit_threshold, trace_test_mse))
+  rebind("c_ard_nmf_dense", function(A, At, tol, maxit, verbose, L1, L2, threads, w, seed, inv_density, overfit_threshold,
+                                      trace_test_mse)
+    .Call(dll[["_singlet_c_ard_nmf_dense"]], A, At, tol, maxit, verbose, L1, L2, threads, w, seed, inv_density,
+          overfit_threshold, trace_test_mse))
   rebind("c_project_model", function(A, w, L1, L2, threads)
     .Call(dll[["_singlet_c_project_model"]], A, w, L1, L2, threads))
   rebind("Rcpp_predict", function(A, w, L1, L2, threads)

@@ -243,11 +243,149 @@ SEXP _singlet_Rcpp_predict(SEXP A_, SEXP w_, SEXP L1_, SEXP L2_, SEXP threads_) 
  * When the file is compiled INTO the singlet package instead, drop this table
  * and keep the reference's own CallEntries (src/RcppExports.cpp:449-477): the
  * four symbols above then simply replace the four Rcpp-generated ones. */
+/* ---- chunk lists: R lists of dgCMatrix column chunks (R/ard_nmf.R:114, 181) ------------------------- */
+typedef struct {
+    int n;
+    const double** x;
+    const int** i;
+    const int** p;
+    int* ncol;
+    int nrow;
+} dgc_list;
+
+static dgc_list view_dgc_list(SEXP lst, const char* what) {
+    dgc_list L;
+    if (TYPEOF(lst) != VECSXP || XLENGTH(lst) < 1) Rf_error("%s: not a non-empty list of dgCMatrix", what);
+    L.n = (int)XLENGTH(lst);
+    L.x = (const double**)R_alloc(L.n, sizeof(double*));
+    L.i = (const int**)R_alloc(L.n, sizeof(int*));
+    L.p = (const int**)R_alloc(L.n, sizeof(int*));
+    L.ncol = (int*)R_alloc(L.n, sizeof(int));
+    L.nrow = 0;
+    for (int q = 0; q < L.n; ++q) {
+        dgc_view v = view_dgc(VECTOR_ELT(lst, q), what);
+        if (q == 0) L.nrow = v.nrow;
+        else if (v.nrow != L.nrow) Rf_error("%s: chunks differ in their number of rows", what);
+        L.x[q] = v.x; L.i[q] = v.i; L.p[q] = v.p; L.ncol[q] = v.ncol;
+    }
+    return L;
+}
+
+/* ---- c_nmf_sparse_list(A_, At_, tol, maxit, verbose, L1, L2, threads, w)  (src/singlet.cpp:715-743) ---- */
+SEXP _singlet_c_nmf_sparse_list(SEXP A_, SEXP At_, SEXP tol_, SEXP maxit_, SEXP verbose_, SEXP L1_, SEXP L2_, SEXP threads_,
+                                SEXP w_) {
+    dgc_list A = view_dgc_list(A_, "A"), At = view_dgc_list(At_, "At");
+    if (!Rf_isMatrix(w_) || TYPEOF(w_) != REALSXP) Rf_error("w must be a numeric matrix");
+    const int k = Rf_nrows(w_);
+    if (Rf_ncols(w_) != A.nrow) Rf_error("w must be k x nrow(A)");
+    const int n = At.nrow;   /* n = At[0].rows(), l.723 */
+    const int verbose = Rf_asLogical(verbose_);
+    const int maxit = Rf_asInteger(maxit_);
+    SEXP w = PROTECT(Rf_allocMatrix(REALSXP, k, A.nrow)), d = PROTECT(Rf_allocVector(REALSXP, k)),
+         h = PROTECT(Rf_allocMatrix(REALSXP, k, n));
+    sgl_callbacks cb = {NULL, verbose ? log_nmf : NULL, poll_cb};
+    if (verbose) Rprintf("\n%4s | %8s \n---------------\n", "iter", "tol");
+    int n_iter = 0;
+    int rc = sgl_c_nmf_sparse_list(A.n, A.x, A.i, A.p, A.ncol, At.n, At.x, At.i, At.p, At.ncol, A.nrow, Rf_asReal(tol_),
+                                   (uint16_t)maxit, verbose, Rf_asReal(L1_), Rf_asReal(L2_), (uint16_t)Rf_asInteger(threads_),
+                                   REAL(w_), k, REAL(w), REAL(d), REAL(h), &n_iter, NULL, &cb);
+    if (rc == SGL_EINTR) { UNPROTECT(3); Rf_onintr(); }
+    fail_if(rc);
+    const char* names[3] = {"w", "d", "h"};
+    SEXP vals[3] = {w, d, h};
+    SEXP out = named_list(3, names, vals);
+    UNPROTECT(3);
+    return out;
+}
+
+/* shared tail of the three c_ard_* entry points: trace vectors -> the reference's 7-element list */
+static SEXP ard_result(SEXP w, SEXP d, SEXP h, int n_trace, const double* t_mse, const int* t_it, const double* t_tol,
+                       const double* t_sco) {
+    SEXP v_mse = PROTECT(Rf_allocVector(REALSXP, n_trace)), v_it = PROTECT(Rf_allocVector(INTSXP, n_trace)),
+         v_tol = PROTECT(Rf_allocVector(REALSXP, n_trace)), v_sco = PROTECT(Rf_allocVector(REALSXP, n_trace));
+    for (int q = 0; q < n_trace; ++q) {
+        REAL(v_mse)[q] = t_mse[q];
+        INTEGER(v_it)[q] = t_it[q];
+        REAL(v_tol)[q] = t_tol[q];
+        REAL(v_sco)[q] = t_sco[q];
+    }
+    const char* names[7] = {"w", "d", "h", "test_mse", "iter", "tol", "score_overfit"};
+    SEXP vals[7] = {w, d, h, v_mse, v_it, v_tol, v_sco};
+    SEXP out = named_list(7, names, vals);
+    UNPROTECT(4);
+    return out;
+}
+
+/* ---- c_ard_nmf_sparse_list(A_, At_, tol, maxit, verbose, L1, L2, threads, w, rng_seed, inv_density,
+ *                            overfit_threshold, trace_test_mse)  (src/singlet.cpp:1162-1234) ---- */
+SEXP _singlet_c_ard_nmf_sparse_list(SEXP A_, SEXP At_, SEXP tol_, SEXP maxit_, SEXP verbose_, SEXP L1_, SEXP L2_, SEXP threads_,
+                                    SEXP w_, SEXP seed_, SEXP invd_, SEXP thr_, SEXP trace_) {
+    dgc_list A = view_dgc_list(A_, "A"), At = view_dgc_list(At_, "At");
+    if (!Rf_isMatrix(w_) || TYPEOF(w_) != REALSXP) Rf_error("w must be a numeric matrix");
+    const int k = Rf_nrows(w_);
+    if (Rf_ncols(w_) != A.nrow) Rf_error("w must be k x nrow(A)");
+    const int n = At.nrow;
+    const int verbose = Rf_asLogical(verbose_);
+    const int maxit = Rf_asInteger(maxit_);
+    SEXP w = PROTECT(Rf_allocMatrix(REALSXP, k, A.nrow)), d = PROTECT(Rf_allocVector(REALSXP, k)),
+         h = PROTECT(Rf_allocMatrix(REALSXP, k, n));
+    double* t_mse = (double*)R_alloc(maxit + 1, sizeof(double));
+    double* t_tol = (double*)R_alloc(maxit + 1, sizeof(double));
+    double* t_sco = (double*)R_alloc(maxit + 1, sizeof(double));
+    int* t_it = (int*)R_alloc(maxit + 1, sizeof(int));
+    int n_trace = 0;
+    sgl_callbacks cb = {NULL, verbose ? log_ard : NULL, poll_cb};
+    if (verbose) Rprintf("\n%4s | %8s | %8s \n---------------------------\n", "iter", "tol", "overfit");
+    int rc = sgl_c_ard_nmf_sparse_list(A.n, A.x, A.i, A.p, A.ncol, At.n, At.x, At.i, At.p, At.ncol, A.nrow, Rf_asReal(tol_),
+                                       (uint16_t)maxit, verbose, Rf_asReal(L1_), Rf_asReal(L2_),
+                                       (uint16_t)Rf_asInteger(threads_), REAL(w_), k, (uint64_t)Rf_asReal(seed_),
+                                       (uint64_t)Rf_asReal(invd_), Rf_asReal(thr_), (uint16_t)Rf_asInteger(trace_), REAL(w),
+                                       REAL(d), REAL(h), t_mse, t_it, t_tol, t_sco, &n_trace, &cb);
+    if (rc == SGL_EINTR) { UNPROTECT(3); Rf_onintr(); }
+    fail_if(rc);
+    SEXP out = ard_result(w, d, h, n_trace, t_mse, t_it, t_tol, t_sco);
+    UNPROTECT(3);
+    return out;
+}
+
+/* ---- c_ard_nmf_dense(A, At, tol, maxit, verbose, L1, L2, threads, w, seed, inv_density, overfit_threshold,
+ *                      trace_test_mse)  (src/singlet.cpp:1357-1361); At is not needed ---- */
+SEXP _singlet_c_ard_nmf_dense(SEXP A_, SEXP At_, SEXP tol_, SEXP maxit_, SEXP verbose_, SEXP L1_, SEXP L2_, SEXP threads_, SEXP w_,
+                              SEXP seed_, SEXP invd_, SEXP thr_, SEXP trace_) {
+    (void)At_;
+    if (!Rf_isMatrix(A_) || TYPEOF(A_) != REALSXP) Rf_error("A must be a numeric matrix");
+    if (!Rf_isMatrix(w_) || TYPEOF(w_) != REALSXP) Rf_error("w must be a numeric matrix");
+    const int m = Rf_nrows(A_), n = Rf_ncols(A_), k = Rf_nrows(w_);
+    if (Rf_ncols(w_) != m) Rf_error("w must be k x nrow(A)");
+    const int verbose = Rf_asLogical(verbose_);
+    const int maxit = Rf_asInteger(maxit_);
+    SEXP w = PROTECT(Rf_allocMatrix(REALSXP, k, m)), d = PROTECT(Rf_allocVector(REALSXP, k)), h = PROTECT(Rf_allocMatrix(REALSXP, k, n));
+    double* t_mse = (double*)R_alloc(maxit + 1, sizeof(double));
+    double* t_tol = (double*)R_alloc(maxit + 1, sizeof(double));
+    double* t_sco = (double*)R_alloc(maxit + 1, sizeof(double));
+    int* t_it = (int*)R_alloc(maxit + 1, sizeof(int));
+    int n_trace = 0;
+    sgl_callbacks cb = {NULL, verbose ? log_ard : NULL, poll_cb};
+    if (verbose) Rprintf("\n%4s | %8s | %8s \n---------------------------\n", "iter", "tol", "overfit");
+    int rc = sgl_c_ard_nmf_dense(REAL(A_), m, n, Rf_asReal(tol_), (uint16_t)maxit, verbose, Rf_asReal(L1_), Rf_asReal(L2_),
+                                 (uint16_t)Rf_asInteger(threads_), REAL(w_), k, (uint64_t)Rf_asReal(seed_), (uint64_t)Rf_asReal(invd_),
+                                 Rf_asReal(thr_), (uint16_t)Rf_asInteger(trace_), REAL(w), REAL(d), REAL(h), t_mse, t_it, t_tol,
+                                 t_sco, &n_trace, &cb);
+    if (rc == SGL_EINTR) { UNPROTECT(3); Rf_onintr(); }
+    fail_if(rc);
+    SEXP out = ard_result(w, d, h, n_trace, t_mse, t_it, t_tol, t_sco);
+    UNPROTECT(3);
+    return out;
+}
+
 static const R_CallMethodDef call_entries[] = {
     {"_singlet_c_nmf", (DL_FUNC)&_singlet_c_nmf, 11},
     {"_singlet_c_ard_nmf", (DL_FUNC)&_singlet_c_ard_nmf, 13},
     {"_singlet_c_linked_nmf", (DL_FUNC)&_singlet_c_linked_nmf, 11},
     {"_singlet_c_nmf_dense", (DL_FUNC)&_singlet_c_nmf_dense, 11},
+    {"_singlet_c_nmf_sparse_list", (DL_FUNC)&_singlet_c_nmf_sparse_list, 9},
+    {"_singlet_c_ard_nmf_sparse_list", (DL_FUNC)&_singlet_c_ard_nmf_sparse_list, 13},
+    {"_singlet_c_ard_nmf_dense", (DL_FUNC)&_singlet_c_ard_nmf_dense, 13},
     {"_singlet_c_project_model", (DL_FUNC)&_singlet_c_project_model, 5},
     {"_singlet_Rcpp_predict", (DL_FUNC)&_singlet_Rcpp_predict, 5},
     {NULL, NULL, 0}};

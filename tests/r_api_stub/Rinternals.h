@@ -23,6 +23,7 @@ void Rf_unprotect(int);
 SEXP Rf_allocVector(unsigned int, R_xlen_t);
 SEXP Rf_allocMatrix(unsigned int, int, int);
 SEXP SET_VECTOR_ELT(SEXP, R_xlen_t, SEXP);
+SEXP VECTOR_ELT(SEXP, R_xlen_t);
 void SET_STRING_ELT(SEXP, R_xlen_t, SEXP);
 SEXP Rf_mkChar(const char*);
 SEXP Rf_setAttrib(SEXP, SEXP, SEXP);

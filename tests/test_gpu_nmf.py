@@ -386,9 +386,60 @@ def test_c_nmf_dense_and_sparse_list(sa, ora):
     chunks = [dS.col_slice(a, b) for a, b in zip(cuts, cuts[1:])]
     lst = sa.c_nmf_sparse_list(chunks, None, 0.0, 4, False, 0.01, 0.0, 0, w0.T)
     assert np.array_equal(lst["w"], sparse["w"]) and np.array_equal(lst["h"], sparse["h"]) and np.array_equal(lst["d"], sparse["d"])
+    # ... against the oracle's restatement of the chunk loops (running column offset, src/singlet.cpp:384-402), with
+    # the list of column chunks of t(A) given as well
+    At = sp.csc_matrix(D.T)
+    dAt = sa.dgCMatrix(At.data, At.indices, At.indptr, (n, m))
+    tcuts = [0, 1, 90, 91, m]
+    tchunks = [dAt.col_slice(a, b) for a, b in zip(tcuts, tcuts[1:])]
+    o_chunks = [ora.CSC(ch.x, ch.i, ch.p, ch.nrow, ch.ncol) for ch in chunks]
+    o_tchunks = [ora.CSC(ch.x, ch.i, ch.p, ch.nrow, ch.ncol) for ch in tchunks]
+    oref = ora.c_nmf_sparse_list(o_chunks, o_tchunks, 0.0, 4, 0.01, 0.0, 0, w0)
+    lst2 = sa.c_nmf_sparse_list(chunks, tchunks, 0.0, 4, False, 0.01, 0.0, 0, w0.T)
+    _check(lst2, oref)
+    assert np.array_equal(lst2["w"], lst["w"]) and np.array_equal(lst2["h"], lst["h"])
     # run_nmf takes the dense branch for a plain array (R/run_nmf.R:57)
     fit = sa.run_nmf(D, 5, tol=1e-3, maxit=5, verbose=False, seed=3)
     assert fit["w"].shape == (m, 5) and np.all(np.diff(fit["d"]) <= 0)
+
+
+def test_c_ard_nmf_dense_and_sparse_list(sa, ora):
+    """The masked loop behind the two other front-ends R/ard_nmf.R uses (l.109, 114): the dense one
+    (src/singlet.cpp:1357-1361, predict_mask :506-533) solves every column; the chunk list (:1162-1234) hashes
+    on `i + offset` (:485, :590).  Both against the oracle's restatements of those loops."""
+    import scipy.sparse as sp
+    m, n, k = 150, 210, 6
+    A = ora.synth_csc(m, n, 8)
+    D = A.to_dense()
+    D[:, [9, 140]] = 0.0      # empty cells: solved by the dense path, skipped by the sparse one
+    D[[4, 77], :] = 0.0
+    w0 = ora.synth_winit(k, m)
+    ref = ora.c_ard_nmf_dense(D, 0.0, 5, 0.01, 0.0, 0, w0, 31, 10, 1e9, 2)
+    got = sa.c_ard_nmf_dense(D, None, 0.0, 5, False, 0.01, 0.0, 0, w0.T, 31, 10, 1e9, 2)
+    assert list(got["iter"]) == list(ref["iter"]) == [0, 2, 4, 5]
+    _check(got, ref)
+    assert rel_fro(got["test_mse"], ref["test_mse"]) < 1e-9
+    S, St = sp.csc_matrix(D), sp.csc_matrix(D.T)
+    dS = sa.dgCMatrix(S.data, S.indices, S.indptr, (m, n))
+    dSt = sa.dgCMatrix(St.data, St.indices, St.indptr, (n, m))
+    cuts, tcuts = [0, 50, 51, 120, n], [0, 75, m]
+    chunks = [dS.col_slice(a, b) for a, b in zip(cuts, cuts[1:])]
+    tchunks = [dSt.col_slice(a, b) for a, b in zip(tcuts, tcuts[1:])]
+    oc = [ora.CSC(ch.x, ch.i, ch.p, ch.nrow, ch.ncol) for ch in chunks]
+    otc = [ora.CSC(ch.x, ch.i, ch.p, ch.nrow, ch.ncol) for ch in tchunks]
+    lref = ora.c_ard_nmf_sparse_list(oc, otc, 0.0, 5, 0.01, 0.0, 0, w0, 31, 10, 1e9, 2)
+    for tl in (tchunks, None):
+        lgot = sa.c_ard_nmf_sparse_list(chunks, tl, 0.0, 5, False, 0.01, 0.0, 0, w0.T, 31, 10, 1e9, 2)
+        assert list(lgot["iter"]) == list(lref["iter"])
+        _check(lgot, lref)
+        assert rel_fro(lgot["test_mse"], lref["test_mse"]) < 1e-9
+    # the sparse list skips the empty genes (their w columns keep the scaled initial values) the dense front-end solves
+    assert not np.array_equal(lgot["w"][:, 4], got["w"][:, 4])
+    # bad lists come back as errors
+    with pytest.raises(ValueError):
+        sa.c_nmf_sparse_list([], None, 0.0, 1, False, 0.0, 0.0, 0, w0.T)
+    with pytest.raises(sa.SingletHipError):   # an At list that is not t(A)
+        sa.c_nmf_sparse_list(chunks, tchunks[:1], 0.0, 1, False, 0.0, 0.0, 0, w0.T)
 
 
 def test_edge_arguments(sa, ora, ctx):
