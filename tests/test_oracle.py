@@ -202,3 +202,35 @@ def test_pbmc3k_fixture_and_config1(ora):
     assert r["iter"] == 3 and np.all(np.isfinite(r["w"])) and np.all(r["h"] >= 0)
     assert np.all(np.diff(r["tol"]) < 0)         # converging
     assert abs(r["w"].sum(axis=0) - 1).max() < 1e-9   # rows of W sum to 1 after scale()
+
+
+def test_list_and_dense_ard_restatements_agree_with_the_plain_ones(ora):
+    """The chunk-list loops (src/singlet.cpp:384-402, 469-503, 571-607: running column offset) and the dense
+    masked loops (:506-533, 608-632) restated in the oracle: on a matrix without empty columns they are the
+    plain c_nmf / c_ard_nmf bit for bit, however the columns are cut."""
+    A = ora.synth_csc(60, 90, 5)
+    At = A.t()
+    w0 = ora.synth_winit(5, 60)
+
+    def split(M, cuts):
+        b = [0] + cuts + [M.ncol]
+        return [ora.CSC(M.x[M.p[lo]:M.p[hi]], M.i[M.p[lo]:M.p[hi]], M.p[lo:hi + 1] - M.p[lo], M.nrow, hi - lo)
+                for lo, hi in zip(b[:-1], b[1:])]
+    r1 = ora.c_nmf(A, At, 0.0, 4, 0.01, 0.01, 0, 0, 0, w0)
+    r2 = ora.c_nmf_sparse_list(split(A, [20, 55]), split(At, [7, 30, 31]), 0.0, 4, 0.01, 0.0, 0, w0)
+    assert np.array_equal(r1["w"], r2["w"]) and np.array_equal(r1["h"], r2["h"]) and np.array_equal(r1["tol"], r2["tol"])
+    a1 = ora.c_ard_nmf(A, At, 0.0, 5, 0.01, 0.0, 0, w0, 7, 10, 1e9, 2)
+    a2 = ora.c_ard_nmf_sparse_list(split(A, [1, 89]), split(At, [59]), 0.0, 5, 0.01, 0.0, 0, w0, 7, 10, 1e9, 2)
+    a3 = ora.c_ard_nmf_dense(A.to_dense(), 0.0, 5, 0.01, 0.0, 0, w0, 7, 10, 1e9, 2)
+    for a in (a2, a3):
+        assert list(a["iter"]) == list(a1["iter"]) == [0, 2, 4, 5]
+        assert np.array_equal(a["w"], a1["w"]) and np.array_equal(a["h"], a1["h"]) and np.array_equal(a["test_mse"], a1["test_mse"])
+    # an all-zero gene: skipped by the sparse loops (stale w column), solved by the dense one
+    D = A.to_dense()
+    D[3, :] = 0.0
+    import scipy.sparse as sp
+    S = sp.csc_matrix(D)
+    As = ora.CSC(S.data, S.indices, S.indptr, 60, 90)
+    s1 = ora.c_ard_nmf(As, As.t(), 0.0, 3, 0.01, 0.0, 0, w0, 7, 10, 1e9, 1)
+    s3 = ora.c_ard_nmf_dense(D, 0.0, 3, 0.01, 0.0, 0, w0, 7, 10, 1e9, 1)
+    assert not np.array_equal(s1["w"][3], s3["w"][3])
