@@ -354,16 +354,18 @@ int k_cor(sgl_ctx* c, const double* x, const double* y, int64_t n, double* out_d
 }
 
 // ---------------------------------------------------------------- misc ------
-// Gpad[j + GS*i] = G[j + k*i] inside k x k, 0 outside, for i < KP, j < GS (GS = row stride >= KP).
+// Gpad[j + GS*i] = G[j + k*i] inside k x k, 0 outside, for i < KP, j < GS (GS = row stride >= KP); one more row,
+// i = KP: the correctly rounded reciprocals of the diagonal, Gpad[j + GS*KP] = 1 / G[j, j] (1 outside).
 __global__ void pad_gram_kernel(const double* __restrict__ G, int k, int KP, int GS, double* __restrict__ Gpad) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= KP * GS) return;
+    if (e >= (KP + 1) * GS) return;
     const int j = e % GS, i = e / GS;
-    Gpad[e] = (i < k && j < k) ? G[j + k * i] : 0.0;
+    if (i == KP) Gpad[e] = (j < k) ? __ddiv_rn(1.0, G[j + k * j]) : 1.0;
+    else Gpad[e] = (i < k && j < k) ? G[j + k * i] : 0.0;
 }
 
 int k_pad_gram(hipStream_t s, const double* G, int k, int KP, int GS, double* Gpad) {
-    pad_gram_kernel<<<dim3((KP * GS + 255) / 256), dim3(256), 0, s>>>(G, k, KP, GS, Gpad);
+    pad_gram_kernel<<<dim3(((KP + 1) * GS + 255) / 256), dim3(256), 0, s>>>(G, k, KP, GS, Gpad);
     HIPCHK(hipGetLastError());
     return SGL_OK;
 }

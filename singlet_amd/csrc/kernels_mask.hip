@@ -289,66 +289,101 @@ int k_mask_gram_finalize(hipStream_t s, const double* G, const double* S, int k,
 }
 
 // ---------------------------------------------------------------- mse_test --
-// One wave per cell.  Drawn genes are queued in LDS and processed 64 at a
-// time, one gene per lane: pred = Wd[:, g] . h[:, cell]; the matrix value at
-// (g, cell) comes from a binary search of the cell's (ascending) row indices.
+// mse_test (src/singlet.cpp:536-568).  One wave per cell, LANES OVER THE FACTORS: h[:, cell] sits in
+// registers (one or two per lane), every 64-gene chunk is hashed one gene per lane, and for each drawn gene
+// (wave-uniform loop over the ballot) the wave reads Wd[:, gene] as ONE coalesced k * 8-byte line, multiplies
+// and sums over the lanes with DPP row operations.  The matrix value at (gene, cell) comes from a window of
+// the cell's (ascending) non-zeros that slides along with the gene chunks: the entries of the current chunk
+// are scattered into a 64-slot LDS row, lane b picks up slot b, and the drawn gene at bit b takes it by
+// v_readlane.  (Round 1 had one drawn gene per lane: every lane walked its own 400-byte row of Wd and did
+// its own binary search -- 35 ms per call at 30 000 x 100 000, k = 50; this form: see profiles/.)
+// The k-long dot is summed as a lane tree instead of left to right (rounding only: ~1e-16 relative).
+__device__ __forceinline__ double dpp_mov_f64(double v, const int ctrl, const int row_mask) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    int rl, rh;
+    switch (ctrl) {   // the control word must be an immediate
+        case 0: rl = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xf, 0xf, false); rh = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xf, 0xf, false); break;   // quad_perm [1,0,3,2]
+        case 1: rl = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xf, 0xf, false); rh = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xf, 0xf, false); break;   // quad_perm [2,3,0,1]
+        case 2: rl = __builtin_amdgcn_update_dpp(0, lo, 0x141, 0xf, 0xf, false); rh = __builtin_amdgcn_update_dpp(0, hi, 0x141, 0xf, 0xf, false); break; // row_half_mirror
+        case 3: rl = __builtin_amdgcn_update_dpp(0, lo, 0x140, 0xf, 0xf, false); rh = __builtin_amdgcn_update_dpp(0, hi, 0x140, 0xf, 0xf, false); break; // row_mirror
+        case 4: rl = __builtin_amdgcn_update_dpp(0, lo, 0x142, 0xa, 0xf, false); rh = __builtin_amdgcn_update_dpp(0, hi, 0x142, 0xa, 0xf, false); break; // row_bcast:15 into rows 1, 3
+        default: rl = __builtin_amdgcn_update_dpp(0, lo, 0x143, 0xc, 0xf, false); rh = __builtin_amdgcn_update_dpp(0, hi, 0x143, 0xc, 0xf, false); break; // row_bcast:31 into rows 2, 3
+    }
+    (void)row_mask;
+    return __hiloint2double(rh, rl);
+}
+// sum over the 64 lanes, returned wave-uniform
+__device__ __forceinline__ double wave_sum_f64(double v) {
+    v += dpp_mov_f64(v, 0, 0xf);
+    v += dpp_mov_f64(v, 1, 0xf);
+    v += dpp_mov_f64(v, 2, 0xf);
+    v += dpp_mov_f64(v, 3, 0xf);   // every lane of a 16-lane row holds its row's sum
+    v += dpp_mov_f64(v, 4, 0xa);   // rows 1 and 3 add the sum of the row before
+    v += dpp_mov_f64(v, 5, 0xc);   // rows 2 and 3 add lane 31: lane 63 holds the total
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+
+template <int R>
 __global__ __launch_bounds__(256) void mse_test_kernel(const double* __restrict__ Ax, const int32_t* __restrict__ Ai,
                                                        const int64_t* __restrict__ Ap, int32_t m, int64_t n,
                                                        int64_t cell_off, const double* __restrict__ Wd,
                                                        const double* __restrict__ H, int k, uint64_t seed,
                                                        SglDiv inv_density, double* __restrict__ losses) {
-    __shared__ int queue[4][128];
+    __shared__ double slot[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t gw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    int* qv = queue[wave];
+    double* sl = slot[wave];
     for (int64_t cell = gw; cell < n; cell += nwaves) {
         const uint64_t xi = sgl_rand_i(seed, (uint64_t)(cell + cell_off));
-        const int64_t lo0 = Ap[cell], hi0 = Ap[cell + 1];
-        const double* h = H + cell * k;
+        const int64_t qend = Ap[cell + 1];
+        int64_t qbase = Ap[cell];
+        double h[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) h[r] = (lane + 64 * r < k) ? H[cell * k + lane + 64 * r] : 0.0;
+        // window of the cell's non-zeros: entry qbase + lane
+        int wrow = (qbase + lane < qend) ? Ai[qbase + lane] : INT32_MAX;
+        double wval = (qbase + lane < qend) ? Ax[qbase + lane] : 0.0;
         double s = 0.0;
         long long cnt = 0;
-        int qn = 0;
-        for (int g0 = 0; g0 < m + 64; g0 += 64) {
+        for (int g0 = 0; g0 < m; g0 += 64) {
             const int g = g0 + lane;
-            const bool last = g0 >= m;
-            bool drawn = false;
-            if (!last && g < m) drawn = sgl_divides(sgl_rand_j(xi, (uint64_t)g), inv_density);
-            const unsigned long long mk = __ballot(drawn);
-            if (drawn) qv[qn + __popcll(mk & ((1ull << lane) - 1ull))] = g;
-            qn += __popcll(mk);
-            __builtin_amdgcn_wave_barrier();
-            if (qn >= 64 || (last && qn > 0)) {
-                const int take = qn < 64 ? qn : 64;
-                if (lane < take) {
-                    const int gene = qv[lane];
-                    double pred = 0.0;
-                    const double* wd = Wd + (int64_t)gene * k;
-                    for (int t = 0; t < k; ++t) pred = fma(wd[t], h[t], pred);
-                    int64_t lo = lo0, hi = hi0;
-                    while (lo < hi) {
-                        const int64_t mid = (lo + hi) >> 1;
-                        if (Ai[mid] < gene) lo = mid + 1; else hi = mid;
-                    }
-                    const double val = (lo < hi0 && Ai[lo] == gene) ? Ax[lo] : 0.0;
-                    const double e = pred - val;
-                    s = fma(e, e, s);
-                    ++cnt;
-                }
-                __builtin_amdgcn_wave_barrier();
-                // shift the remainder down
-                const int rem = qn - take;
-                int mv = 0;
-                if (lane < rem) mv = qv[take + lane];
-                __builtin_amdgcn_wave_barrier();
-                if (lane < rem) qv[lane] = mv;
-                qn = rem;
-                __builtin_amdgcn_wave_barrier();
+            const bool drawn = (g < m) && sgl_divides(sgl_rand_j(xi, (uint64_t)g), inv_density);
+            unsigned long long mk = __ballot(drawn);
+            if (mk == 0ull) {   // nothing to evaluate in this chunk: only keep the window moving (cheap test below)
+                if (__builtin_amdgcn_readlane(wrow, 63) >= g0 + 64) continue;
             }
-        }
-        for (int off = 32; off > 0; off >>= 1) {
-            s += __shfl_down(s, off, 64);
-            cnt += __shfl_down(cnt, off, 64);
+            // values of this chunk's non-zeros -> slot[row - g0]; advance the window while it ends inside the chunk
+            sl[lane] = 0.0;
+            __builtin_amdgcn_wave_barrier();
+            while (true) {
+                if (wrow >= g0 && wrow < g0 + 64) sl[wrow - g0] = wval;
+                const int last = __builtin_amdgcn_readlane(wrow, 63);
+                if (last >= g0 + 64 || qbase + 64 >= qend) break;   // the window reaches past the chunk, or the column is exhausted
+                qbase += 64;
+                wrow = (qbase + lane < qend) ? Ai[qbase + lane] : INT32_MAX;
+                wval = (qbase + lane < qend) ? Ax[qbase + lane] : 0.0;
+            }
+            __builtin_amdgcn_wave_barrier();
+            const double myval = sl[lane];          // A[g0 + lane, cell] (0 if absent)
+            __builtin_amdgcn_wave_barrier();
+            while (mk != 0ull) {
+                const int b = __builtin_ctzll(mk);
+                mk &= mk - 1ull;
+                const double* wd = Wd + (int64_t)(g0 + b) * k;
+                double prod = 0.0;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int f = lane + 64 * r;
+                    if (f < k) prod = fma(wd[f], h[r], prod);
+                }
+                const double pred = wave_sum_f64(prod);
+                const int vl = __builtin_amdgcn_readlane(__double2loint(myval), b), vh = __builtin_amdgcn_readlane(__double2hiint(myval), b);
+                const double e = pred - __hiloint2double(vh, vl);
+                s = fma(e, e, s);
+                ++cnt;
+            }
         }
         if (lane == 0) losses[cell] = (cnt > 0) ? s / (double)cnt : 0.0;
     }
@@ -389,9 +424,15 @@ int k_mse_test(sgl_ctx* c, const double* Wd, const double* H, int k, uint64_t se
     double* part = c->ws + n;
     int64_t blocks = (n + 3) / 4;
     if (blocks > 256 * 16) blocks = 256 * 16;
-    mse_test_kernel<<<dim3((unsigned)blocks), dim3(256), 0, c->stream>>>(c->A.x, c->A.i, c->A.p, c->A.nrow, n,
-                                                                         c->cell_offset, Wd, H, k, seed, sgl_div_make(inv_density),
-                                                                         losses);
+    if (k <= 64)
+        mse_test_kernel<1><<<dim3((unsigned)blocks), dim3(256), 0, c->stream>>>(c->A.x, c->A.i, c->A.p, c->A.nrow, n, c->cell_offset,
+                                                                                Wd, H, k, seed, sgl_div_make(inv_density), losses);
+    else if (k <= 128)
+        mse_test_kernel<2><<<dim3((unsigned)blocks), dim3(256), 0, c->stream>>>(c->A.x, c->A.i, c->A.p, c->A.nrow, n, c->cell_offset,
+                                                                                Wd, H, k, seed, sgl_div_make(inv_density), losses);
+    else
+        mse_test_kernel<4><<<dim3((unsigned)blocks), dim3(256), 0, c->stream>>>(c->A.x, c->A.i, c->A.p, c->A.nrow, n, c->cell_offset,
+                                                                                Wd, H, k, seed, sgl_div_make(inv_density), losses);
     HIPCHK(hipGetLastError());
     sum_partial_kernel<<<dim3(nblocks), dim3(256), 0, c->stream>>>(losses, n, part);
     HIPCHK(hipGetLastError());

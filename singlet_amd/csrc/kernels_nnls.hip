@@ -140,13 +140,14 @@ __global__ __launch_bounds__(256) void nnls_wave_kernel(const double* __restrict
     for (int64_t col = wave; col < ncols; col += nwaves) {
         if (col_nnz != nullptr && col_nnz[col] == 0) continue;
         const double* Gc = G + col * gstride;
-        double b[R], x[R], gd[R];
+        double b[R], x[R], gd[R], rg[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int j = lane + 64 * r;
             b[r] = (j < k) ? B[col * k + j] : 0.0;
             x[r] = (j < k) ? X[col * k + j] : 0.0;
             gd[r] = (j < k) ? Gc[(int64_t)j * k + j] : 1.0;
+            rg[r] = 1.0 / gd[r];   // correctly rounded reciprocal of this column's diagonal, once per column
         }
         double tol = 1.0;
         int it = 0;
@@ -154,13 +155,15 @@ __global__ __launch_bounds__(256) void nnls_wave_kernel(const double* __restrict
             tol = 0.0;
             for (int i = 0; i < k; ++i) {
                 const int ir = i >> 6, il = i & 63;
-                double bsel = b[0], xsel = x[0], gsel = gd[0];
+                double bsel = b[0], xsel = x[0], gsel = gd[0], rsel = rg[0];
 #pragma unroll
                 for (int r = 1; r < R; ++r) {
-                    if (ir == r) { bsel = b[r]; xsel = x[r]; gsel = gd[r]; }
+                    if (ir == r) { bsel = b[r]; xsel = x[r]; gsel = gd[r]; rsel = rg[r]; }
                 }
-                const double bi = rl64(bsel, il), xi = rl64(xsel, il), gii = rl64(gsel, il);
-                double diff = bi / gii;
+                const double bi = rl64(bsel, il), xi = rl64(xsel, il), gii = rl64(gsel, il), rii = rl64(rsel, il);
+                // b_i / g_ii from the reciprocal (Markstein correction; see nnls_lane.h)
+                const double q0 = bi * rii;
+                double diff = fma(fma(-q0, gii, bi), rii, q0);
                 diff -= L1;
                 diff = fma(L2, xi, diff);
                 double delta = 0.0, xn = xi;

@@ -113,6 +113,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SGL_NNLS_WP
         // GV: explicit one-row-ahead software pipeline of the Gram rows (g2[parity]), fenced with
         // scheduling barriers: left alone, hipcc hoists the loads of dozens of rows of this straight-line
         // code and spills (kilobytes of scratch per lane at k > 64).
+        // row KP of the padded Gram holds the correctly rounded reciprocals 1 / G_jj (k_pad_gram): the step
+        // b_i / G_ii then costs a multiply and two FMAs instead of an 11-instruction IEEE division (below)
+        double rrow[GV ? NG : 1];
+        if (GV) {
+#pragma unroll
+            for (int m = 0; m < NG; ++m) rrow[m] = Gv[KP * GS + 16 * m];
+        }
         double g2[G2 ? 2 : 1][NG];
         if (GV && G2) {
 #pragma unroll
@@ -128,7 +135,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SGL_NNLS_WP
                 const double xi = x[XM ? (i % PF) : i];
                 if (XM && i + PF < k) x[i % PF] = valid ? xt[(i + PF) * xs] : 0.0;  // x of coordinate i + PF (same slot)
                 double grow[NG];
-                double gii;
+                double gii, rii;
                 if (GV) {
                     if (G2) {
                         if (i + 1 < k) {
@@ -143,10 +150,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SGL_NNLS_WP
 #pragma unroll
                     for (int m = 0; m < NG; ++m) grow[m] = g2[G2 ? (i & 1) : 0][m];
                     gii = nnls_dpp_bcast<(i & 15)>(grow[i >> 4]);
+                    rii = nnls_dpp_bcast<(i & 15)>(rrow[i >> 4]);
                 } else {
                     gii = Gs[i + KP * i];
+                    rii = Gs[KP * KP + i];
                 }
-                double diff = b[i] / gii;
+                // b_i / G_ii, correctly rounded, from the correctly rounded reciprocal (Markstein): q = RN(b r),
+                // rem = b - q G_ii exactly (FMA), RN(q + rem r).  G_ii is the same for all columns and sweeps.
+                const double q0 = b[i] * rii;
+                const double rem = fma(-q0, gii, b[i]);
+                double diff = fma(rem, rii, q0);
                 diff -= L1;                 // exact no-op when L1 == 0
                 diff = fma(L2, xi, diff);   // exact no-op when L2 == 0 (x >= 0)
                 // l.237-247 with the two inner tests folded away (fewer selects per coordinate):

@@ -275,20 +275,32 @@ __device__ __forceinline__ uint64_t sgl_rand_j(uint64_t xi, uint64_t j) {
     x ^= x >> 4;
     return x;
 }
-// `x % d == 0` for a kernel-uniform divisor without a 64-bit division per test (hipcc expands a
-// runtime u64 modulo into a long software routine, the bulk of the hashing cost of the masked path).
-// With M = floor((2^64 - 1) / d): q = mulhi(x, M) is floor(x / d) or up to 2 less, so x - q d needs
-// at most two conditional subtractions.  Exact for every x and d >= 1 (d = 0 is rejected on the host).
+// `x % d == 0` for a kernel-uniform divisor without a 64-bit division per test (hipcc expands a runtime u64
+// modulo into a long software routine, the bulk of the hashing cost of the masked path).  With d = 2^s * o
+// (o odd):  d | x  <=>  the low s bits of x are zero  and  o | (x >> s);  and for odd o (Granlund-Montgomery)
+// o | y  <=>  y * o^-1 (mod 2^64) <= floor((2^64 - 1) / o).  One 64-bit low multiply and a compare instead of
+// round 1's multiply-high + multiply-low + two corrections.  Exact for every x and d >= 1 (d = 0 is rejected
+// on the host); tests/test_gpu_ops.py::test_mask_bit_exact holds it against the oracle's `%`.
 struct SglDiv {
-    uint64_t d, M;
+    uint64_t d, low_mask, inv, lim;
+    int shift;
 };
-static inline SglDiv sgl_div_make(uint64_t d) { return SglDiv{d, d > 1 ? ~0ull / d : 0ull}; }
+static inline SglDiv sgl_div_make(uint64_t d) {
+    SglDiv v{d, 0ull, 1ull, ~0ull, 0};
+    if (d <= 1) return v;
+    uint64_t o = d;
+    while ((o & 1ull) == 0) { o >>= 1; ++v.shift; }
+    v.low_mask = (1ull << v.shift) - 1ull;
+    uint64_t inv = o;                       // Newton: doubles the correct low bits each step (3 -> 6 -> ... -> 96)
+    for (int q = 0; q < 6; ++q) inv *= 2ull - o * inv;
+    v.inv = inv;
+    v.lim = ~0ull / o;
+    return v;
+}
 __device__ __forceinline__ bool sgl_divides(uint64_t x, SglDiv dv) {
     if (dv.d <= 1) return true;
-    uint64_t r = x - __umul64hi(x, dv.M) * dv.d;
-    r -= (r >= dv.d) ? dv.d : 0ull;
-    r -= (r >= dv.d) ? dv.d : 0ull;
-    return r == 0;
+    if ((x & dv.low_mask) != 0ull) return false;
+    return (x >> dv.shift) * dv.inv <= dv.lim;
 }
 __device__ __forceinline__ bool sgl_draw(uint64_t state, uint64_t i, uint64_t j, SglDiv inv_density) {
     return sgl_divides(sgl_rand2(state, i, j), inv_density);
