@@ -81,6 +81,83 @@ def test_two_rank_sharded_loop_matches_unsharded():
     assert np.allclose(t0, ref["tol"], rtol=1e-9)
 
 
+def _team_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    from oracle import oracle as ora
+    from oracle_backend import OracleTeamRank
+    from singlet_amd.sharded import shard_by_nnz
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m, n, k = 121, 301, 7          # 121 genes over 2 ranks: unequal last block (the padding path)
+    A = ora.synth_csc(m, n, 10)
+    bounds = shard_by_nnz(A.p, world)
+    lo, hi = bounds[rank], bounds[rank + 1]
+    s, e = A.p[lo], A.p[hi]
+    Ash = ora.CSC(A.x[s:e], A.i[s:e], A.p[lo:hi + 1] - A.p[lo], m, hi - lo)
+
+    def all_reduce(arr):
+        dist.all_reduce(torch.from_numpy(arr))
+
+    def reduce_scatter(full):      # rows [rank * mb, (rank + 1) * mb) of the sum over the ranks
+        blocks = [torch.from_numpy(np.ascontiguousarray(b)) for b in np.split(full, world)]
+        out = torch.empty_like(blocks[rank])
+        try:
+            dist.reduce_scatter(out, blocks)
+        except (RuntimeError, NotImplementedError):   # a gloo build without reduce_scatter: same result by parts
+            for r, b in enumerate(blocks):
+                dist.reduce(b, dst=r)
+            out = blocks[rank]
+        return out.numpy()
+
+    def all_gather(block):
+        outs = [torch.empty_like(torch.from_numpy(block)) for _ in range(world)]
+        dist.all_gather(outs, torch.from_numpy(np.ascontiguousarray(block)))
+        return np.vstack([o.numpy() for o in outs])
+
+    t = OracleTeamRank(ora, rank, world, reduce_scatter, all_reduce, all_gather)
+    t.upload(Ash, Ash.t())
+    t.fit_init(k, ora.synth_winit(k, m))
+    tols = [t.iterate(0.01, 0.01, 0.0, 0.0) for _ in range(4)]
+    W, d, H = t.get_factors()
+    q.put((rank, lo, hi, W.copy(), d, H, np.array(tols)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_team_exchange_pattern_matches_unsharded():
+    """The exchange pattern of the library's native team (multi.hip): unscaled partials, ONE grouped exchange
+    (reduce-scatter by gene blocks + all-reduce of [Gram | row sums]), gene blocks solved per rank, all-gather.
+    Two gloo ranks with the oracle's operators reproduce the unsharded loop to rounding."""
+    import torch.multiprocessing as mp
+    from oracle import oracle as ora
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_team_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    m, n, k = 121, 301, 7
+    A = ora.synth_csc(m, n, 10)
+    ref = ora.c_nmf(A, A.t(), 0.0, 4, 0.01, 0.01, 0.0, 0.0, 0, ora.synth_winit(k, m))
+    (_, lo0, hi0, W0, d0, H0, t0), (_, lo1, hi1, W1, d1, H1, t1) = res
+    assert (lo0, hi1) == (0, n) and hi0 == lo1
+    assert np.array_equal(W0, W1) and np.array_equal(d0, d1) and np.array_equal(t0, t1)  # replicated bit-for-bit
+    H = np.vstack([H0, H1])
+    rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)
+    assert rel(W0, ref["w"]) < 1e-11 and rel(H, ref["h"]) < 1e-11 and rel(d0, ref["d"]) < 1e-12
+    assert np.allclose(t0, ref["tol"], rtol=1e-8)
+
+
 def test_shard_helpers():
     from singlet_amd.sharded import shard_by_count, shard_by_nnz
     assert [shard_by_count(10, 3, r) for r in range(3)] == [(0, 4), (4, 3), (7, 3)]
