@@ -321,6 +321,7 @@ def main():
                          "frac_of_measured_copy": achieved / HBM_MEASURED_GBS, "traffic": traffic,
                          "stream_layout": dict(lay, stream_bytes=stream_bytes, output_bytes=out_bytes,
                                                factor_tile_bytes_staged_from_l2=staged_bytes),
+                         "stream_layouts": {"rhs_h": layout["A"], "rhs_w": layout["At"]},
                          "algorithmic_bytes_per_pass": dom_bytes, "ms_per_pass": dom_ms,
                          "whole_iteration": {"algorithmic_bytes": bytes_iter, "achieved": bytes_iter / (ms_step * 1e-3) / 1e9 / world,
                                              "frac": bytes_iter / (ms_step * 1e-3) / 1e9 / world / HBM_PEAK_GBS}},

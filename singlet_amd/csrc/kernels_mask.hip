@@ -91,14 +91,18 @@ __global__ __launch_bounds__(256) void mask_gram_kernel(int64_t col0, int64_t nc
     }
 }
 
-// Same downdate on the FP64 matrix cores, k <= 64 (NT = ceil(k / 16) <= 4).  AAt(submat(w, idx)) is a
+// Same downdate on the FP64 matrix cores, k <= 128 (NT = ceil(k / 16) <= 8).  AAt(submat(w, idx)) is a
 // k x |idx| by |idx| x k contraction: with v_mfma_f64_16x16x4_f64 (operand layout in kernels_dense.hip)
 // four drawn rows feed all NT (NT + 1) / 2 lower-triangle 16 x 16 tiles from NT loads per lane, where
-// the VALU kernel above reads two LDS operands per FMA.  One workgroup per column: every 256-row chunk
-// is hashed (one row per thread), the drawn rows are compacted into an LDS queue, and each of the 4
-// waves takes 4 queued rows per step; the 4 waves' tiles are summed at the end.
+// the VALU kernel above reads two LDS operands per FMA.  One workgroup per column, every wave on its own
+// quarter of the rows: per STEP a wave hashes 64 rows (one per lane; ~50 VALU instructions), appends the
+// drawn ones to its ring queue in LDS, and feeds ONE queued group of 4 rows to the matrix cores.  Hash and
+// MFMAs of a step sit in one basic block, interleaved by sched_group_barrier: a v_mfma_f64_16x16x4 occupies
+// the matrix pipe for 64 cycles during which the wave issues the next hash instructions (round 1 hashed
+// ALL its rows first and only then turned to the matrix cores: 46 % MFMA-busy; profiles/).  The operands
+// of the next group are gathered (L2) while the current step runs.  The 4 waves' tiles are summed at the end.
 typedef double mg_d4 __attribute__((ext_vector_type(4)));
-#define MG_QW 1024  // drawn rows a wave queues in LDS before it turns to the matrix cores
+#define MG_QW 1024  // ring queue of drawn rows per wave (power of two)
 
 // NPARTS > 1 (k > 96): the tile set no longer fits a wave's registers; launch PART = 0 .. NPARTS-1, each
 // computing the tiles t with t % NPARTS == PART (the rows are hashed again in every part).
@@ -110,8 +114,7 @@ __global__ __launch_bounds__(256) void mask_gram_mfma_kernel(int64_t col0, int64
                                                              int64_t col_off, int64_t row_off, double* __restrict__ Gout, int raw) {
     constexpr int NTILES_ALL = NT * (NT + 1) / 2;
     constexpr int NTILES = (NTILES_ALL - PART + NPARTS - 1) / NPARTS;  // tiles of this part
-    constexpr int DEPTH = (NT <= 4) ? 4 : 2;                             // row groups in flight
-    __shared__ int list[4 * MG_QW];
+    __shared__ int list[4 * (MG_QW + 64)];   // per wave: the ring + a dump slot for the lanes that drew nothing
     __shared__ double sm[4][64 * 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, kk = lane >> 4;
@@ -124,14 +127,13 @@ __global__ __launch_bounds__(256) void mask_gram_mfma_kernel(int64_t col0, int64
     mg_d4 acc[NTILES];
 #pragma unroll
     for (int t = 0; t < NTILES; ++t) acc[t] = mg_d4{0, 0, 0, 0};
-    // Every wave works on its own: it hashes 64 rows per step (one per lane), compacts the drawn ones
-    // into its own LDS queue (no workgroup barrier), and drains the queue through the matrix cores in
-    // groups of 4 rows.  operands of group g for this lane: row q[4 g + kk], factors b*16 + r16.
-    int* q = list + wave * MG_QW;
-    auto load_group = [&](double (&f)[NT], int g, int pending) {
-        const int idx = 4 * g + kk;
-        const bool valid = idx < pending;
-        const int row = valid ? q[idx] : 0;
+    int* q = list + wave * (MG_QW + 64);
+    unsigned head = 0, tail = 0;   // rows queued / rows handed to the matrix cores (wave-uniform, monotone)
+    // operands of one group for this lane: row q[tail + kk] (kk = lane / 16), factors b * 16 + r16; rows
+    // beyond `avail` contribute zeros (the last, partial group)
+    auto load_group = [&](double (&f)[NT], unsigned first, int avail) {
+        const bool valid = kk < avail;
+        const int row = valid ? q[(first + kk) & (MG_QW - 1)] : 0;
 #pragma unroll
         for (int b = 0; b < NT; ++b) {
             const int fr = b * 16 + r16;
@@ -139,47 +141,21 @@ __global__ __launch_bounds__(256) void mask_gram_mfma_kernel(int64_t col0, int64
         }
     };
     auto mfma_group = [&](const double (&f)[NT]) {
-        int t = 0, q = 0;
+        int t = 0, qi = 0;
 #pragma unroll
         for (int bi = 0; bi < NT; ++bi)
 #pragma unroll
             for (int bj = 0; bj <= bi; ++bj) {
                 if (t % NPARTS == PART) {
-                    acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[bi], f[bj], acc[q], 0, 0, 0);
-                    ++q;
+                    acc[qi] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[bi], f[bj], acc[qi], 0, 0, 0);
+                    ++qi;
                 }
                 ++t;
             }
     };
-    // four groups' gathers (from L2) in flight before their MFMAs; `all` also takes the last, partial
-    // group (missing rows contribute zeros)
-    auto drain = [&](int pending, bool all) -> int {
-        const int ngroups = all ? (pending + 3) / 4 : pending / 4;
-        int g = 0;
-        if (DEPTH == 4) {
-            for (; g + 4 <= ngroups; g += 4) {
-                double f0[NT], f1[NT], f2[NT], f3[NT];
-                load_group(f0, g, pending); load_group(f1, g + 1, pending); load_group(f2, g + 2, pending); load_group(f3, g + 3, pending);
-                mfma_group(f0); mfma_group(f1); mfma_group(f2); mfma_group(f3);
-            }
-        } else {
-            for (; g + 2 <= ngroups; g += 2) {
-                double f0[NT], f1[NT];
-                load_group(f0, g, pending); load_group(f1, g + 1, pending);
-                mfma_group(f0); mfma_group(f1);
-            }
-        }
-        for (; g < ngroups; ++g) {
-            double f0[NT];
-            load_group(f0, g, pending);
-            mfma_group(f0);
-        }
-        return ngroups * 4;
-    };
-
     const uint64_t gcol = (uint64_t)(col + col_off);
-    int pending = 0;  // rows queued by this wave (wave-uniform)
-    for (int64_t r0 = (int64_t)wave * 64; r0 < nrow; r0 += 256) {
+    // branch-free hash step: lanes that drew nothing write to the dump slot
+    auto hash_step = [&](int64_t r0) {
         const int64_t r = r0 + lane;
         bool drawn = false;
         if (r < nrow) {
@@ -187,17 +163,51 @@ __global__ __launch_bounds__(256) void mask_gram_mfma_kernel(int64_t col0, int64
             drawn = mask_t ? sgl_draw(seed, grow, gcol, inv_density) : sgl_draw(seed, gcol, grow, inv_density);
         }
         const unsigned long long m = __ballot(drawn);
-        if (drawn) q[pending + __popcll(m & ((1ull << lane) - 1ull))] = (int)r;
-        pending += __popcll(m);
-        if (pending > MG_QW - 64) {  // another step might not fit
-            const int done = drain(pending, false);
-            const int rem = pending - done;  // < 4 left-over rows move to the front
-            const int v = (lane < rem) ? q[done + lane] : 0;
-            if (lane < rem) q[lane] = v;
-            pending = rem;
+        const unsigned pos = drawn ? ((head + (unsigned)__popcll(m & ((1ull << lane) - 1ull))) & (MG_QW - 1)) : (unsigned)(MG_QW + lane);
+        q[pos] = (int)r;
+        head += (unsigned)__popcll(m);
+    };
+
+    double f[NT];
+    bool have = false;
+    for (int64_t r0 = (int64_t)wave * 64; r0 < nrow; r0 += 256) {
+        if (have) {
+            // one basic block: the MFMAs of the loaded group, the hash of the next 64 rows in their shadow
+            double fc[NT];
+#pragma unroll
+            for (int b = 0; b < NT; ++b) fc[b] = f[b];
+            hash_step(r0);
+            mfma_group(fc);
+#pragma unroll
+            for (int t = 0; t < NTILES; ++t) {
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);                               // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x2, (56 + NTILES - 1) / NTILES, 0);     // its share of the hash
+            }
+        } else {
+            hash_step(r0);
+        }
+        __builtin_amdgcn_wave_barrier();
+        // the queue must never wrap onto unread rows: drain without hashing while it is nearly full
+        while (head - tail > MG_QW - 128) {
+            double fz[NT];
+            load_group(fz, tail, 4);
+            tail += 4;
+            mfma_group(fz);
+        }
+        have = head - tail >= 4;
+        if (have) {   // gather the next group: in flight during the next step
+            load_group(f, tail, 4);
+            tail += 4;
         }
     }
-    drain(pending, true);
+    if (have) mfma_group(f);
+    while (head != tail) {   // what is left, the last group possibly partial
+        const int avail = (int)((head - tail < 4u) ? (head - tail) : 4u);
+        double fz[NT];
+        load_group(fz, tail, avail);
+        tail += (unsigned)avail;
+        mfma_group(fz);
+    }
 
     // sum the 4 waves' tiles in a fixed order; Gout = G - (Gsub + 1e-15 I)  (quirk 8: the two 1e-15 cancel)
     int t = 0, qa = 0;
