@@ -17,6 +17,7 @@
 // arithmetic difference to an SSE2 build of the reference is FMA contraction of
 // b - G*delta.
 #include "sgl_internal.h"
+#include "nnls_static_for.h"
 #include <algorithm>
 #include <cstdlib>
 #include <utility>
@@ -198,10 +199,155 @@ __global__ __launch_bounds__(256) void nnls_wave_kernel(const double* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------
+// Per-column Gram (masked path), k <= 64: FOUR columns per wave, one 16-lane DPP row each ("quad").  In
+// nnls_wave_kernel the ~60 instructions of a coordinate step that are uniform over the wave (two divisions,
+// clamp logic, tol) are issued once per column; here one issue serves four columns, and a lane's share of the
+// Gram row update is ceil(k / 16) FMAs instead of one.  The column's Gram is staged ONCE as a packed lower
+// triangle in LDS (k (k + 1) / 2 doubles: 10 KB at k = 50, four per wave), so global memory sees it once
+// instead of once per sweep; b_i, x_i and 1 / g_ii reach the row's lanes by DPP row_newbcast (builtin: the
+// compiler pads the VALU-write -> DPP-read hazard), g_ii and the Gram row come from LDS.  Arithmetic and order
+// are those of nnls_lane.h (the folded form of src/singlet.cpp:229-250), results bit-identical.
+template <int J>
+__device__ __forceinline__ double quad_bcast(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + J, 0xf, 0xf, false);   // row_newbcast:J
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + J, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+template <int NR>
+__global__ __launch_bounds__(64) void nnls_quad_kernel(const double* __restrict__ G, int64_t gstride,
+                                                       const double* __restrict__ B, double* __restrict__ X,
+                                                       const int64_t* __restrict__ col_nnz, int k, int64_t ncols,
+                                                       double L1, double L2, unsigned long long* __restrict__ sweep_counter) {
+    extern __shared__ __attribute__((aligned(16))) char quad_lds_raw[];
+    const int lane = threadIdx.x, grp = lane >> 4, l = lane & 15;
+    const int TRI = k * (k + 1) / 2, TS = (TRI + 1) & ~1;
+    double* tri = reinterpret_cast<double*>(quad_lds_raw) + grp * TS;   // tri[i (i + 1) / 2 + j] = a[i, j], j <= i
+    const double kd = (double)k;
+    int trij[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) { const int j = l + 16 * r; trij[r] = (j < k) ? j * (j + 1) / 2 : 0; }
+    long long total_sweeps = 0, ran_total = 0;
+    const int64_t nquads = (ncols + 3) >> 2;
+    for (int64_t quad = blockIdx.x; quad < nquads; quad += gridDim.x) {
+        const int64_t col = quad * 4 + grp;
+        const bool cvalid = col < ncols && (col_nnz == nullptr || col_nnz[col] != 0);
+        const double* Gc = G + (cvalid ? col : 0) * gstride;
+        __builtin_amdgcn_wave_barrier();
+        if (cvalid) {   // the 16 lanes of the row stage their column's lower triangle
+            for (int i = 0; i < k; ++i) {
+                const int ti = i * (i + 1) / 2;
+                for (int j = l; j <= i; j += 16) tri[ti + j] = Gc[(int64_t)i * k + j];
+            }
+        }
+        double b[NR], x[NR], rg[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int j = l + 16 * r;
+            const bool v = cvalid && j < k;
+            b[r] = v ? B[col * k + j] : 0.0;
+            x[r] = v ? X[col * k + j] : 0.0;
+            rg[r] = v ? 1.0 / Gc[(int64_t)j * k + j] : 1.0;   // correctly rounded reciprocal of the diagonal
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        double tol = 1.0;
+        int it = 0, ran = 0;
+        while (true) {
+            const bool go = cvalid && it < 100 && (tol / kd) > 1e-8;
+            if (__ballot(go) == 0ull) break;
+            ++ran;
+            if (go) tol = 0.0;
+            static_for<16 * NR>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                constexpr int ir = i >> 4, il = i & 15;
+                if (i < k) {
+                    constexpr int ti = i * (i + 1) / 2;
+                    const double bi = quad_bcast<il>(b[ir]);
+                    const double xi = quad_bcast<il>(x[ir]);
+                    const double rii = quad_bcast<il>(rg[ir]);
+                    const double gii = tri[ti + i];
+                    double g[NR];
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) {
+                        if (r < ir) g[r] = tri[ti + l + 16 * r];                 // j < i for the whole row of lanes
+                        else if (r > ir) g[r] = tri[trij[r] + i];                // j > i: a[j, i]
+                        else g[r] = tri[(l <= il) ? (ti + l + 16 * r) : (trij[r] + i)];
+                    }
+                    const double q0 = bi * rii;
+                    double diff = fma(fma(-q0, gii, bi), rii, q0);   // b_i / g_ii (Markstein, see nnls_lane.h)
+                    diff -= L1;
+                    diff = fma(L2, xi, diff);
+                    const bool clamp = -diff > xi;
+                    const double xn = clamp ? 0.0 : xi + diff;
+                    double delta = clamp ? -xi : diff;
+                    delta = go ? delta : 0.0;
+                    const double tadd = fabs(diff / (xn + 1e-15));
+                    const double tnew = clamp ? ((xi != 0.0) ? 1.0 : tol) : tol + tadd;
+                    tol = go ? tnew : tol;
+                    x[ir] = (go && l == il) ? xn : x[ir];
+                    const double nd = -delta;
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) b[r] = fma(g[r], nd, b[r]);
+                }
+            });
+            it += go ? 1 : 0;
+        }
+        if (cvalid) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int j = l + 16 * r;
+                if (j < k) X[col * k + j] = x[r];
+            }
+            if (l == 0) total_sweeps += it;
+        }
+        ran_total += ran;
+    }
+    if (sweep_counter != nullptr) {
+        for (int off = 32; off > 0; off >>= 1) total_sweeps += __shfl_down(total_sweeps, off, 64);
+        if (lane == 0 && (total_sweeps != 0 || ran_total != 0)) {
+            atomicAdd(sweep_counter, (unsigned long long)total_sweeps);
+            atomicAdd(sweep_counter + 2, (unsigned long long)ran_total);
+        }
+    }
+}
+
+template <int NR>
+static int launch_nnls_quad(hipStream_t s, const double* G, int64_t gstride, const double* B, double* X, const int64_t* col_nnz,
+                            int k, int64_t ncols, double L1, double L2, unsigned long long* sweep_counter) {
+    const int TRI = k * (k + 1) / 2, TS = (TRI + 1) & ~1;
+    const size_t lds = sizeof(double) * 4 * (size_t)TS;
+    static bool attr_set[64] = {false};   // per (function, device)
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    if (lds > 48 * 1024 && (dev < 0 || dev >= 64 || !attr_set[dev])) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&nnls_quad_kernel<NR>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
+    }
+    const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(16, (160 * 1024) / (int64_t)lds));
+    const int64_t nquads = (ncols + 3) / 4;
+    const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>(nquads, 256 * per_cu * 4));
+    nnls_quad_kernel<NR><<<dim3((unsigned)blocks), dim3(64), lds, s>>>(G, gstride, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
+    HIPCHK(hipGetLastError());
+    return SGL_OK;
+}
+
 int k_nnls_wave(hipStream_t s, const double* G, int64_t gstride, const double* B, double* X, const int64_t* col_nnz,
                 int k, int64_t ncols, double L1, double L2, unsigned long long* sweep_counter) {
     if (ncols <= 0) return SGL_OK;
     if (k > SGL_MAX_K) { sgl_set_error("k_nnls_wave: k=%d > %d", k, SGL_MAX_K); return SGL_EINVAL; }
+    // per-column Grams: four columns per wave while four waves' triangles fit a CU's LDS (k <= 50).  Measured at
+    // 30 000 x 100 000 (nnls_h, ms): k = 10: 1.1 vs 4.4 for nnls_wave_kernel, k = 30: 5.8 vs 14.0, k = 50: 21.5 vs
+    // 27.1; at k = 64 (two waves per CU) 48.4 vs 38.5, so larger ranks stay on the wave kernel.  (env: A/B tests)
+    if (gstride != 0 && 4 * 4 * sizeof(double) * (size_t)(((k * (k + 1) / 2) + 1) & ~1) <= 160 * 1024 && !getenv("SGL_NNLS_NO_QUAD")) {
+        switch ((k + 15) / 16) {
+            case 1: return launch_nnls_quad<1>(s, G, gstride, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
+            case 2: return launch_nnls_quad<2>(s, G, gstride, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
+            case 3: return launch_nnls_quad<3>(s, G, gstride, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
+            default: return launch_nnls_quad<4>(s, G, gstride, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
+        }
+    }
     int64_t blocks = (ncols + 3) / 4;
     if (blocks > 256 * 32) blocks = 256 * 32;
     dim3 g((unsigned)blocks), b(256);

@@ -20,19 +20,8 @@
 #define SGL_NNLS_REPACK_NUM 3
 #define SGL_NNLS_REPACK_DEN 8
 #endif
-#include <utility>
-#include <type_traits>
 
-// compile-time loop: guarantees that b[] / x[] are only ever indexed by constants
-// (so they live in VGPRs) regardless of the optimiser's unroll thresholds.
-template <typename F, int... Is>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
-    (f(std::integral_constant<int, Is>{}), ...);
-}
-template <int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-    static_for_impl(f, std::make_integer_sequence<int, N>{});
-}
+#include "nnls_static_for.h"
 
 // GV = false: the Gram reaches the FMAs as scalar operands (s_load; row stride KP).
 // GV = true : row i of the Gram is fetched with ceil(KP / 16) coalesced vector loads, every 16-lane row of
