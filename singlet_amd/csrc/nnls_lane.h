@@ -104,8 +104,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SGL_NNLS_WP
         // code and spills (kilobytes of scratch per lane at k > 64).
         // row KP of the padded Gram holds the correctly rounded reciprocals 1 / G_jj (k_pad_gram): the step
         // b_i / G_ii then costs a multiply and two FMAs instead of an 11-instruction IEEE division (below)
-        double rrow[GV ? NG : 1];
-        if (GV) {
+        // (not in the k > 64 instances: they have no registers to spare -- measured 11 % slower at k = 100 -- and
+        // keep the division)
+        constexpr bool RCP = !XM;
+        double rrow[(GV && RCP) ? NG : 1];
+        if (GV && RCP) {
 #pragma unroll
             for (int m = 0; m < NG; ++m) rrow[m] = Gv[KP * GS + 16 * m];
         }
@@ -139,16 +142,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SGL_NNLS_WP
 #pragma unroll
                     for (int m = 0; m < NG; ++m) grow[m] = g2[G2 ? (i & 1) : 0][m];
                     gii = nnls_dpp_bcast<(i & 15)>(grow[i >> 4]);
-                    rii = nnls_dpp_bcast<(i & 15)>(rrow[i >> 4]);
+                    rii = RCP ? nnls_dpp_bcast<(i & 15)>(rrow[RCP ? (i >> 4) : 0]) : 0.0;
                 } else {
                     gii = Gs[i + KP * i];
                     rii = Gs[KP * KP + i];
                 }
                 // b_i / G_ii, correctly rounded, from the correctly rounded reciprocal (Markstein): q = RN(b r),
                 // rem = b - q G_ii exactly (FMA), RN(q + rem r).  G_ii is the same for all columns and sweeps.
-                const double q0 = b[i] * rii;
-                const double rem = fma(-q0, gii, b[i]);
-                double diff = fma(rem, rii, q0);
+                double diff;
+                if (RCP) {
+                    const double q0 = b[i] * rii;
+                    const double rem = fma(-q0, gii, b[i]);
+                    diff = fma(rem, rii, q0);
+                } else {
+                    diff = b[i] / gii;
+                }
                 diff -= L1;                 // exact no-op when L1 == 0
                 diff = fma(L2, xi, diff);   // exact no-op when L2 == 0 (x >= 0)
                 // l.237-247 with the two inner tests folded away (fewer selects per coordinate):
