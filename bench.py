@@ -219,14 +219,22 @@ def main():
     if mode == "native":
         # rank 0 makes the RCCL id, the host side broadcasts its 128 bytes, every rank joins with its context;
         # a rank that cannot (RCCL missing ...) makes ALL ranks take the hook path, and the JSON line says so
-        err = None
-        try:
-            ids = [sa.comm_unique_id() if rank == 0 else None]
-            if dist is not None:
-                dist.broadcast_object_list(ids, src=0)
-            ctx.comm_init_rank(world, rank, ids[0])
-        except Exception as e:  # noqa: BLE001
-            err = repr(e)
+        err, my_id = None, None
+        if rank == 0:
+            try:
+                my_id = sa.comm_unique_id()
+            except Exception as e:  # noqa: BLE001
+                err = repr(e)
+        ids = [my_id]
+        if dist is not None:
+            dist.broadcast_object_list(ids, src=0)      # always: the other ranks are waiting in it
+        if ids[0] is None:
+            err = err or "rank 0 could not create an RCCL id"
+        else:
+            try:
+                ctx.comm_init_rank(world, rank, ids[0])
+            except Exception as e:  # noqa: BLE001
+                err = repr(e)
         failed = 1 if err else 0
         if dist is not None:
             flag = torch.tensor([failed], dtype=torch.int32, device="cuda")

@@ -50,14 +50,27 @@ def _worker(rank, conn, q, job):
         from oracle import oracle as ora
         from singlet_amd.sharded import nmf_loop
         kind, m, n, k, split = job
-        A = ora.synth_csc(m, n, 20 if kind == "nmf" else 10)
+        A = ora.synth_csc(m, n, 20 if kind.startswith("nmf") else 10)
+        if kind == "nmf_late_hook":   # gene 5 only in the second shard, gene 9 nowhere
+            keep = ~(((A.i == 5) & (np.repeat(np.arange(n), np.diff(A.p)) < split)) | (A.i == 9))
+            cnt = np.bincount(np.repeat(np.arange(n), np.diff(A.p))[keep], minlength=n)
+            A = ora.CSC(A.x[keep], A.i[keep], np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32), m, n)
         lo, hi = (0, split) if rank == 0 else (split, n)
         Ash, s, e = _shard(A, ora, lo, hi)
         c = sa.Context(0)
         try:
             c.upload(sa.dgCMatrix(Ash.x, Ash.i, Ash.p, (Ash.nrow, Ash.ncol)), None, cell_offset=lo, ncells_total=n)
-            c.set_allreduce(PipeSum(rank, conn))
-            if kind == "nmf":
+            if kind != "nmf_late_hook":
+                c.set_allreduce(PipeSum(rank, conn))
+            if kind == "nmf_late_hook":
+                # the hook installed AFTER sgl_fit_init: the global gene counts must be rebuilt through it on the
+                # next W-update (a gene without entries in one shard would otherwise keep a stale column there)
+                c.fit_init(k, ora.synth_winit(k, m))
+                c.set_allreduce(PipeSum(rank, conn))
+                it, tols = nmf_loop(c, 0.0, 4, 0.01, 0.01, 0.0, 0.0)
+                W, d, H = c.get_factors()
+                q.put((rank, "ok", (W, d, H, tols)))
+            elif kind == "nmf":
                 c.fit_init(k, ora.synth_winit(k, m))
                 it, tols = nmf_loop(c, 0.0, 4, 0.01, 0.01, 0.0, 0.0)
                 W, d, H = c.get_factors()
@@ -103,6 +116,20 @@ def test_two_shards_one_gpu_match_unsharded(sa, ora, m, n, k, split):
     H = np.vstack([H0, H1])
     assert rel_fro(W0, ref["w"]) < 1e-9 and rel_fro(H, ref["h"]) < 1e-9 and rel_fro(d0, ref["d"]) < 1e-9
     assert rel_fro(W0, one["w"].T) < 1e-11 and rel_fro(H, one["h"].T) < 1e-11
+
+
+@pytest.mark.timeout(120)
+def test_hook_installed_after_fit_init_still_uses_global_gene_counts(sa, ora):
+    m, n, k, split = 120, 500, 6, 260
+    A = ora.synth_csc(m, n, 20)
+    col = np.repeat(np.arange(n), np.diff(A.p))
+    keep = ~(((A.i == 5) & (col < split)) | (A.i == 9))
+    cnt = np.bincount(col[keep], minlength=n)
+    A2 = ora.CSC(A.x[keep], A.i[keep], np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32), m, n)
+    ref = ora.c_nmf(A2, A2.t(), 0.0, 4, 0.01, 0.01, 0.0, 0.0, 0, ora.synth_winit(k, m))
+    (W0, d0, H0, t0), (W1, d1, H1, t1) = _run_two(("nmf_late_hook", m, n, k, split))
+    assert np.array_equal(W0, W1) and np.array_equal(d0, d1)          # no rank keeps a stale column
+    assert rel_fro(W0, ref["w"]) < 1e-9 and rel_fro(np.vstack([H0, H1]), ref["h"]) < 1e-9
 
 
 @pytest.mark.timeout(120)
