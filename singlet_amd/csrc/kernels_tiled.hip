@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void tiled_fill_kernel(const double* __restric
                     }
                     const int pos = P + q;
                     const int64_t dst = c0 + (int64_t)(pos >> 5) * 64 + h * 32 + (pos & 31);
-                    sroff[dst] = ro;
+                    if (sroff != nullptr) sroff[dst] = ro;
                     sx[dst] = xv;
                 }
             }
@@ -129,6 +129,7 @@ void sgl_tiled_free(DevTiled& S) {
     if (S.cstart) (void)hipFree(S.cstart);
     if (S.cnt) (void)hipFree(S.cnt);
     if (S.part) (void)hipFree(S.part);
+    if (S.xm) (void)hipFree(S.xm);
     S = DevTiled();
 }
 
@@ -209,6 +210,70 @@ int sgl_tiled_build(sgl_ctx* c, const DevCSC& M, int k, DevTiled& S) {
     if (chunk_entries) (void)hipFree(chunk_entries);
     if (rc == SGL_OK && e != hipSuccess) { sgl_set_error("tiled build failed: %s", hipGetErrorString(e)); rc = SGL_EHIP; }
     if (rc != SGL_OK) sgl_tiled_free(S);
+    return rc;
+}
+
+// ------------------------------------------------------- masked value array --
+// The cross-validation mask of c_ard_nmf is fixed for a fit (seed, inv_density): predict_mask leaves the drawn
+// entries out of the right-hand sides (src/singlet.cpp:449-457).  Instead of hashing every entry in every
+// iteration (acc_kernel<MASK>), a second VALUE array of the entry stream is built once per fit with x = 0 at
+// the drawn entries -- the tiled kernel then runs unchanged on it (a zero adds +0 * F: the sums are those of
+// skipping the entry, as with the stream's pads).  8 B per stored entry on top of the 12.
+__global__ __launch_bounds__(256) void mask_values_kernel(const double* __restrict__ x, const int32_t* __restrict__ idx,
+                                                          const int64_t* __restrict__ p, int64_t ncol, uint64_t seed,
+                                                          SglDiv inv_density, int mask_t, int64_t col_off, int64_t row_off,
+                                                          double* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t c = wave; c < ncol; c += nwaves) {
+        const uint64_t gc = (uint64_t)(c + col_off);
+        for (int64_t q = p[c] + lane; q < p[c + 1]; q += 64) {
+            const uint64_t gr = (uint64_t)(idx[q] + row_off);
+            const bool drawn = mask_t ? sgl_draw(seed, gr, gc, inv_density) : sgl_draw(seed, gc, gr, inv_density);
+            out[q] = drawn ? 0.0 : x[q];
+        }
+    }
+}
+
+// S.xm = the stream's value array for the mask (seed, inv_density); rebuilt only when the mask changes
+int sgl_tiled_mask_values(sgl_ctx* c, const DevCSC& M, DevTiled& S, uint64_t seed, uint64_t inv_density, int mask_t,
+                          int64_t col_off, int64_t row_off) {
+    if (S.xm && S.xm_seed == seed && S.xm_inv == inv_density && S.xm_mask_t == mask_t) return SGL_OK;
+    hipStream_t s = c->stream;
+    if (!S.xm) {
+        SGLCHK(t_alloc(&S.xm, (size_t)S.E + 512));
+        HIPCHK(hipMemsetAsync(S.xm + S.E, 0, 512 * sizeof(double), s));
+    }
+    double* xm_csc = nullptr;
+    SGLCHK(t_alloc(&xm_csc, (size_t)M.nnz));
+    DevCSC tmp = M;
+    tmp.tile_rows = S.TR;
+    tmp.ntiles = S.T;
+    tmp.seg = nullptr;
+    int rc = t_alloc(&tmp.seg, (size_t)(S.T + 1) * (size_t)M.ncol);
+    if (rc == SGL_OK) rc = k_build_segments(s, tmp);
+    if (rc == SGL_OK && M.ncol > 0) {
+        const int64_t wb = std::min<int64_t>(((int64_t)M.ncol + 3) / 4, 256 * 32);
+        mask_values_kernel<<<dim3((unsigned)wb), dim3(256), 0, s>>>(M.x, M.i, M.p, M.ncol, seed, sgl_div_make(inv_density), mask_t,
+                                                                   col_off, row_off, xm_csc);
+        if (hipGetLastError() != hipSuccess) { sgl_set_error("masked values: kernel launch failed"); rc = SGL_EHIP; }
+    }
+    const int64_t nchunks = S.nwb * S.T;
+    if (rc == SGL_OK && nchunks > 0) {
+        const int KS = (S.k + 1) & ~1;
+        int64_t blocks = (nchunks + 3) / 4;
+        if (blocks > 256 * 64) blocks = 256 * 64;
+        tiled_fill_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(xm_csc, M.i, tmp.seg, M.ncol, S.T, S.nwb, S.TR, KS * 8, S.cnt,
+                                                                       S.cstart, nullptr, S.xm);
+        if (hipGetLastError() != hipSuccess) { sgl_set_error("masked values: fill kernel launch failed"); rc = SGL_EHIP; }
+    }
+    const hipError_t e = hipStreamSynchronize(s);
+    if (tmp.seg) (void)hipFree(tmp.seg);
+    (void)hipFree(xm_csc);
+    if (rc == SGL_OK && e != hipSuccess) { sgl_set_error("masked values: %s", hipGetErrorString(e)); rc = SGL_EHIP; }
+    if (rc == SGL_OK) { S.xm_seed = seed; S.xm_inv = inv_density; S.xm_mask_t = mask_t; }
+    else { (void)hipFree(S.xm); S.xm = nullptr; }
     return rc;
 }
 
@@ -501,7 +566,7 @@ __global__ void acc_tiled_reduce_kernel(const double* __restrict__ part, int R, 
 
 // F: first factor row of this part (row stride ldf), B: its first output row (column stride ldb), kf <= S.k
 // factor rows.  One launch = one pass over the stream.
-int k_acc_tiled(hipStream_t s, const DevTiled& S, const double* F, int ldf, double* B, int ldb, int kf) {
+int k_acc_tiled(hipStream_t s, const DevTiled& S, const double* F, int ldf, double* B, int ldb, int kf, const double* xvals) {
     if (S.ncol <= 0) return SGL_OK;
     if (kf <= 0 || kf > S.k) { sgl_set_error("k_acc_tiled: bad part size %d (stream built for %d)", kf, S.k); return SGL_EINVAL; }
     const int KS = (S.k + 1) & ~1;
@@ -520,7 +585,7 @@ int k_acc_tiled(hipStream_t s, const DevTiled& S, const double* F, int ldf, doub
     double* out = slabs ? S.part : B;
     const int64_t n = (int64_t)kf * S.ncol;
     acc_tiled_kernel<<<dim3((unsigned)nwg_x, (unsigned)S.R), dim3(64 * TILED_NW), lds, s>>>(
-        S.roff, S.x, S.cstart, S.cnt, S.T, S.nwb, F, kf, S.TR, S.nrow, S.tiles_per_range, out, S.ncol, KS, ldf,
+        S.roff, xvals ? xvals : S.x, S.cstart, S.cnt, S.T, S.nwb, F, kf, S.TR, S.nrow, S.tiles_per_range, out, S.ncol, KS, ldf,
         slabs ? kf : ldb, slabs ? n : 0);
     HIPCHK(hipGetLastError());
     if (slabs) {
@@ -533,10 +598,10 @@ int k_acc_tiled(hipStream_t s, const DevTiled& S, const double* F, int ldf, doub
 }
 
 // the whole rank: one pass per part of at most S.k factor rows (one part for k <= 64)
-int k_acc_tiled_all(hipStream_t s, const DevTiled& S, const double* F, double* B, int k) {
+int k_acc_tiled_all(hipStream_t s, const DevTiled& S, const double* F, double* B, int k, const double* xvals) {
     for (int f0 = 0; f0 < k; f0 += S.k) {
         const int kf = (k - f0 < S.k) ? (k - f0) : S.k;
-        SGLCHK(k_acc_tiled(s, S, F + f0, k, B + f0, k, kf));
+        SGLCHK(k_acc_tiled(s, S, F + f0, k, B + f0, k, kf, xvals));
     }
     return SGL_OK;
 }

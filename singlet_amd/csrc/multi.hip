@@ -490,8 +490,7 @@ static int team_ard_iterate(sgl_team* T, double L1, double L2, uint64_t seed, ui
         SGLCHK(k_gram(c, c->H, k, c->A.ncol, Gh, 0.0));
         SGLCHK(sgl_phase_end(c, &pe));
         SGLCHK(sgl_phase_begin(c, SGL_PH_RHS_W, &pe));
-        // hash argument order of the At pass: draw(cell = row + cell_offset, gene = column)
-        SGLCHK(k_acc(c->stream, c->At, c->H, k, Bw, seed, inv_density, 2, 0, c->cell_offset));
+        SGLCHK(sgl_masked_rhs(c, 1, c->H, Bw, seed, inv_density));   // hash: draw(cell = row + cell_offset, gene = column)
         SGLCHK(sgl_phase_end(c, &pe));
         SGLCHK(sgl_phase_begin(c, SGL_PH_MASK, &pe));
         HIPCHK(hipMemsetAsync(c->Sbuf, 0, sizeof(double) * (size_t)mpad * k * k, c->stream));

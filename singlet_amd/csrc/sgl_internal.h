@@ -52,6 +52,9 @@ struct DevTiled {
     int64_t* cstart = nullptr;  // [nwb * T + 1] first entry of chunk (wb, t)
     uint8_t* cnt = nullptr;     // [nwb * T * CW] 4-entry groups of slot s in chunk (wb, t)
     double* part = nullptr;     // [R][k * ncol] partial slabs when the tile range is split
+    double* xm = nullptr;       // value per entry with the cross-validation mask applied (0 at drawn entries), per fit
+    uint64_t xm_seed = 0, xm_inv = 0;
+    int xm_mask_t = -1;
     int32_t TR = 0, T = 0, CW = 0, k = 0, R = 1, tiles_per_range = 0;
     int64_t nwb = 0, E = 0, ncol = 0, nrow = 0;
 };
@@ -204,8 +207,12 @@ int k_acc(hipStream_t s, const DevCSC& M, const double* F, int k, double* B,
 // LDS-tiled accumulate
 void sgl_tiled_free(DevTiled& S);
 int sgl_tiled_build(sgl_ctx* c, const DevCSC& M, int k, DevTiled& S);
-int k_acc_tiled(hipStream_t s, const DevTiled& S, const double* F, int ldf, double* B, int ldb, int kf);
-int k_acc_tiled_all(hipStream_t s, const DevTiled& S, const double* F, double* B, int k);
+int k_acc_tiled(hipStream_t s, const DevTiled& S, const double* F, int ldf, double* B, int ldb, int kf, const double* xvals = nullptr);
+int k_acc_tiled_all(hipStream_t s, const DevTiled& S, const double* F, double* B, int k, const double* xvals = nullptr);
+int sgl_tiled_mask_values(sgl_ctx* c, const DevCSC& M, DevTiled& S, uint64_t seed, uint64_t inv_density, int mask_t,
+                          int64_t col_off, int64_t row_off);
+// masked right-hand sides of predict_mask for one orientation (0: A, 1: At), through the tiled kernel when the fit has one
+int sgl_masked_rhs(sgl_ctx* c, int orientation, const double* F, double* Bbuf, uint64_t seed, uint64_t inv_density);
 int tiled_part_size(int k);
 
 // input staging (kernels_prep.hip)

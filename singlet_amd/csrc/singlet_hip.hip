@@ -814,6 +814,23 @@ int sgl_mask_workspace(sgl_ctx* c) {
     return SGL_OK;
 }
 
+// Right-hand sides of predict_mask (l.449-457).  Hash argument order: A pass draw(cell = col + cell_offset,
+// gene = row); At pass draw(cell = row + cell_offset, gene = col).  With entry streams (k <= 128) the mask is
+// folded into a second value array once per fit and the LDS-tiled kernel runs on it; otherwise every entry is
+// hashed in the plain CSC kernel.  SGL_MASKED_RHS_PLAIN=1 forces the latter (A/B tests).
+int sgl_masked_rhs(sgl_ctx* c, int orientation, const double* F, double* Bbuf, uint64_t seed, uint64_t inv_density) {
+    const int mask_t = orientation ? 1 : 0;
+    const DevCSC& M = orientation ? c->At : c->A;
+    DevTiled& S = orientation ? c->TAt : c->TA;
+    const int64_t col_off = mask_t ? 0 : c->cell_offset;
+    const int64_t row_off = mask_t ? c->cell_offset : 0;
+    if (c->use_tiled && S.roff && !getenv("SGL_MASKED_RHS_PLAIN")) {
+        SGLCHK(sgl_tiled_mask_values(c, M, S, seed, inv_density, mask_t, col_off, row_off));
+        return k_acc_tiled_all(c->stream, S, F, Bbuf, c->k, S.xm);
+    }
+    return k_acc(c->stream, M, F, c->k, Bbuf, seed, inv_density, mask_t ? 2 : 1, col_off, row_off);
+}
+
 // predict_mask (src/singlet.cpp:436-466) for one orientation, columns in
 // chunks so the per-column Grams a_i (k*k doubles each) stay bounded.
 int sgl_predict_mask_dev(sgl_ctx* c, const DevCSC& M, const int64_t* col_nnz, const double* F, double* X,
@@ -826,7 +843,7 @@ int sgl_predict_mask_dev(sgl_ctx* c, const DevCSC& M, const int64_t* col_nnz, co
     const int64_t row_off = mask_t ? c->cell_offset : 0;
     { Phase ph(c, SGL_PH_GRAM); SGLCHK(k_gram(c, F, k, M.nrow, c->G, 1e-15)); }
     { Phase ph(c, rhs_phase);
-      SGLCHK(k_acc(c->stream, M, F, k, Bbuf, seed, inv_density, mask_t ? 2 : 1, col_off, row_off)); }
+      SGLCHK(sgl_masked_rhs(c, mask_t, F, Bbuf, seed, inv_density)); }
     const int64_t chunk = c->gcols_chunk;
     for (int64_t c0 = 0; c0 < M.ncol; c0 += chunk) {
         const int64_t nc = std::min<int64_t>(chunk, M.ncol - c0);
