@@ -6,6 +6,8 @@
 // The hash is the bit-exact uint64 rng of kernels_hash.hip.
 #include "sgl_internal.h"
 #include <cstdlib>
+#include <utility>
+#include <type_traits>
 
 // lower-triangle pair p -> (i, j), i >= j, p = i*(i+1)/2 + j
 __device__ __forceinline__ void tri_unrank(int p, int& i, int& j) {
@@ -102,11 +104,27 @@ __global__ __launch_bounds__(256) void mask_gram_kernel(int64_t col0, int64_t nc
 // ALL its rows first and only then turned to the matrix cores: 46 % MFMA-busy; profiles/).  The operands
 // of the next group are gathered (L2) while the current step runs.  The 4 waves' tiles are summed at the end.
 typedef double mg_d4 __attribute__((ext_vector_type(4)));
+template <typename F_, int... Is>
+__device__ __forceinline__ void static_for_rem_impl(F_&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, typename F_>
+__device__ __forceinline__ void static_for_rem(F_&& f) { static_for_rem_impl(f, std::make_integer_sequence<int, (N > 0 ? N : 1)>{}); }
 #define MG_QW 1024  // ring queue of drawn rows per wave (power of two)
 
 // NPARTS > 1 (k > 96): the tile set no longer fits a wave's registers; launch PART = 0 .. NPARTS-1, each
 // computing the tiles t with t % NPARTS == PART (the rows are hashed again in every part).
-template <int NT, int NPARTS = 1, int PART = 0>
+// REM > 0 (k = 16 NT + r with r <= REM, REM = 2 or 4): the last r factor rows would cost NT + 1 more, almost
+// empty, 16 x 16 tiles (k = 50: 10 tiles where 6 are full).  They are updated on the VALU instead, in the
+// MFMAs' shadow: lane (kk, r16) of a row group holds F[row_kk, 16 b + r16] for every block b, the factors
+// 16 NT + i (i < REM) of that row sit in lanes r16 = i of block NT and reach the group's 16 lanes by DPP
+// row_newbcast:i -- 2 REM (NT + 1) FP64 FMAs per group of 4 rows instead of NT + 1 MFMAs.
+template <int J>
+__device__ __forceinline__ double mg_bcast(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + J, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + J, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+template <int NT, int NPARTS = 1, int PART = 0, int REM = 0>
 __global__ __launch_bounds__(256) void mask_gram_mfma_kernel(int64_t col0, int64_t ncols, int32_t nrow,
                                                              const int64_t* __restrict__ col_nnz,
                                                              const double* __restrict__ F, const double* __restrict__ G,
@@ -124,23 +142,38 @@ __global__ __launch_bounds__(256) void mask_gram_mfma_kernel(int64_t col0, int64
     double* out = Gout + (size_t)lc * k * k;
     if (col_nnz != nullptr && col_nnz[col] == 0) return;  // column is skipped by predict_mask (l.444)
 
+    constexpr int NB = NT + (REM > 0 ? 1 : 0);   // factor blocks a lane loads per row
+    static_assert(REM == 0 || NPARTS == 1, "the VALU remainder is built for single-part launches");
     mg_d4 acc[NTILES];
 #pragma unroll
     for (int t = 0; t < NTILES; ++t) acc[t] = mg_d4{0, 0, 0, 0};
+    double accr[REM > 0 ? REM : 1][NB];          // VALU remainder: rows 16 NT + i against columns 16 b + r16
+#pragma unroll
+    for (int i = 0; i < (REM > 0 ? REM : 1); ++i)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) accr[i][b] = 0.0;
     int* q = list + wave * (MG_QW + 64);
     unsigned head = 0, tail = 0;   // rows queued / rows handed to the matrix cores (wave-uniform, monotone)
     // operands of one group for this lane: row q[tail + kk] (kk = lane / 16), factors b * 16 + r16; rows
     // beyond `avail` contribute zeros (the last, partial group)
-    auto load_group = [&](double (&f)[NT], unsigned first, int avail) {
+    auto load_group = [&](double (&f)[NB], unsigned first, int avail) {
         const bool valid = kk < avail;
         const int row = valid ? q[(first + kk) & (MG_QW - 1)] : 0;
 #pragma unroll
-        for (int b = 0; b < NT; ++b) {
+        for (int b = 0; b < NB; ++b) {
             const int fr = b * 16 + r16;
             f[b] = (valid && fr < k) ? F[(int64_t)row * k + fr] : 0.0;
         }
     };
-    auto mfma_group = [&](const double (&f)[NT]) {
+    auto mfma_group = [&](const double (&f)[NB]) {
+        if (REM > 0) {   // the remainder rows on the VALU
+            static_for_rem<REM>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                const double v = mg_bcast<i>(f[NT]);
+#pragma unroll
+                for (int b = 0; b < NB; ++b) accr[i][b] = fma(f[b], v, accr[i][b]);
+            });
+        }
         int t = 0, qi = 0;
 #pragma unroll
         for (int bi = 0; bi < NT; ++bi)
@@ -168,20 +201,20 @@ __global__ __launch_bounds__(256) void mask_gram_mfma_kernel(int64_t col0, int64
         head += (unsigned)__popcll(m);
     };
 
-    double f[NT];
+    double f[NB];
     bool have = false;
     for (int64_t r0 = (int64_t)wave * 64; r0 < nrow; r0 += 256) {
         if (have) {
             // one basic block: the MFMAs of the loaded group, the hash of the next 64 rows in their shadow
-            double fc[NT];
+            double fc[NB];
 #pragma unroll
-            for (int b = 0; b < NT; ++b) fc[b] = f[b];
+            for (int b = 0; b < NB; ++b) fc[b] = f[b];
             hash_step(r0);
             mfma_group(fc);
 #pragma unroll
             for (int t = 0; t < NTILES; ++t) {
                 __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);                               // one MFMA
-                __builtin_amdgcn_sched_group_barrier(0x2, (56 + NTILES - 1) / NTILES, 0);     // its share of the hash
+                __builtin_amdgcn_sched_group_barrier(0x2, (56 + 3 * REM * NB + NTILES - 1) / NTILES, 0);   // its share of the hash (+ remainder FMAs)
             }
         } else {
             hash_step(r0);
@@ -189,7 +222,7 @@ __global__ __launch_bounds__(256) void mask_gram_mfma_kernel(int64_t col0, int64
         __builtin_amdgcn_wave_barrier();
         // the queue must never wrap onto unread rows: drain without hashing while it is nearly full
         while (head - tail > MG_QW - 128) {
-            double fz[NT];
+            double fz[NB];
             load_group(fz, tail, 4);
             tail += 4;
             mfma_group(fz);
@@ -203,7 +236,7 @@ __global__ __launch_bounds__(256) void mask_gram_mfma_kernel(int64_t col0, int64
     if (have) mfma_group(f);
     while (head != tail) {   // what is left, the last group possibly partial
         const int avail = (int)((head - tail < 4u) ? (head - tail) : 4u);
-        double fz[NT];
+        double fz[NB];
         load_group(fz, tail, avail);
         tail += (unsigned)avail;
         mfma_group(fz);
@@ -237,6 +270,29 @@ __global__ __launch_bounds__(256) void mask_gram_mfma_kernel(int64_t col0, int64
             }
             ++t;
         }
+    if (REM > 0) {   // remainder rows: sum the 4 row groups of the 4 waves (fixed order)
+        static_for_rem<REM>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                __syncthreads();
+                sm[wave][lane] = accr[i][b];
+                __syncthreads();
+                if (wave == 0 && kk == 0) {
+                    double sub = 0.0;
+                    for (int w = 0; w < 4; ++w)
+                        for (int g = 0; g < 4; ++g) sub += sm[w][g * 16 + r16];
+                    const int row = 16 * NT + i, cc = 16 * b + r16;
+                    if (row < k && cc < k && cc <= row) {
+                        if (row == cc && !raw) sub += 1e-15;
+                        const double v = raw ? sub : G[(size_t)cc * k + row] - sub;
+                        out[(size_t)cc * k + row] = v;
+                        if (row != cc) out[(size_t)row * k + cc] = v;
+                    }
+                }
+            }
+        });
+    }
 }
 
 // G == nullptr: "raw" mode -- Gcols[c] = the plain sum of f f^T over the masked rows of column c (no Gram,
@@ -249,6 +305,27 @@ int k_mask_gram_cols(hipStream_t s, int64_t col0, int64_t ncols, int32_t nrow, c
     dim3 g((unsigned)ncols), b(256);
     if (k <= 128 && !getenv("SGL_MASK_GRAM_VALU")) {  // env: keep the VALU kernel reachable for A/B tests
 #define SGL_MGM(...) mask_gram_mfma_kernel<__VA_ARGS__><<<g, b, 0, s>>>(col0, ncols, nrow, col_nnz, F, G, k, seed, sgl_div_make(inv_density), mask_t, col_offset, row_offset, Gcols, raw)
+        // k = 16 NT + r with r <= 4: the remainder rows on the VALU (REM = 2 / 4) instead of NT + 1 more tiles
+        const int nt_full = k / 16, rem = k % 16;
+        if (rem >= 1 && rem <= 4 && nt_full >= 1 && nt_full <= 6 && !getenv("SGL_MASK_GRAM_NO_REM")) {
+            const int key = nt_full * 10 + (rem <= 2 ? 2 : 4);
+            switch (key) {
+                case 12: SGL_MGM(1, 1, 0, 2); break;
+                case 14: SGL_MGM(1, 1, 0, 4); break;
+                case 22: SGL_MGM(2, 1, 0, 2); break;
+                case 24: SGL_MGM(2, 1, 0, 4); break;
+                case 32: SGL_MGM(3, 1, 0, 2); break;
+                case 34: SGL_MGM(3, 1, 0, 4); break;
+                case 42: SGL_MGM(4, 1, 0, 2); break;
+                case 44: SGL_MGM(4, 1, 0, 4); break;
+                case 52: SGL_MGM(5, 1, 0, 2); break;
+                case 54: SGL_MGM(5, 1, 0, 4); break;
+                case 62: SGL_MGM(6, 1, 0, 2); break;
+                default: SGL_MGM(6, 1, 0, 4); break;
+            }
+            HIPCHK(hipGetLastError());
+            return SGL_OK;
+        }
         switch ((k + 15) / 16) {
             case 1: SGL_MGM(1); break;
             case 2: SGL_MGM(2); break;

@@ -85,7 +85,7 @@ def test_rcpp_predict(sa, ora, shape):
     assert rel_fro(got.T, ref) < TOL and same_zero_pattern(got.T, ref)
 
 
-@pytest.mark.parametrize("k,trace,maxit", [(6, 1, 4), (8, 2, 5), (5, 3, 4), (30, 2, 3), (50, 2, 2), (70, 2, 2), (90, 1, 2), (100, 2, 2), (116, 2, 2)])
+@pytest.mark.parametrize("k,trace,maxit", [(6, 1, 4), (8, 2, 5), (5, 3, 4), (17, 2, 3), (20, 1, 3), (30, 2, 3), (36, 2, 2), (49, 2, 2), (50, 2, 2), (52, 2, 2), (66, 2, 2), (70, 2, 2), (83, 2, 2), (90, 1, 2), (100, 2, 2), (116, 2, 2)])
 def test_c_ard_nmf_parity(sa, ora, k, trace, maxit):
     m, n = (220, 260) if k <= 100 else (900, 1000)   # enough data for every factor to stay alive
     A = ora.synth_csc(m, n, 20)
