@@ -5,7 +5,7 @@
 #     (FP64 MFMA op count + MFMA busy cycles: the Gram kernels)                   -> r2_pmc_*.csv
 #  3. a masked (c_ard_nmf) iteration at 30 000 genes x 200 000 cells, k = 50: kernel stats, FETCH / WRITE and
 #     the matrix-core set (mask_gram_mfma_kernel)                                  -> r2_ard_*.csv
-# Summaries land in gpurun_out/; copy the ones to keep into profiles/.
+# Summaries land in gpurun_out/; copy the ones to keep into profiles/.  `prof_r2.sh ard` runs part 3 only.
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=gpurun_out
@@ -25,12 +25,14 @@ run_pmc() {  # name, "counters", command...
   rm -rf $O/$name.d
 }
 BENCH="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+if [ "$1" != "ard" ]; then
 run_stats r2_kernel_stats python3 bench.py --no-cpu-baseline
 run_pmc r2_pmc_fetch_size "FETCH_SIZE" $BENCH
 run_pmc r2_pmc_write_size "WRITE_SIZE" $BENCH
 run_pmc r2_pmc_sq_cycles "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" $BENCH
 run_pmc r2_pmc_sq_insts "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM" $BENCH
 run_pmc r2_pmc_mfma "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" $BENCH
+fi
 ARD="python3 scripts/ard_rate.py 200000 30000 50 2"
 run_stats r2_ard_kernel_stats $ARD
 run_pmc r2_ard_pmc_fetch_size "FETCH_SIZE" $ARD
