@@ -162,21 +162,12 @@ __global__ __launch_bounds__(256) void nnls_wave_kernel(const double* __restrict
                     if (ir == r) { bsel = b[r]; xsel = x[r]; gsel = gd[r]; rsel = rg[r]; }
                 }
                 const double bi = rl64(bsel, il), xi = rl64(xsel, il), gii = rl64(gsel, il), rii = rl64(rsel, il);
-                // b_i / g_ii from the reciprocal (Markstein correction; see nnls_lane.h)
+                // b_i / g_ii from the reciprocal (Markstein correction; see nnls_lane.h), then l.235-247
                 const double q0 = bi * rii;
-                double diff = fma(fma(-q0, gii, bi), rii, q0);
-                diff -= L1;
-                diff = fma(L2, xi, diff);
-                double delta = 0.0, xn = xi;
-                if (-diff > xi) {
-                    if (xi != 0.0) { delta = -xi; tol = 1.0; xn = 0.0; }
-                } else if (diff != 0.0) {
-                    xn = xi + diff;
-                    delta = diff;
-                    tol += fabs(diff / (xn + 1e-15));
-                }
-                if (delta != 0.0 || xn != xi) {  // wave-uniform
-                    const double nd = -delta;
+                const double diff0 = fma(fma(-q0, gii, bi), rii, q0);
+                double xn = xi;
+                const double nd = sgl_nnls_step(diff0, xn, tol, true, L1, L2);
+                if (nd != 0.0 || xn != xi) {  // wave-uniform
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
                         const int j = lane + 64 * r;
@@ -276,18 +267,10 @@ __global__ __launch_bounds__(64) void nnls_quad_kernel(const double* __restrict_
                         else g[r] = tri[(l <= il) ? (ti + l + 16 * r) : (trij[r] + i)];
                     }
                     const double q0 = bi * rii;
-                    double diff = fma(fma(-q0, gii, bi), rii, q0);   // b_i / g_ii (Markstein, see nnls_lane.h)
-                    diff -= L1;
-                    diff = fma(L2, xi, diff);
-                    const bool clamp = -diff > xi;
-                    const double xn = clamp ? 0.0 : xi + diff;
-                    double delta = clamp ? -xi : diff;
-                    delta = go ? delta : 0.0;
-                    const double tadd = fabs(diff / (xn + 1e-15));
-                    const double tnew = clamp ? ((xi != 0.0) ? 1.0 : tol) : tol + tadd;
-                    tol = go ? tnew : tol;
-                    x[ir] = (go && l == il) ? xn : x[ir];
-                    const double nd = -delta;
+                    const double diff0 = fma(fma(-q0, gii, bi), rii, q0);   // b_i / g_ii (Markstein, see nnls_lane.h)
+                    double xn = xi;
+                    const double nd = sgl_nnls_step(diff0, xn, tol, go, L1, L2);
+                    x[ir] = (l == il) ? xn : x[ir];
 #pragma unroll
                     for (int r = 0; r < NR; ++r) b[r] = fma(g[r], nd, b[r]);
                 }

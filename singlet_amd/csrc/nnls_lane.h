@@ -59,6 +59,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SGL_NNLS_WP
     const bool valid = in_range && (ps.list != nullptr || col_nnz == nullptr || col_nnz[col] != 0);
     const bool to_end = (ps.next_list == nullptr) || n_in <= (int64_t)ps.final_below;
     constexpr int PF = XM ? 2 : 4;   // coordinates of x read ahead (XM)
+    // (An instance serves KP - 1 <= k <= KP, or KP - 7 <= k above 64, so the `i < k` tests below could be compile-time
+    // for most coordinates.  Measured: without those branches the coordinates form one basic block, the register
+    // allocator spills -- 368 B of scratch per lane at KP = 50 against 28 -- and nnls_h goes from 7.1 to 10.7 ms.)
+    constexpr int KLOW = 0;
     constexpr bool G2 = !XM;          // one-row-ahead double buffer of the Gram rows (registers permitting)
     double b[KP], x[XM ? PF : KP];
     double* bp = B + col * k;
@@ -123,14 +127,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SGL_NNLS_WP
         }
         static_for<KP>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
-            if (i < k) {
+            if (i < KLOW || i < k) {
                 const double xi = x[XM ? (i % PF) : i];
-                if (XM && i + PF < k) x[i % PF] = valid ? xt[(i + PF) * xs] : 0.0;  // x of coordinate i + PF (same slot)
+                if (XM && (i + PF < KLOW || i + PF < k)) x[i % PF] = valid ? xt[(i + PF) * xs] : 0.0;  // x of coordinate i + PF (same slot)
                 double grow[NG];
                 double gii, rii;
                 if (GV) {
                     if (G2) {
-                        if (i + 1 < k) {
+                        if (i + 1 < KLOW || i + 1 < k) {
 #pragma unroll
                             for (int m = 0; m < NG; ++m) g2[(i + 1) & 1][m] = Gv[(i + 1) * GS + 16 * m];
                         }
@@ -149,34 +153,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SGL_NNLS_WP
                 }
                 // b_i / G_ii, correctly rounded, from the correctly rounded reciprocal (Markstein): q = RN(b r),
                 // rem = b - q G_ii exactly (FMA), RN(q + rem r).  G_ii is the same for all columns and sweeps.
-                double diff;
+                double diff0;
                 if (RCP) {
                     const double q0 = b[i] * rii;
                     const double rem = fma(-q0, gii, b[i]);
-                    diff = fma(rem, rii, q0);
+                    diff0 = fma(rem, rii, q0);
                 } else {
-                    diff = b[i] / gii;
+                    diff0 = sgl_div_normal(b[i], gii);
                 }
-                diff -= L1;                 // exact no-op when L1 == 0
-                diff = fma(L2, xi, diff);   // exact no-op when L2 == 0 (x >= 0)
-                // l.237-247 with the two inner tests folded away (fewer selects per coordinate):
-                //  clamp (-diff > x_i): x_i -> 0, b += G[:, i] x_i, tol = 1 -- when x_i == 0 all three
-                //    are no-ops (delta = -0.0 leaves b as it is), so only `tol = 1` needs the x_i != 0 test;
-                //  otherwise x_i += diff, b -= G[:, i] diff, tol += |diff / (x_i + 1e-15)| -- with
-                //    diff == 0 these add exact zeros, which is what skipping them does.
-                const bool clamp = -diff > xi;
-                const double xn = clamp ? 0.0 : xi + diff;
-                double delta = clamp ? -xi : diff;
-                delta = go ? delta : 0.0;
+                // l.235-247 through sgl_nnls_step (branch-free; a stopped column takes a zero step)
+                double xv = xi;
+                const double nd = sgl_nnls_step(diff0, xv, tol, go, L1, L2);
                 if (XM) {
-                    if (go) xt[i * xs] = xn;
+                    if (go) xt[i * xs] = xv;
                 } else {
-                    x[i] = go ? xn : xi;
+                    x[i] = xv;
                 }
-                const double tadd = fabs(diff / (xn + 1e-15));
-                const double tnew = clamp ? ((xi != 0.0) ? 1.0 : tol) : tol + tadd;
-                tol = go ? tnew : tol;
-                const double nd = -delta;
                 static_for<KP>([&](auto jc) {
                     constexpr int j = decltype(jc)::value;
                     if (GV) nnls_dpp_fmac<(j & 15)>(b[j], grow[j >> 4], nd);

@@ -14,3 +14,40 @@ __device__ __forceinline__ void static_for(F&& f) {
     static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
+
+// x / y, correctly rounded, for finite operands in the normal range (no over- / underflow on the way): the
+// instruction sequence hipcc emits for an FP64 division (v_rcp_f64, two Newton steps, quotient, remainder,
+// correction) WITHOUT its v_div_scale / v_div_fixup frame, which only acts on denormal or extreme-exponent
+// operands and on inf / nan / zero divisors.  In the NNLS the divisors are x + 1e-15 >= 1e-15 and Gram
+// diagonals >= 1e-15, the dividends finite steps: bit-identical to `x / y` there, 8 instructions instead of 11
+// and no special-case control flow (hipcc had wrapped the division of the tol term in exec-mask branches).
+__device__ __forceinline__ double sgl_div_normal(double x, double y) {
+    double r = __builtin_amdgcn_rcp(y);
+    double e = __builtin_fma(-y, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-y, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    const double q = x * r;
+    const double rem = __builtin_fma(-y, q, x);
+    return __builtin_fma(rem, r, q);
+}
+
+// One coordinate step of nnls (src/singlet.cpp:233-247) without the row update, branch-free, selects kept to
+// the minimum.  In: diff0 = b_i / a_ii (before the penalties), x_i, running tol, go (false: the column has
+// stopped -- its step is forced to zero, which leaves x, b and tol as they are).  Out: x_i, tol updated;
+// returns nd = -delta, the factor of the row update b += a[:, i] * nd.
+//   clamp (-diff > x_i): x_i -> 0, delta = -x_i, tol = 1 unless x_i was 0 (then nothing changes: delta = -0);
+//   otherwise            x_i += diff, delta = diff, tol += |diff / (x_i + 1e-15)|  (diff == 0 adds exact zeros).
+__device__ __forceinline__ double sgl_nnls_step(double diff0, double& xi, double& tol, bool go, double L1, double L2) {
+    double diff = diff0 - L1;                      // exact no-op when L1 == 0
+    diff = __builtin_fma(L2, xi, diff);            // exact no-op when L2 == 0 (x >= 0)
+    diff = go ? diff : 0.0;
+    const bool clamp = -diff > xi;
+    const double xn = clamp ? 0.0 : xi + diff;
+    const double nd = clamp ? xi : -diff;
+    const double tadd = __builtin_fabs(sgl_div_normal(diff, xn + 1e-15));
+    const double t1 = (xi != 0.0) ? 1.0 : tol;
+    tol = clamp ? t1 : tol + tadd;
+    xi = xn;
+    return nd;
+}
