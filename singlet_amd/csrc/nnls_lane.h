@@ -59,10 +59,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SGL_NNLS_WP
     const bool valid = in_range && (ps.list != nullptr || col_nnz == nullptr || col_nnz[col] != 0);
     const bool to_end = (ps.next_list == nullptr) || n_in <= (int64_t)ps.final_below;
     constexpr int PF = XM ? 2 : 4;   // coordinates of x read ahead (XM)
-    // (An instance serves KP - 1 <= k <= KP, or KP - 7 <= k above 64, so the `i < k` tests below could be compile-time
-    // for most coordinates.  Measured: without those branches the coordinates form one basic block, the register
-    // allocator spills -- 368 B of scratch per lane at KP = 50 against 28 -- and nnls_h goes from 7.1 to 10.7 ms.)
-    constexpr int KLOW = 0;
+    // An instance serves KP - 1 <= k <= KP (KP - 7 <= k above 64): for the coordinates below KLOW the run-time test
+    // `i < k` is always true.  hipcc implemented it as a lane mask kept in (spilled) SGPRs -- ~10 instructions per
+    // coordinate -- but simply dropping it makes the whole sweep ONE basic block, and then the register allocator
+    // spills (368 B of scratch per lane at KP = 50 against 20, nnls_h 7.1 -> 10.7 ms at config 3).  So those
+    // coordinates keep a branch, on an opaque always-true scalar: s_cmp + s_cbranch, no mask (nnls_h 6.6 -> 5.8 ms).
+    constexpr int KLOW = XM ? KP - 7 : KP - 1;
+    int one = 1;
     constexpr bool G2 = !XM;          // one-row-ahead double buffer of the Gram rows (registers permitting)
     double b[KP], x[XM ? PF : KP];
     double* bp = B + col * k;
@@ -127,7 +130,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SGL_NNLS_WP
         }
         static_for<KP>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
-            if (i < KLOW || i < k) {
+            bool run_i = i < k;
+            if (i < KLOW) { asm volatile("" : "+s"(one)); run_i = one != 0; }   // opaque, always true: keeps one basic block per coordinate
+            if (run_i) {
                 const double xi = x[XM ? (i % PF) : i];
                 if (XM && (i + PF < KLOW || i + PF < k)) x[i % PF] = valid ? xt[(i + PF) * xs] : 0.0;  // x of coordinate i + PF (same slot)
                 double grow[NG];
