@@ -244,7 +244,7 @@ __global__ __launch_bounds__(64) void nnls_quad_kernel(const double* __restrict_
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
         double tol = 1.0;
-        int it = 0, ran = 0;
+        int it = 0, ran = 0, one = 1;
         while (true) {
             const bool go = cvalid && it < 100 && (tol / kd) > 1e-8;
             if (__ballot(go) == 0ull) break;
@@ -253,7 +253,11 @@ __global__ __launch_bounds__(64) void nnls_quad_kernel(const double* __restrict_
             static_for<16 * NR>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
                 constexpr int ir = i >> 4, il = i & 15;
-                if (i < k) {
+                // an instance serves 16 (NR - 1) < k <= 16 NR: below that the test is always true; those coordinates
+                // branch on an opaque always-true scalar instead (see nnls_lane.h)
+                bool run_i = i < k;
+                if (i <= 16 * (NR - 1)) { asm volatile("" : "+s"(one)); run_i = one != 0; }
+                if (run_i) {
                     constexpr int ti = i * (i + 1) / 2;
                     const double bi = quad_bcast<il>(b[ir]);
                     const double xi = quad_bcast<il>(x[ir]);
