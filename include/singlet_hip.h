@@ -23,6 +23,9 @@
  *    outputs go to caller-allocated buffers.
  *  - all arithmetic on the path is FP64 on the GPU; there is no CPU fallback:
  *    without a usable gfx950 device every entry point fails with SGL_ENODEV.
+ *  - rank limits: c_nmf / c_project_model k <= 256 (fast paths up to 128); the masked
+ *    (c_ard_nmf*) entry points k <= 128, refused with SGL_EINVAL before any upload.
+ *  - several GPUs: section 2b; the one-shot sgl_c_nmf / sgl_c_ard_nmf honour SINGLET_NGPU.
  */
 #ifndef SINGLET_HIP_H
 #define SINGLET_HIP_H
@@ -43,7 +46,7 @@ extern "C" {
 #define SGL_ENOMEM (-4)   /* device or host allocation failed */
 #define SGL_EINTR (-5)    /* the poll callback asked to stop (Rcpp::checkUserInterrupt) */
 #define SGL_ESTATE (-6)   /* call out of order on a context */
-#define SGL_ECOMM (-7)    /* the all-reduce callback failed */
+#define SGL_ECOMM (-7)    /* the all-reduce callback failed, or RCCL is missing / returned an error */
 
 SGL_API const char* sgl_last_error(void);
 /* ABI version of this header; bumped on any signature change. */
