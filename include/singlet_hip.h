@@ -89,6 +89,14 @@ SGL_API int sgl_c_nmf(const double* Ax, const int32_t* Ai, const int32_t* Ap,
               double* w_out, double* d_out, double* h_out,
               int32_t* n_iter, double* tol_trace, const sgl_callbacks* cb);
 
+/* Opt-in resident matrix between one-shot calls: with SINGLET_HIP_CACHE=1 in the environment sgl_c_nmf and
+ * sgl_c_ard_nmf keep the context of their last call and skip upload / validation / transpose when the next call
+ * passes the same host slots (same pointers, shape, non-zero count and a sampled fingerprint of x, i, p) -- the
+ * unchanged R drivers' rank sweep (R/ard_nmf.R:95-160, R/cross_validate_nmf.R:69-97) then runs on a resident A.
+ * The pointers are compared, never dereferenced later.  Unset (default): every call uploads.
+ * sgl_cache_release frees the kept context (and its device memory); call it before unloading the library. */
+SGL_API int sgl_cache_release(void);
+
 /* c_ard_nmf (src/singlet.cpp:1155-1159 -> c_ard_nmf_base :1090-1152).
  * Replaces _singlet_c_ard_nmf (src/RcppExports.cpp:284-304).
  * Trace arrays (test_mse, iter, tol, score_overfit) must hold maxit + 1

@@ -43,6 +43,7 @@ SIGNATURES = {
     "sgl_last_error": (C.c_char_p, []),
     "sgl_abi_version": (C.c_int, []),
     "sgl_device_count": (C.c_int, []),
+    "sgl_cache_release": (C.c_int, []),
     "sgl_c_nmf": (C.c_int, _CSC + _CSC + [C.c_int32, C.c_int32, C.c_double, C.c_uint16, C.c_int, C.c_double,
                                           C.c_double, C.c_double, C.c_double, C.c_uint16, f64p, C.c_int32, f64p, f64p,
                                           f64p, i32p, f64p, _CB]),

@@ -9,6 +9,7 @@
 #include <string.h>
 #include <algorithm>
 #include <string>
+#include <mutex>
 #include <stdlib.h>
 
 // ------------------------------------------------------------------ errors --
@@ -947,6 +948,100 @@ static int current_device_or_zero() {
     return d;
 }
 
+// ---- resident matrix between one-shot calls (opt-in) -------------------------------------------------
+// R's ard_nmf / cross_validate_nmf call c_ard_nmf / c_nmf tens of times on the SAME A (R/ard_nmf.R:95-160,
+// R/cross_validate_nmf.R:69-97): every call would upload, validate, transpose and re-tile 2 x 18 GB at config 3.
+// With SINGLET_HIP_CACHE=1 in the environment the one-shot entry points sgl_c_nmf and sgl_c_ard_nmf keep the
+// context of their last call and reuse its resident matrix when the next call passes the same host slots:
+// same pointers, same shape, same non-zero count AND the same fingerprint (a hash over p and over 64 Ki
+// evenly spaced samples of x and i plus their first and last 512 entries).  The library still never retains
+// the host pointers for access -- they are compared, not dereferenced later.  The fingerprint is a heuristic:
+// a host that rewrites the same buffers in place between calls with values that agree at every sampled
+// position would get the old matrix; that is why this is opt-in (unset: every call uploads, as before).
+struct CachedCtx {
+    sgl_ctx* c = nullptr;
+    const void *ax = nullptr, *ai = nullptr, *ap = nullptr;
+    int32_t nrow = 0, ncol = 0;
+    int64_t nnz = 0;
+    uint64_t fp = 0;
+    int device = -1;
+};
+static CachedCtx g_cache;
+static std::mutex g_cache_mu;   // held for the whole one-shot call while the cache is in play (R is single-threaded; Python need not be)
+
+static uint64_t fp_mix(uint64_t h, uint64_t v) {
+    h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+    return h * 0xD6E8FEB86659FD93ull;
+}
+static uint64_t fingerprint(const double* x, const int32_t* idx, const int32_t* p, int32_t ncol) {
+    const int64_t nnz = p[ncol];
+    uint64_t h = 0x5157ull;
+    for (int32_t q = 0; q <= ncol; ++q) h = fp_mix(h, (uint64_t)(uint32_t)p[q]);
+    auto at = [&](int64_t q) {
+        uint64_t bits;
+        memcpy(&bits, &x[q], 8);
+        h = fp_mix(h, bits);
+        h = fp_mix(h, (uint64_t)(uint32_t)idx[q]);
+    };
+    const int64_t edge = std::min<int64_t>(512, nnz);
+    for (int64_t q = 0; q < edge; ++q) { at(q); at(nnz - 1 - q); }
+    const int64_t stride = std::max<int64_t>(1, nnz / 65536);
+    for (int64_t q = 0; q < nnz; q += stride) at(q);
+    return h;
+}
+
+// A context with (Ax, Ai, Ap) resident: from the cache when allowed and matching, else fresh.  *cached tells the
+// caller not to destroy it.
+static int acquire_ctx(const double* Ax, const int32_t* Ai, const int32_t* Ap, const double* Atx, const int32_t* Ati,
+                       const int32_t* Atp, int32_t nrow, int32_t ncol, sgl_ctx** out, bool* cached) {
+    *out = nullptr;
+    *cached = false;
+    const char* e = getenv("SINGLET_HIP_CACHE");
+    const bool use_cache = e && atoi(e) > 0;
+    const int dev = current_device_or_zero();
+    if (!use_cache) {
+        if (g_cache.c) { sgl_destroy(g_cache.c); g_cache = CachedCtx(); }   // switched off again: release the memory
+        SGLCHK(sgl_create(dev, out));
+        const int rc = sgl_upload_csc(*out, Ax, Ai, Ap, Atx, Ati, Atp, nrow, ncol, 0, ncol);
+        if (rc != SGL_OK) { sgl_destroy(*out); *out = nullptr; }
+        return rc;
+    }
+    if (!Ax || !Ai || !Ap || nrow <= 0 || ncol <= 0) { sgl_set_error("missing slot or empty matrix"); return SGL_EINVAL; }
+    const uint64_t fp = fingerprint(Ax, Ai, Ap, ncol);
+    if (g_cache.c && g_cache.ax == Ax && g_cache.ai == Ai && g_cache.ap == Ap && g_cache.nrow == nrow && g_cache.ncol == ncol &&
+        g_cache.nnz == (int64_t)Ap[ncol] && g_cache.fp == fp && g_cache.device == dev) {
+        *out = g_cache.c;
+        *cached = true;
+        return SGL_OK;
+    }
+    if (g_cache.c) { sgl_destroy(g_cache.c); g_cache = CachedCtx(); }
+    sgl_ctx* c = nullptr;
+    SGLCHK(sgl_create(dev, &c));
+    const int rc = sgl_upload_csc(c, Ax, Ai, Ap, Atx, Ati, Atp, nrow, ncol, 0, ncol);
+    if (rc != SGL_OK) { sgl_destroy(c); return rc; }
+    g_cache.c = c;
+    g_cache.ax = Ax; g_cache.ai = Ai; g_cache.ap = Ap;
+    g_cache.nrow = nrow; g_cache.ncol = ncol; g_cache.nnz = Ap[ncol];
+    g_cache.fp = fp;
+    g_cache.device = dev;
+    *out = c;
+    *cached = true;
+    return SGL_OK;
+}
+struct AcquiredCtx {   // destroys a non-cached context on scope exit; serialises the calls that share the cached one
+    std::unique_lock<std::mutex> lk{g_cache_mu};
+    sgl_ctx* c = nullptr;
+    bool cached = false;
+    ~AcquiredCtx() { if (c && !cached) sgl_destroy(c); }
+};
+
+// releases the cached context (if any); also what a host calls before unloading the library
+extern "C" int sgl_cache_release(void) {
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    if (g_cache.c) { sgl_destroy(g_cache.c); g_cache = CachedCtx(); }
+    return SGL_OK;
+}
+
 extern "C" int sgl_c_nmf(const double* Ax, const int32_t* Ai, const int32_t* Ap, const double* Atx, const int32_t* Ati,
                          const int32_t* Atp, int32_t nrow, int32_t ncol, double tol, uint16_t maxit, int verbose,
                          double L1_w, double L1_h, double L2_w, double L2_h, uint16_t threads, const double* w_init,
@@ -963,9 +1058,8 @@ extern "C" int sgl_c_nmf(const double* Ax, const int32_t* Ai, const int32_t* Ap,
             return sgl_c_nmf_multi(want, Ax, Ai, Ap, nrow, ncol, tol, maxit, L1_w, L1_h, L2_w, L2_h, w_init, k, w_out, d_out, h_out, n_iter, tol_trace, cb);
         }
     }
-    CtxHolder hd;
-    SGLCHK(sgl_create(current_device_or_zero(), &hd.c));
-    SGLCHK(sgl_upload_csc(hd.c, Ax, Ai, Ap, Atx, Ati, Atp, nrow, ncol, 0, ncol));
+    AcquiredCtx hd;
+    SGLCHK(acquire_ctx(Ax, Ai, Ap, Atx, Ati, Atp, nrow, ncol, &hd.c, &hd.cached));
     SGLCHK(sgl_fit_init(hd.c, k, w_init, 0));
     SGLCHK(sgl_nmf_run(hd.c, tol, maxit, L1_w, L1_h, L2_w, L2_h, n_iter, tol_trace, cb));
     return sgl_get_factors(hd.c, w_out, d_out, h_out);
@@ -1060,9 +1154,8 @@ extern "C" int sgl_c_ard_nmf(const double* Ax, const int32_t* Ai, const int32_t*
                                        trace_test_mse, w_out, d_out, h_out, test_mse, iter, tol_out, score_overfit, n_trace, cb);
         }
     }
-    CtxHolder hd;
-    SGLCHK(sgl_create(current_device_or_zero(), &hd.c));
-    SGLCHK(sgl_upload_csc(hd.c, Ax, Ai, Ap, Atx, Ati, Atp, nrow, ncol, 0, ncol));
+    AcquiredCtx hd;
+    SGLCHK(acquire_ctx(Ax, Ai, Ap, Atx, Ati, Atp, nrow, ncol, &hd.c, &hd.cached));
     SGLCHK(sgl_fit_init(hd.c, k, w_init, 0));
     int32_t nit = 0;
     SGLCHK(sgl_ard_run(hd.c, tol, maxit, L1, L2, seed, inv_density, overfit_threshold, trace_test_mse, test_mse, iter,

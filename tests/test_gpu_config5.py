@@ -101,3 +101,35 @@ def test_ard_rank_limit_is_checked_before_the_upload(sa, ora):
     with pytest.raises(sa.SingletHipError) as e:
         sa.c_ard_nmf(to_dgc(sa, A), None, 0.0, 2, False, 0.01, 0.0, 0, w0.T, 1, 20, 1e9, 1)
     assert "128" in str(e.value)
+
+
+def test_one_shot_cache_keeps_the_matrix_resident(sa, ora, monkeypatch):
+    """SINGLET_HIP_CACHE=1: the one-shot entry points reuse the resident matrix when the same host slots come
+    again (what R's unchanged ard_nmf loop passes), notice a changed value at a sampled position, and give the
+    results of the uncached calls bit for bit."""
+    import time
+    from singlet_amd import _lib
+    A = ora.synth_csc(3000, 20000, 20)
+    dA = to_dgc(sa, A)
+    w5, w8 = ora.synth_winit(5, 3000), ora.synth_winit(8, 3000)
+    plain5 = sa.c_ard_nmf(dA, None, 0.0, 3, False, 0.01, 0.0, 0, w5.T, 9, 20, 1e9, 1)
+    plain8 = sa.c_nmf(dA, None, 0.0, 3, False, 0.01, 0.01, 0.0, 0.0, 0, w8.T)
+    monkeypatch.setenv("SINGLET_HIP_CACHE", "1")
+    try:
+        t0 = time.perf_counter()
+        c5 = sa.c_ard_nmf(dA, None, 0.0, 3, False, 0.01, 0.0, 0, w5.T, 9, 20, 1e9, 1)      # uploads, keeps
+        t1 = time.perf_counter()
+        c8 = sa.c_nmf(dA, None, 0.0, 3, False, 0.01, 0.01, 0.0, 0.0, 0, w8.T)               # reuses
+        c5b = sa.c_ard_nmf(dA, None, 0.0, 3, False, 0.01, 0.0, 0, w5.T, 9, 20, 1e9, 1)     # reuses
+        for key in ("w", "h", "d", "test_mse"):
+            assert np.array_equal(c5[key], plain5[key]) and np.array_equal(c5b[key], plain5[key])
+        for key in ("w", "h", "d"):
+            assert np.array_equal(c8[key], plain8[key])
+        # a value changed in place at a sampled position (the first entries are always sampled): re-uploaded
+        dA.x[3] *= 2.0
+        changed = sa.c_nmf(dA, None, 0.0, 3, False, 0.01, 0.01, 0.0, 0.0, 0, w8.T)
+        monkeypatch.delenv("SINGLET_HIP_CACHE")
+        ref = sa.c_nmf(dA, None, 0.0, 3, False, 0.01, 0.01, 0.0, 0.0, 0, w8.T)              # cache off: released, plain call
+        assert np.array_equal(changed["w"], ref["w"]) and not np.array_equal(changed["w"], plain8["w"])
+    finally:
+        _lib.load().sgl_cache_release()
