@@ -76,7 +76,9 @@ __global__ __launch_bounds__(256) void tiled_fill_kernel(const double* __restric
                                                          int64_t nwb, int TR, int row_bytes,
                                                          const uint8_t* __restrict__ cnt,
                                                          const int64_t* __restrict__ cstart,
-                                                         uint32_t* __restrict__ sroff, double* __restrict__ sx) {
+                                                         uint32_t* __restrict__ sroff, double* __restrict__ sx,
+                                                         int masked, uint64_t seed, SglDiv inv_density, int mask_t,
+                                                         int64_t col_off, int64_t row_off) {
     const int lane = threadIdx.x & 63;
     const int64_t gw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -96,8 +98,13 @@ __global__ __launch_bounds__(256) void tiled_fill_kernel(const double* __restric
                     uint32_t ro = 0;
                     double xv = 0.0;
                     if (a + q < b) {
-                        ro = (uint32_t)(idx[a + q] - t * TR) * (uint32_t)row_bytes;
+                        const int32_t r = idx[a + q];
+                        ro = (uint32_t)(r - t * TR) * (uint32_t)row_bytes;
                         xv = x[a + q];
+                        if (masked) {  // predict_mask leaves the drawn entries out (src/singlet.cpp:449-457): x = 0 adds +0 * F
+                            const uint64_t gc = (uint64_t)(col + col_off), gr = (uint64_t)(r + row_off);
+                            if (mask_t ? sgl_draw(seed, gr, gc, inv_density) : sgl_draw(seed, gc, gr, inv_density)) xv = 0.0;
+                        }
                     }
                     const int pos = P + q;
                     const int64_t dst = c0 + (int64_t)(pos >> 5) * 64 + h * 32 + (pos & 31);
@@ -123,7 +130,22 @@ static int t_alloc(T_** p, size_t count) {
     return SGL_OK;
 }
 
+// grow-only buffer: keeps the allocation when it is large enough (3 % headroom on growth: the stream size moves
+// by a few per cent with the rank)
+template <typename T_>
+static int t_reserve(T_** p, size_t* cap, size_t count) {
+    if (*p != nullptr && *cap >= count) return SGL_OK;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    const size_t want = count + count / 32 + 64;
+    SGLCHK(t_alloc(p, want));
+    *cap = want;
+    return SGL_OK;
+}
+
 void sgl_tiled_free(DevTiled& S) {
+    if (S.seg) (void)hipFree(S.seg);
     if (S.roff) (void)hipFree(S.roff);
     if (S.x) (void)hipFree(S.x);
     if (S.cstart) (void)hipFree(S.cstart);
@@ -134,8 +156,11 @@ void sgl_tiled_free(DevTiled& S) {
 }
 
 int sgl_tiled_build(sgl_ctx* c, const DevCSC& M, int k, DevTiled& S) {
-    sgl_tiled_free(S);
     hipStream_t s = c->stream;
+    // same matrix (any change of it frees the streams), same part size: the stream is still valid
+    if (S.built && S.k == k && S.ncol == M.ncol && S.nrow == M.nrow && S.src_nnz == M.nnz) return SGL_OK;
+    S.built = false;
+    S.xm_mask_t = -1;   // the masked value array follows the stream layout
     S.k = k;
     S.CW = TILED_CW;
     const int KS = (k + 1) & ~1;  // LDS row stride in doubles: rows start 16-byte aligned
@@ -148,21 +173,22 @@ int sgl_tiled_build(sgl_ctx* c, const DevCSC& M, int k, DevTiled& S) {
     S.nwb = ((int64_t)M.ncol + S.CW - 1) / S.CW;
     S.ncol = M.ncol;
     S.nrow = M.nrow;
+    S.src_nnz = M.nnz;
     const int64_t nchunks = S.nwb * S.T;
 
-    // segment starts per (tile, column)
+    // segment starts per (tile, column); kept for the masked value array
+    int rc = t_reserve(&S.seg, &S.cap_seg, (size_t)(S.T + 1) * (size_t)M.ncol);
     DevCSC tmp = M;
     tmp.tile_rows = TR;
     tmp.ntiles = S.T;
-    tmp.seg = nullptr;
-    SGLCHK(t_alloc(&tmp.seg, (size_t)(S.T + 1) * (size_t)M.ncol));
-    int rc = k_build_segments(s, tmp);
+    tmp.seg = S.seg;
+    if (rc == SGL_OK) rc = k_build_segments(s, tmp);
     int64_t* chunk_entries = nullptr;
     if (rc == SGL_OK) rc = t_alloc(&chunk_entries, (size_t)nchunks);
-    if (rc == SGL_OK) rc = t_alloc(&S.cnt, (size_t)nchunks * TILED_NP);
-    if (rc == SGL_OK) rc = t_alloc(&S.cstart, (size_t)nchunks + 1);
+    if (rc == SGL_OK) rc = t_reserve(&S.cnt, &S.cap_cnt, (size_t)nchunks * TILED_NP);
+    if (rc == SGL_OK) rc = t_reserve(&S.cstart, &S.cap_cstart, (size_t)nchunks + 1);
     if (rc == SGL_OK) {
-        tiled_count_kernel<<<dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, s>>>(tmp.seg, M.ncol, S.T, S.nwb, S.cnt,
+        tiled_count_kernel<<<dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, s>>>(S.seg, M.ncol, S.T, S.nwb, S.cnt,
                                                                                          chunk_entries);
         if (hipGetLastError() != hipSuccess) { sgl_set_error("tiled build: count kernel launch failed"); rc = SGL_EHIP; }
     }
@@ -175,8 +201,8 @@ int sgl_tiled_build(sgl_ctx* c, const DevCSC& M, int k, DevTiled& S) {
     }
     S.E = E;
     // + 512 entries of slack: the kernel prefetches four 64-entry sets past the end
-    if (rc == SGL_OK) rc = t_alloc(&S.roff, (size_t)E + 512);
-    if (rc == SGL_OK) rc = t_alloc(&S.x, (size_t)E + 512);
+    if (rc == SGL_OK) rc = t_reserve(&S.roff, &S.cap_roff, (size_t)E + 512);
+    if (rc == SGL_OK) rc = t_reserve(&S.x, &S.cap_x, (size_t)E + 512);
     if (rc == SGL_OK) {
         if (hipMemsetAsync(S.roff + E, 0, 512 * sizeof(uint32_t), s) != hipSuccess ||
             hipMemsetAsync(S.x + E, 0, 512 * sizeof(double), s) != hipSuccess) { sgl_set_error("tiled build: clearing the stream slack failed"); rc = SGL_EHIP; }
@@ -184,8 +210,8 @@ int sgl_tiled_build(sgl_ctx* c, const DevCSC& M, int k, DevTiled& S) {
     if (rc == SGL_OK && nchunks > 0) {
         int64_t blocks = (nchunks + 3) / 4;
         if (blocks > 256 * 64) blocks = 256 * 64;
-        tiled_fill_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(M.x, M.i, tmp.seg, M.ncol, S.T, S.nwb, TR, KS * 8,
-                                                                       S.cnt, S.cstart, S.roff, S.x);
+        tiled_fill_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(M.x, M.i, S.seg, M.ncol, S.T, S.nwb, TR, KS * 8,
+                                                                       S.cnt, S.cstart, S.roff, S.x, 0, 0, sgl_div_make(1), 0, 0, 0);
         if (hipGetLastError() != hipSuccess) { sgl_set_error("tiled build: fill kernel launch failed"); rc = SGL_EHIP; }
     }
     // split of the tile range over blockIdx.y so that the grid fills 256 CUs (1 workgroup per CU)
@@ -204,12 +230,12 @@ int sgl_tiled_build(sgl_ctx* c, const DevCSC& M, int k, DevTiled& S) {
     }
     S.tiles_per_range = (S.T + R - 1) / R;
     S.R = (S.T + S.tiles_per_range - 1) / S.tiles_per_range;
-    if (rc == SGL_OK && S.R > 1) rc = t_alloc(&S.part, (size_t)S.R * (size_t)k * (size_t)M.ncol);
+    if (rc == SGL_OK && S.R > 1) rc = t_reserve(&S.part, &S.cap_part, (size_t)S.R * (size_t)k * (size_t)M.ncol);
     hipError_t e = hipStreamSynchronize(s);
-    if (tmp.seg) (void)hipFree(tmp.seg);
     if (chunk_entries) (void)hipFree(chunk_entries);
     if (rc == SGL_OK && e != hipSuccess) { sgl_set_error("tiled build failed: %s", hipGetErrorString(e)); rc = SGL_EHIP; }
-    if (rc != SGL_OK) sgl_tiled_free(S);
+    if (rc != SGL_OK) { sgl_tiled_free(S); return rc; }
+    S.built = true;
     return rc;
 }
 
@@ -219,62 +245,29 @@ int sgl_tiled_build(sgl_ctx* c, const DevCSC& M, int k, DevTiled& S) {
 // iteration (acc_kernel<MASK>), a second VALUE array of the entry stream is built once per fit with x = 0 at
 // the drawn entries -- the tiled kernel then runs unchanged on it (a zero adds +0 * F: the sums are those of
 // skipping the entry, as with the stream's pads).  8 B per stored entry on top of the 12.
-__global__ __launch_bounds__(256) void mask_values_kernel(const double* __restrict__ x, const int32_t* __restrict__ idx,
-                                                          const int64_t* __restrict__ p, int64_t ncol, uint64_t seed,
-                                                          SglDiv inv_density, int mask_t, int64_t col_off, int64_t row_off,
-                                                          double* __restrict__ out) {
-    const int lane = threadIdx.x & 63;
-    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    for (int64_t c = wave; c < ncol; c += nwaves) {
-        const uint64_t gc = (uint64_t)(c + col_off);
-        for (int64_t q = p[c] + lane; q < p[c + 1]; q += 64) {
-            const uint64_t gr = (uint64_t)(idx[q] + row_off);
-            const bool drawn = mask_t ? sgl_draw(seed, gr, gc, inv_density) : sgl_draw(seed, gc, gr, inv_density);
-            out[q] = drawn ? 0.0 : x[q];
-        }
-    }
-}
-
-// S.xm = the stream's value array for the mask (seed, inv_density); rebuilt only when the mask changes
+// S.xm = the stream's value array for the mask (seed, inv_density); rebuilt only when the mask changes.  The hash
+// runs inside the fill kernel (no temporary copy of the matrix values: at config-5 size that copy was a 12 GB
+// allocation per fit and orientation).
 int sgl_tiled_mask_values(sgl_ctx* c, const DevCSC& M, DevTiled& S, uint64_t seed, uint64_t inv_density, int mask_t,
                           int64_t col_off, int64_t row_off) {
+    if (!S.built || !S.seg) { sgl_set_error("masked values: no entry stream"); return SGL_ESTATE; }
     if (S.xm && S.xm_seed == seed && S.xm_inv == inv_density && S.xm_mask_t == mask_t) return SGL_OK;
     hipStream_t s = c->stream;
-    if (!S.xm) {
-        SGLCHK(t_alloc(&S.xm, (size_t)S.E + 512));
-        HIPCHK(hipMemsetAsync(S.xm + S.E, 0, 512 * sizeof(double), s));
-    }
-    double* xm_csc = nullptr;
-    SGLCHK(t_alloc(&xm_csc, (size_t)M.nnz));
-    DevCSC tmp = M;
-    tmp.tile_rows = S.TR;
-    tmp.ntiles = S.T;
-    tmp.seg = nullptr;
-    int rc = t_alloc(&tmp.seg, (size_t)(S.T + 1) * (size_t)M.ncol);
-    if (rc == SGL_OK) rc = k_build_segments(s, tmp);
-    if (rc == SGL_OK && M.ncol > 0) {
-        const int64_t wb = std::min<int64_t>(((int64_t)M.ncol + 3) / 4, 256 * 32);
-        mask_values_kernel<<<dim3((unsigned)wb), dim3(256), 0, s>>>(M.x, M.i, M.p, M.ncol, seed, sgl_div_make(inv_density), mask_t,
-                                                                   col_off, row_off, xm_csc);
-        if (hipGetLastError() != hipSuccess) { sgl_set_error("masked values: kernel launch failed"); rc = SGL_EHIP; }
-    }
+    S.xm_mask_t = -1;
+    SGLCHK(t_reserve(&S.xm, &S.cap_xm, (size_t)S.E + 512));
+    HIPCHK(hipMemsetAsync(S.xm + S.E, 0, 512 * sizeof(double), s));
     const int64_t nchunks = S.nwb * S.T;
-    if (rc == SGL_OK && nchunks > 0) {
+    if (nchunks > 0) {
         const int KS = (S.k + 1) & ~1;
         int64_t blocks = (nchunks + 3) / 4;
         if (blocks > 256 * 64) blocks = 256 * 64;
-        tiled_fill_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(xm_csc, M.i, tmp.seg, M.ncol, S.T, S.nwb, S.TR, KS * 8, S.cnt,
-                                                                       S.cstart, nullptr, S.xm);
-        if (hipGetLastError() != hipSuccess) { sgl_set_error("masked values: fill kernel launch failed"); rc = SGL_EHIP; }
+        tiled_fill_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(M.x, M.i, S.seg, M.ncol, S.T, S.nwb, S.TR, KS * 8, S.cnt,
+                                                                       S.cstart, nullptr, S.xm, 1, seed, sgl_div_make(inv_density),
+                                                                       mask_t, col_off, row_off);
+        HIPCHK(hipGetLastError());
     }
-    const hipError_t e = hipStreamSynchronize(s);
-    if (tmp.seg) (void)hipFree(tmp.seg);
-    (void)hipFree(xm_csc);
-    if (rc == SGL_OK && e != hipSuccess) { sgl_set_error("masked values: %s", hipGetErrorString(e)); rc = SGL_EHIP; }
-    if (rc == SGL_OK) { S.xm_seed = seed; S.xm_inv = inv_density; S.xm_mask_t = mask_t; }
-    else { (void)hipFree(S.xm); S.xm = nullptr; }
-    return rc;
+    S.xm_seed = seed; S.xm_inv = inv_density; S.xm_mask_t = mask_t;
+    return SGL_OK;
 }
 
 // ---------------------------------------------------------------- kernel ----

@@ -55,6 +55,13 @@ struct DevTiled {
     double* xm = nullptr;       // value per entry with the cross-validation mask applied (0 at drawn entries), per fit
     uint64_t xm_seed = 0, xm_inv = 0;
     int xm_mask_t = -1;
+    int64_t* seg = nullptr;     // [(T + 1) * ncol] first non-zero of column c at or below row t * TR (kept for the masked values)
+    // The buffers outlive a fit: a rank sweep re-inits the fit tens of times on one matrix, and hipMalloc / hipFree of
+    // tens of GB cost up to seconds each at config-5 size.  cap_* = allocated element counts; `built` = the stream
+    // content is valid for (k, src_nnz); any change of the matrix frees everything (sgl_tiled_free).
+    size_t cap_roff = 0, cap_x = 0, cap_cstart = 0, cap_cnt = 0, cap_part = 0, cap_xm = 0, cap_seg = 0;
+    bool built = false;
+    int64_t src_nnz = -1;
     int32_t TR = 0, T = 0, CW = 0, k = 0, R = 1, tiles_per_range = 0;
     int64_t nwb = 0, E = 0, ncol = 0, nrow = 0;
 };

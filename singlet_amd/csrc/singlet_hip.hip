@@ -134,7 +134,9 @@ static void free_csc(DevCSC& M) {
     M = DevCSC();
 }
 
-static void free_fit(sgl_ctx* c) {
+// keep_streams: the entry streams (and their buffers) survive a re-init of the fit on the SAME matrix -- every
+// path that changes the matrix calls free_fit(c) without it
+static void free_fit(sgl_ctx* c, bool keep_streams = false) {
     dev_free(c->W);
     dev_free(c->Wprev);
     dev_free(c->H);
@@ -154,8 +156,10 @@ static void free_fit(sgl_ctx* c) {
     c->link_h_rows = c->link_w_rows = 0;
     dev_free(c->A.seg);
     dev_free(c->At.seg);
-    sgl_tiled_free(c->TA);
-    sgl_tiled_free(c->TAt);
+    if (!keep_streams) {
+        sgl_tiled_free(c->TA);
+        sgl_tiled_free(c->TAt);
+    }
     c->use_tiled = false;
     c->k = 0;
 }
@@ -589,6 +593,9 @@ static int fit_init_impl(sgl_ctx* c, int32_t k, const double* w_init, uint64_t s
         SGLCHK(sgl_tiled_build(c, c->A, tiled_part_size(k), c->TA));
         if (c->At.nnz > 0) SGLCHK(sgl_tiled_build(c, c->At, tiled_part_size(k), c->TAt));
         c->use_tiled = true;
+    } else {  // no tiled path at this rank: do not sit on tens of GB of stale streams
+        sgl_tiled_free(c->TA);
+        sgl_tiled_free(c->TAt);
     }
     HIPCHK(hipStreamSynchronize(c->stream));
     return SGL_OK;
@@ -599,7 +606,7 @@ extern "C" int sgl_fit_init(sgl_ctx* c, int32_t k, const double* w_init, uint64_
     if (!c->A.p || !c->At.p) { sgl_set_error("sgl_fit_init: no matrix resident"); return SGL_ESTATE; }
     if (k <= 0 || k > SGL_MAX_K) { sgl_set_error("rank k=%d unsupported (1..%d)", k, SGL_MAX_K); return SGL_EINVAL; }
     HIPCHK(hipStreamSynchronize(c->stream));
-    free_fit(c);
+    free_fit(c, true);
     const int rc = fit_init_impl(c, k, w_init, synth_seed);
     if (rc != SGL_OK) { free_fit(c); return rc; }   // a half-built fit must not pass FIT_GUARD
     c->k = k;

@@ -51,6 +51,31 @@ def test_ard_run_at_config5_shape_is_finite_and_bit_reproducible(big, k, iters):
     assert np.array_equal(r0["tol"], r1["tol"])
 
 
+def test_entry_streams_survive_fit_reinit(big):
+    """fit_init keeps the entry streams (and their buffers) of the resident matrix: same rank -> no rebuild, other
+    rank -> rebuilt in the same allocations, other mask seed -> only the masked value array is refilled.  Every
+    combination must give the bits of a fresh context."""
+    def fit(ctx, k, seed):
+        ctx.fit_init(k, None)
+        r = ctx.ard_run(0.0, 2, 0.01, 0.0, seed, INV, 1e9, 1)
+        W, d, _ = ctx.get_factors(h=False)
+        return r["test_mse"].copy(), W.copy(), d.copy()
+
+    seq = [(12, SEED), (12, SEED + 1), (30, SEED), (12, SEED)]
+    got = [fit(big, k, s) for k, s in seq]
+    assert np.array_equal(got[0][0], got[3][0]) and np.array_equal(got[0][1], got[3][1])   # back to the first (k, seed)
+    assert not np.array_equal(got[0][0], got[1][0])                                          # another mask is another fit
+    import singlet_amd as sa_mod
+    fresh = sa_mod.Context(0)
+    try:
+        fresh.synth(GENES, CELLS, 20)
+        # a context that never saw another rank or seed
+        f1 = fit(fresh, 12, SEED + 1)
+    finally:
+        fresh.close()
+    assert np.array_equal(f1[0], got[1][0]) and np.array_equal(f1[1], got[1][1]) and np.array_equal(f1[2], got[1][2])
+
+
 def test_never_drawn_mask_reduces_to_the_plain_fit(big):
     """With a divisor no hash value is a multiple of, predict_mask is predict up to the 1e-15 ridge the
     downdate cancels (src/singlet.cpp:461-462): the masked path (plain CSC kernel + per-column Grams +
