@@ -18,6 +18,7 @@ on the CPU beyond bookkeeping.
 """
 import ctypes as C
 import math
+import os
 
 import numpy as np
 
@@ -560,10 +561,58 @@ def _ard_nmf_search(fits, A, df, w_init, test_seed, inv_density, k_init, k_max, 
     return _sort_model(model, A.Dimnames[0], A.Dimnames[1])
 
 
+def _replica_devices(devices):
+    """devices of the replica sweep: an explicit list, a count, or SINGLET_REPLICA_GPUS=N from the environment
+    (None / unset: device 0 only)."""
+    if devices is None:
+        n = int(os.environ.get("SINGLET_REPLICA_GPUS", "1") or "1")
+        return list(range(max(n, 1)))
+    if isinstance(devices, (int, np.integer)):
+        return list(range(max(int(devices), 1)))
+    return [int(d) for d in devices]
+
+
+def _run_grid_on_replicas(A, devices, jobs, run):
+    """SURVEY.md 8(e) "rank-sweep alternative": the (rank, replicate) fits of a grid are independent, so every
+    device keeps its OWN resident copy of A and pulls fits from a shared queue (largest rank first: the cost of a
+    masked fit grows like k^2) -- no communication at all.  One host thread per device (the library calls release
+    the GIL; a context is only ever used by its own thread).  jobs: list of argument tuples; run(fits, job) -> result.
+    Results come back in job order and do not depend on which device ran which fit."""
+    import threading
+    order = sorted(range(len(jobs)), key=lambda q: -jobs[q][0])
+    lock = threading.Lock()
+    results = [None] * len(jobs)
+    errors = []
+
+    def worker(dev):
+        try:
+            with _ResidentFits(A, dev) as fits:
+                while True:
+                    with lock:
+                        if errors or not order:
+                            return
+                        q = order.pop(0)
+                    results[q] = run(fits, jobs[q])
+        except BaseException as e:  # noqa: BLE001 -- re-raised on the calling thread
+            with lock:
+                errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(d,), name="singlet-replica-%d" % i) for i, d in enumerate(devices)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    return results
+
+
 def cross_validate_nmf(A, ranks, n_replicates=3, tol=1e-4, maxit=100, verbose=1, L1=0.01, L2=0, threads=0,
-                       test_density=0.05, tol_overfit=1e-4, trace_test_mse=5, seed=None, resident=True):
+                       test_density=0.05, tol_overfit=1e-4, trace_test_mse=5, seed=None, resident=True, devices=None):
     """R/cross_validate_nmf.R:18-105 (sparse, single-matrix branch) -> cv table with k, rep, test_error, iter, tol.
-    resident = True keeps A in HBM across the whole (rank, replicate) grid."""
+    resident = True keeps A in HBM across the whole (rank, replicate) grid.  devices (a list, a count, or
+    SINGLET_REPLICA_GPUS=N): deal the independent fits of the grid out over several GPUs, each with its own
+    resident copy of A (BASELINE config 5 on one node); the table is the one-device table, row for row."""
     if L1 >= 1:
         raise ValueError("L1 penalty must be strictly in the range (0, 1]")
     A = as_dgCMatrix(A)
@@ -574,16 +623,29 @@ def cross_validate_nmf(A, ranks, n_replicates=3, tol=1e-4, maxit=100, verbose=1,
     inv_density = int(round(1 / test_density))
     df2 = CVData()
     grid = [(k, rep) for rep in range(1, n_replicates + 1) for k in ranks]  # expand.grid(k = ranks, rep = 1:n)
-    fits = _ResidentFits(A) if resident else _OneShotFits(A)
+
+    def fit(fits, job):
+        k, rep = job
+        return fits.c_ard_nmf(tol, maxit, verbose > 1, L1, L2, threads, w_init[rep - 1][:k, :], seeds[rep - 1],
+                              inv_density, tol_overfit, trace_test_mse)
+
+    def rows(k, rep, model):
+        for t in range(len(model["test_mse"])):
+            df2.append({"k": k, "rep": rep, "test_error": float(model["test_mse"][t]), "iter": int(model["iter"][t]),
+                        "tol": float(model["tol"][t])})
+
+    devs = _replica_devices(devices)
+    if resident and len(devs) > 1:
+        for (k, rep), model in zip(grid, _run_grid_on_replicas(A, devs, grid, fit)):
+            rows(k, rep, model)
+        return df2
+    fits = _ResidentFits(A, devs[0]) if resident else _OneShotFits(A)
     try:
         for q, (k, rep) in enumerate(grid):
             if verbose > 1:
                 print("k = %d, rep = %d (%d/%d):" % (k, rep, q + 1, len(grid)))
-            model = fits.c_ard_nmf(tol, maxit, verbose > 1, L1, L2, threads, w_init[rep - 1][:k, :], seeds[rep - 1],
-                                   inv_density, tol_overfit, trace_test_mse)
-            for t in range(len(model["test_mse"])):
-                df2.append({"k": k, "rep": rep, "test_error": float(model["test_mse"][t]), "iter": int(model["iter"][t]),
-                            "tol": float(model["tol"][t])})
+            model = fit(fits, (k, rep))
+            rows(k, rep, model)
             if verbose > 1:
                 print("test set error: %#.4e\n" % model["test_mse"][-1])
                 if model["test_mse"][-1] / model["test_mse"][0] > (1 + tol_overfit):

@@ -120,6 +120,16 @@ def test_resident_sweep_equals_one_shot_calls(sa, ora):
     assert np.array_equal(ma["w"], mb["w"]) and np.array_equal(ma["h"], mb["h"]) and np.array_equal(ma["d"], mb["d"])
 
 
+def test_replica_sweep_equals_the_one_device_sweep(sa, ora):
+    """cross_validate_nmf(devices = ...): the grid dealt out over several resident copies of A (here three contexts
+    on the one device of this box, one host thread each) returns the one-device table bit for bit."""
+    A = to_dgc(sa, ora.synth_csc(400, 900, 10))
+    kw = dict(n_replicates=3, maxit=6, verbose=0, trace_test_mse=2, seed=5)
+    a = sa.cross_validate_nmf(A, [3, 5, 8, 12], **kw)
+    b = sa.cross_validate_nmf(A, [3, 5, 8, 12], devices=[0, 0, 0], **kw)
+    assert len(a) == len(b) == 4 * 3 * len([r for r in a if r["k"] == 3 and r["rep"] == 1]) and all(ra == rb for ra, rb in zip(a, b))
+
+
 def test_ard_rank_limit_is_checked_before_the_upload(sa, ora):
     A = ora.synth_csc(200, 150, 10)
     w0 = ora.synth_winit(130, 200)

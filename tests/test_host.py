@@ -93,6 +93,47 @@ def test_cross_validate_nmf_grid_and_columns(sa, monkeypatch):
         api.cross_validate_nmf(A, [2], L1=1.0)
 
 
+def test_cross_validate_nmf_replica_devices(sa, monkeypatch):
+    """The replica sweep (one resident copy of A per device, fits pulled from a queue, largest rank first) returns
+    the one-device table row for row, whatever device ran which fit; errors of a worker surface on the caller."""
+    from singlet_amd import api
+    import threading
+    log = []
+
+    class FakeFits:
+        def __init__(self, A, device=0):
+            self.device = device
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            pass
+
+        def close(self):
+            pass
+
+        def c_ard_nmf(self, tol, maxit, verbose, L1, L2, threads, w, seed, inv_density, overfit_threshold, trace_test_mse):
+            k = w.shape[0]
+            log.append((self.device, k, seed, threading.current_thread().name))
+            if k == 13:
+                raise RuntimeError("boom")
+            return {"test_mse": np.array([1.0 / k + 1e-9 * (seed % 7), 0.5 / k]), "iter": np.array([0, 5]), "tol": np.array([0.1, 0.01])}
+
+    monkeypatch.setattr(api, "_ResidentFits", FakeFits)
+    A = sa.dgCMatrix.from_dense(np.eye(5))
+    one = api.cross_validate_nmf(A, [2, 3, 5], n_replicates=2, verbose=0, seed=1)
+    log.clear()
+    many = api.cross_validate_nmf(A, [2, 3, 5], n_replicates=2, verbose=0, seed=1, devices=[0, 1, 2])
+    assert list(one) == list(many) and many.columns() == ["k", "rep", "test_error", "iter", "tol"]
+    assert sorted(k for _, k, _, _ in log) == [2, 2, 3, 3, 5, 5] and {d for d, _, _, _ in log} <= {0, 1, 2}
+    assert all(name.startswith("singlet-replica-") for _, _, _, name in log)
+    monkeypatch.setenv("SINGLET_REPLICA_GPUS", "2")
+    assert api._replica_devices(None) == [0, 1] and api._replica_devices(3) == [0, 1, 2] and api._replica_devices([4]) == [4]
+    with pytest.raises(RuntimeError, match="boom"):
+        api.cross_validate_nmf(A, [2, 13], n_replicates=1, verbose=0, seed=1, devices=2)
+
+
 def test_run_nmf_argument_plumbing(sa, monkeypatch):
     from singlet_amd import api
     seen = {}
