@@ -25,6 +25,9 @@ Register plan (asm-owned, the compiler is limited to v0..v63):
 import sys
 
 D = 4
+import os
+G = int(os.environ.get('ROWS_G', '2'))   # entries per part (2: product candidate; 4: what-if for row parts of four)
+PP = 16 // G                               # parts per packet
 XB = [64 + 2 * d for d in range(D)]
 CB = [72 + d for d in range(D)]
 CC, T1, RA, RB = 76, 77, 78, 79
@@ -98,14 +101,14 @@ class Gen:
         """LDS addresses of the 8 parts of packet q (row offsets in RA / RB); M0 must be off"""
         if not self.lds:
             return
-        R = RA if q < 2 else RB
-        for p in range(8):
-            self.A(f"v_add_u32_dpp v{AD[p]}, v{R}, %[lane8] row_newbcast:{8 * (q & 1) + p} row_mask:0xf bank_mask:0xf")
+        R = RA if (q * PP) < 16 else RB
+        for p in range(PP):
+            self.A(f"v_add_u32_dpp v{AD[p]}, v{R}, %[lane8] row_newbcast:{(q * PP) % 16 + p} row_mask:0xf bank_mask:0xf")
 
     def reads(self, fb):
         if not self.lds:
             return
-        for p in range(8):
+        for p in range(PP):
             self.A(f"ds_read_b64 {r2(FB[fb][p])}, v{AD[p]}")
 
     def slots(self, q, fb):
@@ -114,7 +117,7 @@ class Gen:
             j = s >> 1
             if self.idx:
                 A(f"s_lshr_b32 m0, s{S_T[j]}, 16" if s & 1 else f"s_bfe_u32 m0, s{S_T[j]}, 0x100000")
-            f = FB[fb][j] if self.lds else FB[0][0]
+            f = FB[fb][s // G] if self.lds else FB[0][0]
             if self.fma:
                 A(f"v_fmac_f64_dpp {r2(ACC)}, {r2(XQ[q])}, {r2(f)} row_newbcast:{s} row_mask:0xf bank_mask:0xf")
 
@@ -141,7 +144,7 @@ class Gen:
                 self.addrs(q + 1)
                 self.reads(fb ^ 1)
                 if self.lds:
-                    A("s_waitcnt lgkmcnt(8)")   # packet q's factor rows; the 8 reads just issued stay in flight
+                    A(f"s_waitcnt lgkmcnt({PP})")   # packet q's factor rows; the reads just issued stay in flight
             else:
                 L_np, L_join = self.label("np"), self.label("join")
                 A(f"s_cmp_le_u32 s{S_NB}, 1")
@@ -152,7 +155,7 @@ class Gen:
                 self.addrs(0)
                 self.reads(0)
                 if self.lds:
-                    A("s_waitcnt lgkmcnt(8)")
+                    A(f"s_waitcnt lgkmcnt({PP})")
                 A(f"s_branch {L_join}")
                 A(f"{L_np}:")
                 if self.lds:
