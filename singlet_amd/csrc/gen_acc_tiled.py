@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""Generates acc_tiled_gen.inc: the hand-scheduled chunk loop of the LDS-tiled accumulate (kernels_tiled.hip).
+
+Same entry stream, same arithmetic and the same order of operations as the compiler-scheduled loop it replaces
+(results are bit-identical); what changes is the schedule:
+
+  * the LDS reads run ONE OCTET (8 entry pairs) ahead without ever draining: the read of pair j of the next octet
+    is issued right after the two FMAs of pair j of this one, into the register quad those FMAs just consumed
+    (one buffer of 8 quads; counted lgkmcnt(7): LDS returns in order and nothing else uses the counter in here).
+    The compiler's schedule finished every 64-entry set with lgkmcnt(0) and paid the loaded LDS latency once
+    per set;
+  * the accumulators of the 32 column pairs stay IN PLACE in v[128:255]: VGPR index mode is on for the whole
+    loop and M0 (destination-relative, 0x8000 | 4 * pair) is written before each group of FMAs and cleared before
+    the address adds -- a pair switch is three scalar instructions and a v_readlane instead of eight moves through
+    s_set_gpr_idx_on / off;
+  * the next set is prepared (three v_permlane16_swap, stream refill) inside the last octet of the running one.
+
+Stream (kernels_tiled.hip): sets of 64 entries = 32 of the A half, 32 of the B half; row offsets u32, values f64;
+cnt[pair] = groups of 4 entry pairs of that column pair in the chunk.
+
+Register plan (asm-owned; the compiler is capped at v0..v63 by amdgpu_waves_per_eu(8, 8)):
+    v64..67 row-offset ring, v68..75 value ring (4 sets in flight, counted vmcnt)
+    v76..81 / v82..87 prepared set (ra, rb, xa, xb), two copies   v88..95 LDS addresses   v96..127 8 factor quads
+    v128..255 accumulators (pair p: v[128 + 4p : 131 + 4p])
+    s[84:85] / s[86:87] next set to load (row offsets / values), s88 sets left, s89 groups left of the running
+    pair, s90 running pair, s91 its M0 word
+"""
+import sys
+
+ER = [64 + i for i in range(4)]
+EX = [68 + 2 * i for i in range(4)]
+P = [{"ra": 76 + 6 * b, "rb": 77 + 6 * b, "xa": 78 + 6 * b, "xb": 80 + 6 * b} for b in range(2)]
+AD = [88 + j for j in range(8)]
+W = [96 + 4 * j for j in range(8)]
+ACC = 128
+S_RP, S_XP, S_NS, S_REM, S_S, S_ACC = 84, 86, 88, 89, 90, 91
+
+
+def r2(b):
+    return f"v[{b}:{b + 1}]"
+
+
+class Gen:
+    def __init__(self):
+        self.L = []
+        self.lab = 0
+
+    def A(self, s):
+        self.L.append(s)
+
+    def label(self, stem):
+        self.lab += 1
+        return f".Ltiled_{stem}_{self.lab}_%="
+
+    def refill(self, i):
+        A = self.A
+        A(f"global_load_dword v{ER[i]}, %[voff4], s[{S_RP}:{S_RP + 1}]")
+        A(f"global_load_dwordx2 {r2(EX[i])}, %[voff8], s[{S_XP}:{S_XP + 1}]")
+        A(f"s_add_u32 s{S_RP}, s{S_RP}, 256")
+        A(f"s_addc_u32 s{S_RP + 1}, s{S_RP + 1}, 0")
+        A(f"s_add_u32 s{S_XP}, s{S_XP}, 512")
+        A(f"s_addc_u32 s{S_XP + 1}, s{S_XP + 1}, 0")
+
+    def prep(self, i, p):
+        """ring slot i -> prepared set p: rows [A0 A1 B0 B1] -> ra = [A0 A0 B0 B0], rb = [A1 A1 B1 B1] (same for x),
+        then the slot is refilled with the set four ahead.  M0 must be off."""
+        A = self.A
+        A("s_waitcnt vmcnt(6)")   # the two loads of this slot are the oldest of the eight in flight
+        A(f"v_mov_b32 v{p['ra']}, v{ER[i]}")
+        A(f"v_mov_b32 v{p['rb']}, v{ER[i]}")
+        for w in (0, 1):
+            A(f"v_mov_b32 v{p['xa'] + w}, v{EX[i] + w}")
+            A(f"v_mov_b32 v{p['xb'] + w}, v{EX[i] + w}")
+        A("s_nop 1")
+        A(f"v_permlane16_swap_b32 v{p['ra']}, v{p['rb']}")
+        for w in (0, 1):
+            A(f"v_permlane16_swap_b32 v{p['xa'] + w}, v{p['xb'] + w}")
+        self.refill(i)
+        A("s_nop 1")   # VALU write -> DPP read of the prepared registers
+
+    def addrs(self, p, o):
+        """LDS addresses of the 8 entry pairs of octet o (0..3) of prepared set p"""
+        r = p["ra"] if o < 2 else p["rb"]
+        for j in range(8):
+            self.A(f"v_add_u32_dpp v{AD[j]}, v{r}, %[lane16] row_newbcast:{8 * (o & 1) + j} row_mask:0xf bank_mask:0xf")
+
+    def group_head(self):
+        """before a group of 4 entry pairs: count the running pair's groups down, move on to the next pair that has
+        any when they are used up (cnt in lanes 0..31 of %[cnt]); then point M0 at the pair's accumulators"""
+        A = self.A
+        L_next, L_go = self.label("nx"), self.label("go")
+        A(f"s_sub_u32 s{S_REM}, s{S_REM}, 1")
+        A(f"s_cbranch_scc0 {L_go}")
+        A(f"{L_next}:")
+        A(f"s_add_u32 s{S_S}, s{S_S}, 1")
+        A(f"v_readlane_b32 s{S_REM}, %[cnt], s{S_S}")
+        A(f"s_cmp_eq_u32 s{S_REM}, 0")
+        A(f"s_cbranch_scc1 {L_next}")
+        A(f"s_sub_u32 s{S_REM}, s{S_REM}, 1")
+        A(f"s_lshl_b32 s{S_ACC}, s{S_S}, 2")
+        A(f"s_or_b32 s{S_ACC}, s{S_ACC}, 0x8000")
+        A(f"{L_go}:")
+        A(f"s_mov_b32 m0, s{S_ACC}")
+
+    def octet_fmas(self, p, o, reads):
+        """the 16 FMAs of octet o of prepared set p; reads: issue the next octet's read of pair j behind pair j"""
+        A = self.A
+        x = p["xa"] if o < 2 else p["xb"]
+        for g in range(2):
+            self.group_head()
+            for j in range(4 * g, 4 * g + 4):
+                A(f"s_waitcnt lgkmcnt({7 if reads else 7 - j})")
+                bc = f"row_newbcast:{8 * (o & 1) + j} row_mask:0xf bank_mask:0xf"
+                A(f"v_fmac_f64_dpp {r2(ACC)}, {r2(x)}, {r2(W[j])} {bc}")
+                A(f"v_fmac_f64_dpp {r2(ACC + 2)}, {r2(x)}, {r2(W[j] + 2)} {bc}")
+                if reads:
+                    A(f"ds_read_b128 v[{W[j]}:{W[j] + 3}], v{AD[j]}")
+
+    def body(self, d, L_body, L_exit):
+        """one set at ring slot d; precondition: prepared in P[d & 1], the reads of its octet 0 issued"""
+        A = self.A
+        dn = (d + 1) % 4
+        cur, nxt = P[d & 1], P[(d + 1) & 1]
+        A(f"{L_body[d]}:")
+        for o in range(3):
+            A("s_mov_b32 m0, 0")
+            self.addrs(cur, o + 1)
+            self.octet_fmas(cur, o, True)
+        L_last, L_done = self.label("last"), self.label("done")
+        A("s_mov_b32 m0, 0")
+        A(f"s_cmp_le_u32 s{S_NS}, 1")
+        A(f"s_cbranch_scc1 {L_last}")
+        self.prep(dn, nxt)
+        self.addrs(nxt, 0)
+        self.octet_fmas(cur, 3, True)
+        A(f"s_branch {L_done}")
+        A(f"{L_last}:")
+        self.octet_fmas(cur, 3, False)
+        A(f"{L_done}:")
+        A(f"s_sub_u32 s{S_NS}, s{S_NS}, 1")
+        A(f"s_cmp_eq_u32 s{S_NS}, 0")
+        A(f"s_cbranch_scc1 {L_exit[d]}")
+        if d == 3:
+            A(f"s_branch {L_body[0]}")
+
+    def chunk(self):
+        """%[ns] sets starting at ring slot %[phase]"""
+        A = self.A
+        L_body = [self.label(f"b{d}") for d in range(4)]
+        L_pro = [self.label(f"p{d}") for d in range(4)]
+        L_exit = [self.label(f"x{d}") for d in range(4)]
+        L_end = self.label("end")
+        A(f"s_mov_b64 s[{S_RP}:{S_RP + 1}], %[rp]")
+        A(f"s_mov_b64 s[{S_XP}:{S_XP + 1}], %[xp]")
+        A(f"s_mov_b32 s{S_NS}, %[ns]")
+        A(f"s_mov_b32 s{S_REM}, 0")
+        A(f"s_mov_b32 s{S_S}, -1")
+        A(f"s_mov_b32 s{S_ACC}, 0")
+        A(f"s_set_gpr_idx_on s{S_ACC}, 0")   # index mode on, no operand indexed while M0[15:12] = 0
+        A("s_mov_b32 m0, 0")
+        for d in range(1, 4):
+            A(f"s_cmp_eq_u32 %[phase], {d}")
+            A(f"s_cbranch_scc1 {L_pro[d]}")
+        for d in range(4):
+            A(f"{L_pro[d]}:")
+            self.prep(d, P[d & 1])
+            self.addrs(P[d & 1], 0)
+            for j in range(8):
+                A(f"ds_read_b128 v[{W[j]}:{W[j] + 3}], v{AD[j]}")
+            A(f"s_branch {L_body[d]}")
+        for d in range(4):
+            self.body(d, L_body, L_exit)
+        for d in range(4):
+            A(f"{L_exit[d]}:")
+            A(f"s_mov_b32 %[phase], {(d + 1) % 4}")
+            if d < 3:
+                A(f"s_branch {L_end}")
+        A(f"{L_end}:")
+        A("s_mov_b32 m0, 0")
+        A("s_set_gpr_idx_off")
+        A(f"s_mov_b64 %[rp], s[{S_RP}:{S_RP + 1}]")
+        A(f"s_mov_b64 %[xp], s[{S_XP}:{S_XP + 1}]")
+
+    def text(self):
+        return " \\\n".join(f'    "{ins}\\n\\t"' for ins in self.L)
+
+
+def main():
+    out = ["// generated by gen_acc_tiled.py -- do not edit", "#pragma once"]
+    g = Gen()
+    g.chunk()
+    out.append(f"#define ACC_TILED_CHUNK_ASM \\\n{g.text()}")
+    out.append("")
+    g = Gen()
+    g.A(f"s_mov_b64 s[{S_RP}:{S_RP + 1}], %[rp]")
+    g.A(f"s_mov_b64 s[{S_XP}:{S_XP + 1}], %[xp]")
+    for i in range(4):
+        g.refill(i)
+    g.A(f"s_mov_b64 %[rp], s[{S_RP}:{S_RP + 1}]")
+    g.A(f"s_mov_b64 %[xp], s[{S_XP}:{S_XP + 1}]")
+    out.append(f"#define ACC_TILED_RING_FILL_ASM \\\n{g.text()}")
+    out.append("")
+    g = Gen()
+    for c in range(128):
+        g.A(f"v_mov_b32 v{ACC + c}, 0")
+    out.append(f"#define ACC_TILED_ZERO_ASM \\\n{g.text()}")
+    out.append("")
+    clob = [f'"s{r}"' for r in range(S_RP, S_ACC + 1)] + ['"memory"', '"scc"']
+    out.append("#define ACC_TILED_CLOBBERS " + ", ".join(clob))
+    sys.stdout.write("\n".join(out) + "\n")
+
+
+if __name__ == "__main__":
+    main()

@@ -286,41 +286,17 @@ int sgl_tiled_mask_values(sgl_ctx* c, const DevCSC& M, DevTiled& S, uint64_t see
 // batches with ONE v_permlane16_swap per dword: rows [A0 A1 B0 B1] ->
 // [A0 A0 B0 B0] and [A1 A1 B1 B1].
 //
-// Register plan.  The 32 pairs x 2 FP64 accumulators of a wave live in
-// v[128:255], OUTSIDE the compiler's register allocation: the kernel is
-// compiled with amdgpu_num_vgpr(128) and an asm clobber of v255 makes the
-// kernel descriptor allocate all 256.  The running pair's accumulators are
-// swapped with their home registers through VGPR index mode
-// (s_set_gpr_idx_on: M0 = 4 * pair is added to the register number) only when
-// the pair changes.  Letting hipcc index a register array dynamically was tried
-// first: it either moved the array to scratch memory or copied whole
-// 32-register vectors around every slot change.
+// Register plan.  The 32 pairs x 2 FP64 accumulators of a wave live in v[128:255], OUTSIDE the compiler's register
+// allocation, and are updated IN PLACE: VGPR index mode is on inside the chunk loop and M0 (destination-relative,
+// 0x8000 | 4 * pair) selects the running pair's registers for the FMAs (gen_acc_tiled.py).  Letting hipcc index
+// a register array dynamically was tried first: it either moved the array to scratch memory or copied whole
+// 32-register vectors around every slot change.  (Rounds 1 - 2 ran the loop as compiler-scheduled C++ with the
+// running pair swapped in and out of fixed registers: same arithmetic, 3 % slower; see DESIGN.md.)
 //
-// Four statically named stream sets are in flight per wave (3 KiB), loaded by
-// inline asm right after a set is consumed and waited with a counted vmcnt
-// (loads return in order); which set is next is the wave-uniform `phase`.
-typedef double d2_t __attribute__((ext_vector_type(2)));
-#define TILED_SET_WAIT "s_waitcnt vmcnt(6)"
+// Four stream sets are in flight per wave (3 KiB), refilled right after a set is prepared and waited with a
+// counted vmcnt (loads return in order); which ring slot is next is the wave-uniform `phase`.
 
-
-template <int J>
-__device__ __forceinline__ int dpp_addr(uint32_t roff, int lane_off) {
-    int a;
-    asm("v_add_u32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(a) : "v"(roff), "v"(lane_off), "n"(J));
-    return a;
-}
-template <int J>
-__device__ __forceinline__ void dpp_fmac(double& acc, double x, double w) {
-    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(w), "n"(J));
-}
-
-__device__ __forceinline__ void acc_store(int idx4, double v0, double v1) {
-    asm volatile(
-        "s_set_gpr_idx_on %0, gpr_idx(DST)\n\tv_mov_b32 v128, %1\n\tv_mov_b32 v129, %2\n\tv_mov_b32 v130, %3\n\t"
-        "v_mov_b32 v131, %4\n\ts_set_gpr_idx_off"
-        :: "s"(idx4), "v"(__double2loint(v0)), "v"(__double2hiint(v0)), "v"(__double2loint(v1)), "v"(__double2hiint(v1))
-        : "memory");
-}
+// accumulators of pair p -> (v0, v1), for the output stage
 __device__ __forceinline__ void acc_load(int idx4, double& v0, double& v1) {
     int a, b, c, d;
     asm volatile(
@@ -331,14 +307,19 @@ __device__ __forceinline__ void acc_load(int idx4, double& v0, double& v1) {
     v1 = __hiloint2double(d, c);
 }
 
-__global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(128), amdgpu_waves_per_eu(4, 4))) void acc_tiled_kernel(
+#include "acc_tiled_gen.inc"
+
+// The chunk loop is the hand-scheduled inline asm of gen_acc_tiled.py (register plan there).  The compiler's budget
+// is v0..v63 (amdgpu_waves_per_eu(8, 8) caps its allocation at 512 / 8 registers); the clobber makes the kernel
+// descriptor allocate all 256: v64..v255 belong to the asm, whose stream ring stays in flight across compiler code.
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) void acc_tiled_kernel(
     const uint32_t* __restrict__ sroff, const double* __restrict__ sx, const int64_t* __restrict__ cstart,
     const uint8_t* __restrict__ cnt, int T, int64_t nwb, const double* __restrict__ F, int k, int TR, int64_t nrow,
     int tiles_per_range, double* __restrict__ Bout, int64_t ncol, int KS, int ldf, int ldb, int64_t slab) {
     // k = factor rows handled by this launch (a part of the rank when it is above 64), KS = LDS row
     // stride the stream's offsets were built for, ldf / ldb = strides (doubles) between rows of F /
     // columns of the output, slab = doubles between the outputs of two tile ranges (blockIdx.y)
-    asm volatile("" ::: "v255");  // make the kernel descriptor allocate 256 VGPRs
+    asm volatile("" ::: "v255");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* tile = reinterpret_cast<double*>(smem);
     const int lane = threadIdx.x & 63;
@@ -347,36 +328,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(128), amdgpu_wa
     const int t0 = blockIdx.y * tiles_per_range;
     const int t1 = (t0 + tiles_per_range < T) ? (t0 + tiles_per_range) : T;
     const bool wact = wb < nwb;
-    // LDS byte address of this lane's pair of factor rows inside a tile row (raw 32-bit LDS addresses
-    // are used below so that no per-entry base add is emitted)
     typedef __attribute__((address_space(3))) char lds_char;
-    typedef __attribute__((address_space(3))) const d2_t lds_cd2;
-    const int lane16 = (int)(uint32_t)(uintptr_t)(lds_char*)smem + (lane & 31) * 16;
+    // LDS byte address of this lane's pair of factor rows inside a tile row
+    const unsigned lane16 = (unsigned)(uintptr_t)(lds_char*)smem + (lane & 31) * 16;
+    const unsigned voff4 = lane * 4, voff8 = lane * 8;
 
-    for (int p = 0; p < TILED_NP; ++p) acc_store(4 * p, 0.0, 0.0);
+    asm volatile(ACC_TILED_ZERO_ASM ::: "memory");
 
-    int64_t pos = 0;   // stream position (entries) of the next set to LOAD
+    uint64_t rp = 0, xp = 0;   // next 64-entry set to LOAD (row offsets / values)
+    int phase = 0;
     int cnt_next = 0;
     if (wact) {
-        pos = cstart[wb * T + t0];
+        const int64_t pos = cstart[wb * T + t0];
+        const uint64_t r_ = reinterpret_cast<uint64_t>(sroff + pos), x_ = reinterpret_cast<uint64_t>(sx + pos);
+        rp = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((unsigned)(r_ >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((unsigned)r_);
+        xp = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((unsigned)(x_ >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((unsigned)x_);
         if (lane < TILED_NP) cnt_next = (int)cnt[(wb * T + t0) * TILED_NP + lane];
-    }
-    uint32_t er0 = 0, er1 = 0, er2 = 0, er3 = 0;
-    double ex0 = 0.0, ex1 = 0.0, ex2 = 0.0, ex3 = 0.0;
-#define TILED_ISSUE(ER, EX)                                                                       \
-    do {                                                                                          \
-        const uint32_t* pr_ = sroff + (pos + lane);                                               \
-        const double* px_ = sx + (pos + lane);                                                    \
-        asm volatile("global_load_dword %0, %1, off" : "=v"(ER) : "v"(pr_) : "memory");        \
-        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(EX) : "v"(px_) : "memory");      \
-        pos += 64;                                                                                \
-    } while (0)
-    int phase = 0;
-    if (wact) {
-        TILED_ISSUE(er0, ex0);
-        TILED_ISSUE(er1, ex1);
-        TILED_ISSUE(er2, ex2);
-        TILED_ISSUE(er3, ex3);
+        asm volatile(ACC_TILED_RING_FILL_ASM : [rp] "+s"(rp), [xp] "+s"(xp) : [voff4] "v"(voff4), [voff8] "v"(voff8) : ACC_TILED_CLOBBERS);
     }
 
     for (int t = t0; t < t1; ++t) {
@@ -385,7 +353,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(128), amdgpu_wa
         int tot = cntv;             // total groups of the chunk (a multiple of 8)
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off, 64);
-        int nsets = __builtin_amdgcn_readfirstlane(tot) >> 3;  // 64-entry sets (32 per half) of this chunk
+        const int nsets = __builtin_amdgcn_readfirstlane(tot) >> 3;  // 64-entry sets (32 per half) of this chunk
 
         // stage rows [t*TR, ...) of F into LDS, row stride KS doubles
         const int64_t row0 = (int64_t)t * TR;
@@ -394,10 +362,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(128), amdgpu_wa
         const double* __restrict__ src = F + row0 * ldf;
         if (KS == k && ldf == k) {
             // Each thread moves up to NRND * RST 16-byte pieces of the (contiguous) tile in NRND rounds of
-            // RST loads in flight (two rounds of ten measured faster than four of five).  The loads of the
-            // first round are issued before the barrier: they overlap the tail of the previous tile's
-            // work of the other waves.
-            constexpr int RST = 10;
+            // RST loads in flight.  The loads of the first round are issued before the barrier: they overlap
+            // the tail of the previous tile's work of the other waves.
+            constexpr int RST = 8;
             constexpr int NRND = (TILED_LDS_BYTES / 16 + RST * 64 * TILED_NW - 1) / (RST * 64 * TILED_NW);
             static_assert(NRND * RST * 64 * TILED_NW * 16 >= TILED_LDS_BYTES, "staging must cover the whole tile");
             double2 stg[RST];
@@ -444,90 +411,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(128), amdgpu_wa
             if (KS != k)
                 for (int r = (int)threadIdx.x; r < rows; r += 64 * TILED_NW) tile[r * KS + k] = 0.0;
         }
-        // hipcc's wait-count pass cannot see that the conditional staging loads above are complete on
-        // every path, and it does not see the asm stream loads at all: without this explicit wait (which
-        // it does model) it drops an s_waitcnt vmcnt(0) in front of every set of the loop below, which
-        // drains the four-set prefetch queue each time.
+        // all staging loads (and the ring loads in front of them) have landed: the asm's counted vmcnt waits see
+        // only its own eight loads in flight
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
         __syncthreads();
-        if (!wact) continue;
-
-        int s = -1, rem = 0;
-        // running accumulators of pair s: factors 2(l&31), 2(l&31)+1.  (Splitting the run over two
-        // accumulator pairs to shorten the FMA dependency chain was measured: no gain.)
-        double a0 = 0.0, a1 = 0.0;
-        // pair bookkeeping in front of every 4-entry group (wave-uniform)
-#define TILED_SLOT()                                                                              \
-    do {                                                                                          \
-        if (__builtin_expect(rem == 0, 0)) {                                                      \
-            if (s >= 0) acc_store(4 * s, a0, a1);                                                 \
-            do {                                                                                  \
-                ++s;                                                                              \
-                rem = __builtin_amdgcn_readlane(cntv, s);                                         \
-            } while (rem == 0);                                                                   \
-            acc_load(4 * s, a0, a1);                                                              \
-        }                                                                                         \
-        --rem;                                                                                    \
-    } while (0)
-#define TILED_AW(T, J, RR) \
-        const int ad##T##J##_ = dpp_addr<J>(RR, lane16); \
-        const d2_t w##T##J##_ = *(lds_cd2*)(uintptr_t)(uint32_t)ad##T##J##_;
-#define TILED_FM(T, J, XX) dpp_fmac<J>(a0, XX, w##T##J##_.x); dpp_fmac<J>(a1, XX, w##T##J##_.y);
-        // eight entry pairs (row_newbcast lanes J0 .. J7): the eight ds_read_b128 of an octet ...
-#define TILED_RD(T, J0, J1, J2, J3, J4, J5, J6, J7, RR)                                           \
-        TILED_AW(T, J0, RR) TILED_AW(T, J1, RR) TILED_AW(T, J2, RR) TILED_AW(T, J3, RR)           \
-        TILED_AW(T, J4, RR) TILED_AW(T, J5, RR) TILED_AW(T, J6, RR) TILED_AW(T, J7, RR)
-        // ... and its sixteen FMAs, with the pair bookkeeping in front of each 4-entry group
-#define TILED_FMS(T, J0, J1, J2, J3, J4, J5, J6, J7, XX)                                          \
-        TILED_SLOT();                                                                             \
-        TILED_FM(T, J0, XX) TILED_FM(T, J1, XX) TILED_FM(T, J2, XX) TILED_FM(T, J3, XX)           \
-        TILED_SLOT();                                                                             \
-        TILED_FM(T, J4, XX) TILED_FM(T, J5, XX) TILED_FM(T, J6, XX) TILED_FM(T, J7, XX)
-        // The set's two loads are complete once at most the six younger ones (the three other sets)
-        // remain; the set registers pass THROUGH the wait so that no consumer can be scheduled above it.
-        // The four octets of a set are software-pipelined: the LDS reads of octet i+1 are issued before
-        // the FMAs of octet i (with 2 waves per SIMD, un-pipelined reads and FMAs were measured at 51 %
-        // LDS / 50 % VALU busy, i.e. running one after the other).
-#define TILED_SET(ER, EX)                                                                         \
-    do {                                                                                          \
-        asm volatile(TILED_SET_WAIT : "+v"(ER), "+v"(EX) : : "memory");                               \
-        const unsigned rv_ = ER;                                                                  \
-        const unsigned xl_ = (unsigned)__double2loint(EX), xh_ = (unsigned)__double2hiint(EX);    \
-        const auto pr2_ = __builtin_amdgcn_permlane16_swap(rv_, rv_, false, false);               \
-        const auto pl2_ = __builtin_amdgcn_permlane16_swap(xl_, xl_, false, false);               \
-        const auto ph2_ = __builtin_amdgcn_permlane16_swap(xh_, xh_, false, false);               \
-        TILED_ISSUE(ER, EX); /* refill this set with the 64 entries four sets ahead */            \
-        unsigned ra_ = pr2_[0], rb_ = pr2_[1];                                                    \
-        double xa_ = __hiloint2double((int)ph2_[0], (int)pl2_[0]);                                \
-        double xb_ = __hiloint2double((int)ph2_[1], (int)pl2_[1]);                                \
-        /* DPP hazard: a VALU write of a register (the swaps / pair-forming moves above) must be two  \
-           wait states ahead of a DPP read of it, and hipcc pads nothing around inline asm */      \
-        asm volatile("s_nop 1" : "+v"(ra_), "+v"(rb_), "+v"(xa_), "+v"(xb_));                      \
-        TILED_RD(p, 0, 1, 2, 3, 4, 5, 6, 7, ra_)                                                  \
-        TILED_RD(q, 8, 9, 10, 11, 12, 13, 14, 15, ra_)                                            \
-        TILED_FMS(p, 0, 1, 2, 3, 4, 5, 6, 7, xa_)                                                 \
-        TILED_RD(r, 0, 1, 2, 3, 4, 5, 6, 7, rb_)                                                  \
-        TILED_FMS(q, 8, 9, 10, 11, 12, 13, 14, 15, xa_)                                           \
-        TILED_RD(u, 8, 9, 10, 11, 12, 13, 14, 15, rb_)                                            \
-        TILED_FMS(r, 0, 1, 2, 3, 4, 5, 6, 7, xb_)                                                 \
-        TILED_FMS(u, 8, 9, 10, 11, 12, 13, 14, 15, xb_)                                           \
-    } while (0)
-        while (nsets > 0) {
-            if (phase == 0) { TILED_SET(er0, ex0); phase = 1; if (--nsets == 0) break; }
-            if (phase == 1) { TILED_SET(er1, ex1); phase = 2; if (--nsets == 0) break; }
-            if (phase == 2) { TILED_SET(er2, ex2); phase = 3; if (--nsets == 0) break; }
-            if (phase == 3) { TILED_SET(er3, ex3); phase = 0; --nsets; }
+        if (wact && nsets > 0) {
+            asm volatile(ACC_TILED_CHUNK_ASM
+                         : [rp] "+s"(rp), [xp] "+s"(xp), [phase] "+s"(phase)
+                         : [ns] "s"(nsets), [cnt] "v"(cntv), [lane16] "v"(lane16), [voff4] "v"(voff4), [voff8] "v"(voff8)
+                         : ACC_TILED_CLOBBERS);
         }
-        if (s >= 0) acc_store(4 * s, a0, a1);
     }
-    // Up to four refills (issued past the end of this wave's range, into the stream's slack) are
-    // still in flight and WILL write the set registers when they land.  Drain them with the registers
-    // passed through the wait: otherwise hipcc, which knows nothing of the pending writes, reuses
-    // v1 / v68.. for the output addressing below and a late (HBM-latency) return overwrites them.
-    asm volatile("s_waitcnt vmcnt(0)"
-                 : "+v"(er0), "+v"(er1), "+v"(er2), "+v"(er3), "+v"(ex0), "+v"(ex1), "+v"(ex2), "+v"(ex3)
-                 :
-                 : "memory");
+    // Up to four refills (issued past the end of this wave's range, into the stream's slack) are still in flight;
+    // they write the ring registers v64..v75 only, which nothing below touches
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (wact) {
         double* out = Bout + (size_t)blockIdx.y * (size_t)slab;
         const int f = 2 * (lane & 31);

@@ -1,9 +1,11 @@
 """Static checks of the tiled accumulate's generated code (no GPU needed: hipcc cross-compiles).
 
-acc_tiled_kernel keeps its 64 FP64 accumulator pairs in v[128:255], outside hipcc's register
-allocation, addressed from inline asm through VGPR index mode.  That is only sound while the compiler
-itself never allocates a register at or above v128 and never spills: both are properties of a
-particular hipcc, so they are asserted on the assembly this toolchain emits."""
+acc_tiled_kernel keeps its 64 FP64 accumulator pairs in v[128:255] and the working set of its generated
+chunk loop (gen_acc_tiled.py: stream ring, prepared sets, LDS addresses, factor quads) in v[64:127], all
+outside hipcc's register allocation; the ring's loads stay in flight across compiler code.  That is only
+sound while the compiler itself never allocates a register at or above v64 and keeps scratch out of the
+tile loop: both are properties of a particular hipcc, so they are asserted on the assembly this toolchain
+emits."""
 import os
 import re
 import subprocess
@@ -20,6 +22,7 @@ def tiled_asm(tmp_path_factory):
     if not os.path.exists(HIPCC):
         pytest.skip("hipcc not installed")
     out = str(tmp_path_factory.mktemp("asm") / "kernels_tiled.s")
+    subprocess.run(["make", "-C", os.path.dirname(SRC), "acc_tiled_gen.inc"], check=True, capture_output=True, timeout=120)
     subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-S",
                     "--cuda-device-only", "-o", out, SRC], check=True, capture_output=True, timeout=600)
     text = open(out).read()
@@ -38,7 +41,7 @@ def _vregs(line):
     return regs
 
 
-def test_compiler_stays_below_v128_and_never_spills(tiled_asm):
+def test_compiler_stays_below_v64_and_keeps_scratch_out_of_the_loop(tiled_asm):
     body, meta = tiled_asm
     in_asm, worst = False, -1
     for line in body.splitlines():
@@ -54,28 +57,35 @@ def test_compiler_stays_below_v128_and_never_spills(tiled_asm):
         r = _vregs(code)
         if r:
             worst = max(worst, max(r))
-    assert 0 <= worst < 128, "hipcc allocated v%d: the asm-managed accumulators v[128:255] would be clobbered" % worst
+    assert 0 <= worst < 64, "hipcc allocated v%d: the asm-owned registers v[64:255] would be clobbered" % worst
     assert re.search(r"\.amdhsa_next_free_vgpr 256\b", meta), "the kernel descriptor must allocate all 256 VGPRs"
-    # a few loop-invariant 64-bit values may be parked in scratch around the tile loop, but nothing
-    # inside the per-set loop (between the first and the last counted stream wait) may touch scratch
+    # a few loop-invariant values may be parked in scratch around the tile loop; the chunk loop itself is asm
     m = re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", meta)
     assert m and int(m.group(1)) <= 64, "acc_tiled_kernel spills %s bytes per lane" % (m.group(1) if m else "?")
-    lines = body.splitlines()
-    waits = [n for n, l in enumerate(lines) if "s_waitcnt vmcnt(6)" in l]
-    hot = lines[waits[0]:waits[-1] + 400]
-    assert not [l for l in hot if "scratch_" in l or "buffer_store" in l or "buffer_load" in l], "scratch access in the set loop"
 
 
-def test_no_compiler_wait_drains_the_stream_prefetch(tiled_asm):
-    """Inside the set loop only the counted asm wait (vmcnt(6)) may appear: a compiler-inserted
-    s_waitcnt vmcnt(0) there would drain the four-set prefetch queue on every set."""
+def test_chunk_loop_is_the_generated_asm_with_counted_waits(tiled_asm):
+    """The chunk loop must be the generated block: four ring-slot bodies + four prologues, each preparing a set behind
+    the counted stream wait vmcnt(6); inside the block no full drain of the LDS queue except the last octet of a
+    chunk (lgkmcnt(0) appears only as the 7 - j countdown's last step, once per body), and no vmcnt(0)."""
     body, _ = tiled_asm
-    lines = body.splitlines()
-    idx = [n for n, l in enumerate(lines) if "s_waitcnt vmcnt(6)" in l]
-    assert len(idx) == 4, "expected the four phase copies of the set body"
-    for a, b in zip(idx, idx[1:]):
-        seg = [l for l in lines[a + 1:b] if "s_waitcnt" in l and "vmcnt" in l]
-        assert not seg, "compiler vmcnt wait inside a set: %r" % seg[:2]
+    blocks = re.findall(r"#ASMSTART(.*?)#ASMEND", body, re.S)
+    chunk = [b for b in blocks if "v_fmac_f64_dpp" in b]
+    assert len(chunk) == 1, "expected exactly one asm block with the FMAs"
+    text = chunk[0]
+    assert text.count("s_waitcnt vmcnt(6)") == 8          # 4 prologues + 4 in-loop preparations
+    assert "vmcnt(0)" not in text
+    assert text.count("s_waitcnt lgkmcnt(0)") == 4         # pair 7 of the no-prefetch last octet, per ring slot
+    assert text.count("v_fmac_f64_dpp") == 4 * (4 + 1) * 16  # 4 bodies x (4 octets + the no-prefetch copy of the last) x 16
+    assert text.count("ds_read_b128") == 4 * 8 + 4 * 4 * 8  # prologues + one read behind every prefetching pair
+    # M0 is cleared before every burst of address adds (their destinations must not be indexed)
+    lines = [l.strip() for l in text.splitlines() if l.strip()]
+    m0 = None
+    for l in lines:
+        if l.startswith("s_mov_b32 m0"):
+            m0 = l.split(",")[1].strip()
+        elif l.startswith(("v_add_u32_dpp", "v_mov_b32", "v_permlane16_swap")):
+            assert m0 == "0", "VALU with a vector destination while M0 indexes destinations: %s" % l
 
 
 def _dst_src0(code):
