@@ -7,6 +7,7 @@
 // All modes read one row per half-wave (conflict-free).
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include "mix3_gen.inc"
 
 #define CLOB "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "memory"
@@ -20,7 +21,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     const int lane = threadIdx.x & 63;
     const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     const unsigned lane16 = base + (lane & 31) * 16;
-    const unsigned ro = (((threadIdx.x >> 5) * 400 * 9) & 0x3ff0);   // one row per half-wave: conflict-free, like the kernel's reads
+    const unsigned ro = ((((lane & 15) * 53 + (threadIdx.x >> 6) * 7 + (lane >> 5) * 29) % 340) * 400);   // like the kernel: every entry pair its own two rows (one per half-wave), conflict-free
     const double x = 1.0 + 1e-9 * lane;
     asm volatile(MIX3_INIT ::: "memory");
     asm volatile("v_add_u32 v40, %0, %1\n v_add_u32 v41, 400, v40\n v_add_u32 v42, 800, v40\n v_add_u32 v43, 1200, v40\n"
@@ -53,9 +54,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
 }
 
 template <int MODE>
-void run(const char* name, int threads) {
+void run(const char* name, int threads, int iters = 10000) {
     double* out; hipMalloc(&out, 256 * 1024 * 8);
-    const int iters = 10000;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipFuncSetAttribute((const void*)kern<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 140000);
     kern<MODE><<<256, threads, 140000>>>(out, 100);
@@ -66,7 +66,12 @@ void run(const char* name, int threads) {
     printf("%-34s waves/CU=%2d: %7.1f ns per octet round (8 reads / 16 FMAs per wave)\n", name, threads / 64, ms * 1e6 / iters / 2);
     hipFree(out);
 }
-int main() {
+int main(int argc, char** argv) {
+    if (argc > 1) {   // sustained run of the kernel-like modes: does the rate hold over ~1 s (clocks under load)?
+        const int it = atoi(argv[1]);
+        for (int rep = 0; rep < 3; ++rep) { run<7>("7 sustained", 512, it); run<11>("11 sustained", 512, it); }
+        return 0;
+    }
     for (int th : {256, 512, 768}) {
         run<1>("1 reads only", th); run<2>("2 dpp FMAs only", th); run<3>("3 reads + dpp FMAs", th); run<4>("4 plain FMAs only", th);
         run<5>("5 reads + plain FMAs", th); run<6>("6 reads + sgpr-x FMAs", th); run<7>("7 dpp adds + reads + dpp FMAs", th);

@@ -11,19 +11,19 @@ Same entry stream, same arithmetic and the same order of operations as the compi
     per set;
   * the accumulators of the 32 column pairs stay IN PLACE in v[128:255]: VGPR index mode is on for the whole
     loop and M0 (destination-relative, 0x8000 | 4 * pair) is written before each group of FMAs and cleared before
-    the address adds -- a pair switch is three scalar instructions and a v_readlane instead of eight moves through
-    s_set_gpr_idx_on / off;
+    the address adds -- a pair switch is a dozen scalar instructions on a byte queue instead of eight moves through
+    s_set_gpr_idx_on / off plus a v_readlane;
   * the next set is prepared (three v_permlane16_swap, stream refill) inside the last octet of the running one.
 
 Stream (kernels_tiled.hip): sets of 64 entries = 32 of the A half, 32 of the B half; row offsets u32, values f64;
-cnt[pair] = groups of 4 entry pairs of that column pair in the chunk.
+cnt[pair] = groups of 4 entry pairs of that column pair in the chunk (32 bytes per chunk, handed over in SGPRs).
 
 Register plan (asm-owned; the compiler is capped at v0..v63 by amdgpu_waves_per_eu(8, 8)):
     v64..67 row-offset ring, v68..75 value ring (4 sets in flight, counted vmcnt)
     v76..81 / v82..87 prepared set (ra, rb, xa, xb), two copies   v88..95 LDS addresses   v96..127 8 factor quads
     v128..255 accumulators (pair p: v[128 + 4p : 131 + 4p])
     s[84:85] / s[86:87] next set to load (row offsets / values), s88 sets left, s89 groups left of the running
-    pair, s90 running pair, s91 its M0 word
+    pair, s90 running pair, s91 its M0 word, s[92:99] the chunk's group counts
 """
 import sys
 
@@ -33,7 +33,8 @@ P = [{"ra": 76 + 6 * b, "rb": 77 + 6 * b, "xa": 78 + 6 * b, "xb": 80 + 6 * b} fo
 AD = [88 + j for j in range(8)]
 W = [96 + 4 * j for j in range(8)]
 ACC = 128
-S_RP, S_XP, S_NS, S_REM, S_S, S_ACC = 84, 86, 88, 89, 90, 91
+S_RP, S_XP, S_NS, S_REM, S_S, S_ACC, S_T = 84, 86, 88, 89, 90, 91, 83
+S_Q = 92   # s[92:99]: the chunk's 32 group counts (one byte per column pair), consumed as a shift queue
 
 
 def r2(b):
@@ -43,6 +44,8 @@ def r2(b):
 class Gen:
     def __init__(self):
         self.L = []
+        self.cold = []
+        self.cold2 = []
         self.lab = 0
 
     def A(self, s):
@@ -53,13 +56,17 @@ class Gen:
         return f".Ltiled_{stem}_{self.lab}_%="
 
     def refill(self, i):
+        """ring slot i <- the set four ahead of the one it held.  s[S_RP] / s[S_XP] point at the set that goes into
+        slot 0 of the current lap; slots are refilled in the order 0, 1, 2, 3, so the pointers advance once per lap
+        (after slot 3) and the slot is an immediate offset: 2 loads per set, 4 scalar instructions per FOUR sets."""
         A = self.A
-        A(f"global_load_dword v{ER[i]}, %[voff4], s[{S_RP}:{S_RP + 1}]")
-        A(f"global_load_dwordx2 {r2(EX[i])}, %[voff8], s[{S_XP}:{S_XP + 1}]")
-        A(f"s_add_u32 s{S_RP}, s{S_RP}, 256")
-        A(f"s_addc_u32 s{S_RP + 1}, s{S_RP + 1}, 0")
-        A(f"s_add_u32 s{S_XP}, s{S_XP}, 512")
-        A(f"s_addc_u32 s{S_XP + 1}, s{S_XP + 1}, 0")
+        A(f"global_load_dword v{ER[i]}, %[voff4], s[{S_RP}:{S_RP + 1}] offset:{256 * i}")
+        A(f"global_load_dwordx2 {r2(EX[i])}, %[voff8], s[{S_XP}:{S_XP + 1}] offset:{512 * i}")
+        if i == 3:
+            A(f"s_add_u32 s{S_RP}, s{S_RP}, 1024")
+            A(f"s_addc_u32 s{S_RP + 1}, s{S_RP + 1}, 0")
+            A(f"s_add_u32 s{S_XP}, s{S_XP}, 2048")
+            A(f"s_addc_u32 s{S_XP + 1}, s{S_XP + 1}, 0")
 
     def prep(self, i, p):
         """ring slot i -> prepared set p: rows [A0 A1 B0 B1] -> ra = [A0 A0 B0 B0], rb = [A1 A1 B1 B1] (same for x),
@@ -85,22 +92,34 @@ class Gen:
             self.A(f"v_add_u32_dpp v{AD[j]}, v{r}, %[lane16] row_newbcast:{8 * (o & 1) + j} row_mask:0xf bank_mask:0xf")
 
     def group_head(self):
-        """before a group of 4 entry pairs: count the running pair's groups down, move on to the next pair that has
-        any when they are used up (cnt in lanes 0..31 of %[cnt]); then point M0 at the pair's accumulators"""
+        """before a group of 4 entry pairs: count the running pair's groups down; when they are used up take the next
+        pair that has any -- its count is the low byte of the queue s[S_Q:S_Q+7] (32 bytes, shifted down one byte per
+        pair, the next 64-bit word moved in after every eighth) -- and point M0 at its accumulators.  All scalar: a
+        v_readlane here cost ~200 cycles per switch (the SALU waits for the VALU to drain)."""
         A = self.A
-        L_next, L_go = self.label("nx"), self.label("go")
+        L_sw, L_next, L_norot, L_go = self.label("sw"), self.label("nx"), self.label("nr"), self.label("go")
         A(f"s_sub_u32 s{S_REM}, s{S_REM}, 1")
-        A(f"s_cbranch_scc0 {L_go}")
-        A(f"{L_next}:")
-        A(f"s_add_u32 s{S_S}, s{S_S}, 1")
-        A(f"v_readlane_b32 s{S_REM}, %[cnt], s{S_S}")
-        A(f"s_cmp_eq_u32 s{S_REM}, 0")
-        A(f"s_cbranch_scc1 {L_next}")
-        A(f"s_sub_u32 s{S_REM}, s{S_REM}, 1")
-        A(f"s_lshl_b32 s{S_ACC}, s{S_S}, 2")
-        A(f"s_or_b32 s{S_ACC}, s{S_ACC}, 0x8000")
+        A(f"s_cbranch_scc1 {L_sw}")          # rare: the common path falls through (a taken branch per group cost ~10 %)
         A(f"{L_go}:")
         A(f"s_mov_b32 m0, s{S_ACC}")
+        B = self.cold.append                  # out of line, behind the loop
+        B(f"{L_sw}:")
+        B(f"{L_next}:")
+        B(f"s_and_b32 s{S_REM}, s{S_Q}, 0xff")
+        B(f"s_lshr_b64 s[{S_Q}:{S_Q + 1}], s[{S_Q}:{S_Q + 1}], 8")
+        B(f"s_add_u32 s{S_S}, s{S_S}, 1")
+        B(f"s_and_b32 s{S_T}, s{S_S}, 7")
+        B(f"s_cmp_eq_u32 s{S_T}, 7")
+        B(f"s_cbranch_scc0 {L_norot}")
+        for w in range(3):
+            B(f"s_mov_b64 s[{S_Q + 2 * w}:{S_Q + 2 * w + 1}], s[{S_Q + 2 * w + 2}:{S_Q + 2 * w + 3}]")
+        B(f"{L_norot}:")
+        B(f"s_cmp_eq_u32 s{S_REM}, 0")
+        B(f"s_cbranch_scc1 {L_next}")
+        B(f"s_sub_u32 s{S_REM}, s{S_REM}, 1")
+        B(f"s_lshl_b32 s{S_ACC}, s{S_S}, 2")
+        B(f"s_or_b32 s{S_ACC}, s{S_ACC}, 0x8000")
+        B(f"s_branch {L_go}")
 
     def octet_fmas(self, p, o, reads):
         """the 16 FMAs of octet o of prepared set p; reads: issue the next octet's read of pair j behind pair j"""
@@ -108,8 +127,10 @@ class Gen:
         x = p["xa"] if o < 2 else p["xb"]
         for g in range(2):
             self.group_head()
+            # ONE wait per group: with at most 4 reads outstanding behind them, the four quads of this group have
+            # landed (every instruction, s_waitcnt included, takes an issue slot of the wave: ~5 cycles)
+            A(f"s_waitcnt lgkmcnt({4 if reads else 4 - 4 * g})")
             for j in range(4 * g, 4 * g + 4):
-                A(f"s_waitcnt lgkmcnt({7 if reads else 7 - j})")
                 bc = f"row_newbcast:{8 * (o & 1) + j} row_mask:0xf bank_mask:0xf"
                 A(f"v_fmac_f64_dpp {r2(ACC)}, {r2(x)}, {r2(W[j])} {bc}")
                 A(f"v_fmac_f64_dpp {r2(ACC + 2)}, {r2(x)}, {r2(W[j] + 2)} {bc}")
@@ -133,10 +154,14 @@ class Gen:
         self.prep(dn, nxt)
         self.addrs(nxt, 0)
         self.octet_fmas(cur, 3, True)
-        A(f"s_branch {L_done}")
+        A(f"{L_done}:")
+        # the chunk's last octet (nothing to fetch ahead) lives out of line
+        hot, self.L = self.L, []
         A(f"{L_last}:")
         self.octet_fmas(cur, 3, False)
-        A(f"{L_done}:")
+        A(f"s_branch {L_done}")
+        self.cold2 += self.L
+        self.L = hot
         A(f"s_sub_u32 s{S_NS}, s{S_NS}, 1")
         A(f"s_cmp_eq_u32 s{S_NS}, 0")
         A(f"s_cbranch_scc1 {L_exit[d]}")
@@ -153,6 +178,8 @@ class Gen:
         A(f"s_mov_b64 s[{S_RP}:{S_RP + 1}], %[rp]")
         A(f"s_mov_b64 s[{S_XP}:{S_XP + 1}], %[xp]")
         A(f"s_mov_b32 s{S_NS}, %[ns]")
+        for w in range(4):
+            A(f"s_mov_b64 s[{S_Q + 2 * w}:{S_Q + 2 * w + 1}], %[q{w}]")
         A(f"s_mov_b32 s{S_REM}, 0")
         A(f"s_mov_b32 s{S_S}, -1")
         A(f"s_mov_b32 s{S_ACC}, 0")
@@ -175,6 +202,8 @@ class Gen:
             A(f"s_mov_b32 %[phase], {(d + 1) % 4}")
             if d < 3:
                 A(f"s_branch {L_end}")
+        A(f"s_branch {L_end}")
+        self.L += self.cold2 + self.cold   # last octets of a chunk, pair switches
         A(f"{L_end}:")
         A("s_mov_b32 m0, 0")
         A("s_set_gpr_idx_off")
@@ -205,7 +234,7 @@ def main():
         g.A(f"v_mov_b32 v{ACC + c}, 0")
     out.append(f"#define ACC_TILED_ZERO_ASM \\\n{g.text()}")
     out.append("")
-    clob = [f'"s{r}"' for r in range(S_RP, S_ACC + 1)] + ['"memory"', '"scc"']
+    clob = [f'"s{r}"' for r in range(S_T, S_Q + 8)] + ['"memory"', '"scc"']
     out.append("#define ACC_TILED_CLOBBERS " + ", ".join(clob))
     sys.stdout.write("\n".join(out) + "\n")
 

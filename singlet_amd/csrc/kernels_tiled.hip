@@ -337,23 +337,31 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 
     uint64_t rp = 0, xp = 0;   // next 64-entry set to LOAD (row offsets / values)
     int phase = 0;
-    int cnt_next = 0;
+    // group counts of the next chunk (32 bytes = one per column pair) and its size, read on the scalar side one
+    // tile ahead: wb is wave-uniform
+    uint64_t qn0 = 0, qn1 = 0, qn2 = 0, qn3 = 0;
+    int64_t pos_next = 0;
     if (wact) {
         const int64_t pos = cstart[wb * T + t0];
+        pos_next = cstart[wb * T + t0 + 1];
+        const uint64_t* cq = reinterpret_cast<const uint64_t*>(cnt + (wb * T + t0) * TILED_NP);
+        qn0 = cq[0]; qn1 = cq[1]; qn2 = cq[2]; qn3 = cq[3];
         const uint64_t r_ = reinterpret_cast<uint64_t>(sroff + pos), x_ = reinterpret_cast<uint64_t>(sx + pos);
         rp = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((unsigned)(r_ >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((unsigned)r_);
         xp = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((unsigned)(x_ >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((unsigned)x_);
-        if (lane < TILED_NP) cnt_next = (int)cnt[(wb * T + t0) * TILED_NP + lane];
         asm volatile(ACC_TILED_RING_FILL_ASM : [rp] "+s"(rp), [xp] "+s"(xp) : [voff4] "v"(voff4), [voff8] "v"(voff8) : ACC_TILED_CLOBBERS);
     }
 
+    int64_t pos_cur = wact ? cstart[wb * T + t0] : 0;
     for (int t = t0; t < t1; ++t) {
-        const int cntv = cnt_next;  // lane p < 32: 4-entry groups of pair p in this tile
-        if (wact && t + 1 < t1 && lane < TILED_NP) cnt_next = (int)cnt[(wb * T + t + 1) * TILED_NP + lane];
-        int tot = cntv;             // total groups of the chunk (a multiple of 8)
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off, 64);
-        const int nsets = __builtin_amdgcn_readfirstlane(tot) >> 3;  // 64-entry sets (32 per half) of this chunk
+        const uint64_t q0 = qn0, q1 = qn1, q2 = qn2, q3 = qn3;
+        const int nsets = (int)((pos_next - pos_cur) >> 6);  // 64-entry sets (32 per half) of this chunk
+        pos_cur = pos_next;
+        if (wact && t + 1 < t1) {
+            const uint64_t* cq = reinterpret_cast<const uint64_t*>(cnt + (wb * T + t + 1) * TILED_NP);
+            qn0 = cq[0]; qn1 = cq[1]; qn2 = cq[2]; qn3 = cq[3];
+            pos_next = cstart[wb * T + t + 2];
+        }
 
         // stage rows [t*TR, ...) of F into LDS, row stride KS doubles
         const int64_t row0 = (int64_t)t * TR;
@@ -418,7 +426,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         if (wact && nsets > 0) {
             asm volatile(ACC_TILED_CHUNK_ASM
                          : [rp] "+s"(rp), [xp] "+s"(xp), [phase] "+s"(phase)
-                         : [ns] "s"(nsets), [cnt] "v"(cntv), [lane16] "v"(lane16), [voff4] "v"(voff4), [voff8] "v"(voff8)
+                         : [ns] "s"(nsets), [q0] "s"(q0), [q1] "s"(q1), [q2] "s"(q2), [q3] "s"(q3), [lane16] "v"(lane16),
+                           [voff4] "v"(voff4), [voff8] "v"(voff8)
                          : ACC_TILED_CLOBBERS);
         }
     }

@@ -66,8 +66,8 @@ def test_compiler_stays_below_v64_and_keeps_scratch_out_of_the_loop(tiled_asm):
 
 def test_chunk_loop_is_the_generated_asm_with_counted_waits(tiled_asm):
     """The chunk loop must be the generated block: four ring-slot bodies + four prologues, each preparing a set behind
-    the counted stream wait vmcnt(6); inside the block no full drain of the LDS queue except the last octet of a
-    chunk (lgkmcnt(0) appears only as the 7 - j countdown's last step, once per body), and no vmcnt(0)."""
+    the counted stream wait vmcnt(6); one counted LDS wait per group of four entry pairs (a full drain only in front
+    of the last group of a chunk), no vmcnt(0); vector destinations are only written while M0 indexes nothing."""
     body, _ = tiled_asm
     blocks = re.findall(r"#ASMSTART(.*?)#ASMEND", body, re.S)
     chunk = [b for b in blocks if "v_fmac_f64_dpp" in b]
@@ -75,15 +75,19 @@ def test_chunk_loop_is_the_generated_asm_with_counted_waits(tiled_asm):
     text = chunk[0]
     assert text.count("s_waitcnt vmcnt(6)") == 8          # 4 prologues + 4 in-loop preparations
     assert "vmcnt(0)" not in text
-    assert text.count("s_waitcnt lgkmcnt(0)") == 4         # pair 7 of the no-prefetch last octet, per ring slot
     assert text.count("v_fmac_f64_dpp") == 4 * (4 + 1) * 16  # 4 bodies x (4 octets + the no-prefetch copy of the last) x 16
     assert text.count("ds_read_b128") == 4 * 8 + 4 * 4 * 8  # prologues + one read behind every prefetching pair
-    # M0 is cleared before every burst of address adds (their destinations must not be indexed)
-    lines = [l.strip() for l in text.splitlines() if l.strip()]
+    assert text.count("s_waitcnt lgkmcnt(4)") == 4 * (4 * 2 + 1) and text.count("s_waitcnt lgkmcnt(0)") == 4
+    assert "v_readlane" not in text                       # pair switches are scalar (byte queue in SGPRs)
+    # walk the block in program order: the cold section (last octets, pair switches) sits behind the loop and is
+    # entered / left by branches, so the linear M0 state only holds for the hot part
+    hot = text[:text.index("s_set_gpr_idx_off")]
     m0 = None
-    for l in lines:
+    for l in (x.strip() for x in hot.splitlines()):
         if l.startswith("s_mov_b32 m0"):
             m0 = l.split(",")[1].strip()
+        elif l.startswith(".Ltiled_last") or l.startswith(".Ltiled_sw"):
+            m0 = "cold"    # out-of-line code: FMAs behind a group head, no vector-destination VALU besides them
         elif l.startswith(("v_add_u32_dpp", "v_mov_b32", "v_permlane16_swap")):
             assert m0 == "0", "VALU with a vector destination while M0 indexes destinations: %s" % l
 
