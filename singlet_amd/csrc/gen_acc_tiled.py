@@ -91,7 +91,7 @@ class Gen:
         for j in range(8):
             self.A(f"v_add_u32_dpp v{AD[j]}, v{r}, %[lane16] row_newbcast:{8 * (o & 1) + j} row_mask:0xf bank_mask:0xf")
 
-    def group_head(self):
+    def group_head(self, set_m0=True):
         """before a group of 4 entry pairs: count the running pair's groups down; when they are used up take the next
         pair that has any -- its count is the low byte of the queue s[S_Q:S_Q+7] (32 bytes, shifted down one byte per
         pair, the next 64-bit word moved in after every eighth) -- and point M0 at its accumulators.  All scalar: a
@@ -100,8 +100,11 @@ class Gen:
         L_sw, L_next, L_norot, L_go = self.label("sw"), self.label("nx"), self.label("nr"), self.label("go")
         A(f"s_sub_u32 s{S_REM}, s{S_REM}, 1")
         A(f"s_cbranch_scc1 {L_sw}")          # rare: the common path falls through (a taken branch per group cost ~10 %)
-        A(f"{L_go}:")
-        A(f"s_mov_b32 m0, s{S_ACC}")
+        if set_m0:
+            A(f"{L_go}:")
+            A(f"s_mov_b32 m0, s{S_ACC}")
+        else:   # M0 still holds the running pair's word from the octet's first group: only a switch has to write it
+            A(f"{L_go}:")
         B = self.cold.append                  # out of line, behind the loop
         B(f"{L_sw}:")
         B(f"{L_next}:")
@@ -119,6 +122,8 @@ class Gen:
         B(f"s_sub_u32 s{S_REM}, s{S_REM}, 1")
         B(f"s_lshl_b32 s{S_ACC}, s{S_S}, 2")
         B(f"s_or_b32 s{S_ACC}, s{S_ACC}, 0x8000")
+        if not set_m0:
+            B(f"s_mov_b32 m0, s{S_ACC}")
         B(f"s_branch {L_go}")
 
     def octet_fmas(self, p, o, reads):
@@ -126,7 +131,7 @@ class Gen:
         A = self.A
         x = p["xa"] if o < 2 else p["xb"]
         for g in range(2):
-            self.group_head()
+            self.group_head(set_m0=(g == 0))
             # ONE wait per group: with at most 4 reads outstanding behind them, the four quads of this group have
             # landed (every instruction, s_waitcnt included, takes an issue slot of the wave: ~5 cycles)
             A(f"s_waitcnt lgkmcnt({4 if reads else 4 - 4 * g})")
