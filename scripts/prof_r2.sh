@@ -5,7 +5,7 @@
 #     (FP64 MFMA op count + MFMA busy cycles: the Gram kernels)                   -> r2_pmc_*.csv
 #  3. a masked (c_ard_nmf) iteration at 30 000 genes x 200 000 cells, k = 50: kernel stats, FETCH / WRITE and
 #     the matrix-core set (mask_gram_mfma_kernel)                                  -> r2_ard_*.csv
-# Summaries land in gpurun_out/; copy the ones to keep into profiles/.  `prof_r2.sh ard` runs part 3 only.
+# Summaries land in gpurun_out/; copy the ones to keep into profiles/.  `prof_r2.sh ard` runs part 3 only, `prof_r2.sh main` parts 1 - 2.
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=gpurun_out
@@ -33,6 +33,7 @@ run_pmc r2_pmc_sq_cycles "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST
 run_pmc r2_pmc_sq_insts "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM" $BENCH
 run_pmc r2_pmc_mfma "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" $BENCH
 fi
+if [ "$1" == "main" ]; then head -12 $O/r2_kernel_stats.csv; grep acc_tiled $O/r2_pmc_fetch_size.csv $O/r2_pmc_write_size.csv; exit 0; fi
 ARD="python3 scripts/ard_rate.py 200000 30000 50 2"
 run_stats r2_ard_kernel_stats $ARD
 run_pmc r2_ard_pmc_fetch_size "FETCH_SIZE" $ARD

@@ -13,7 +13,7 @@
 #define CLOB "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "memory"
 template <int MODE>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) void kern(double* out, int iters) {
-    asm volatile("" ::: "v145");
+    asm volatile("" ::: "v255");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* t = (double*)smem;
     for (int e = threadIdx.x; e < 16384; e += blockDim.x) t[e] = 1.0 + e * 1e-6;
@@ -32,7 +32,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     const double* gp = (const double*)(((uintptr_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(gpu_ >> 32)) << 32) |
                                        (uintptr_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)gpu_));
     asm volatile("s_mov_b32 s42, 0x7fffffff\n s_mov_b32 s43, 0x8000" ::: "s42", "s43");
-    if (MODE == 11) asm volatile("s_mov_b32 m0, 0\n s_set_gpr_idx_on m0, 0\n s_mov_b32 m0, 0" ::: "memory");
+    if (MODE == 11 || MODE == 12) asm volatile("s_mov_b32 m0, 0\n s_set_gpr_idx_on m0, 0\n s_mov_b32 m0, 0" ::: "memory");
     const int iters2 = (MODE >= 10) ? iters / 2 : iters;   // a set = four octets = two "rounds" of the other modes
     for (int it = 0; it < iters2; ++it) {
         if (MODE == 1) asm volatile(MIX3_BODY_1 :: [x] "v"(x), [ro] "v"(ro), [lane16] "v"(lane16) : "memory");
@@ -45,9 +45,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         if (MODE == 8) asm volatile(MIX3_BODY_8 :: [x] "v"(x), [ro] "v"(ro), [lane16] "v"(lane16) : "memory");
         if (MODE == 9) asm volatile(MIX3_BODY_9 :: [x] "v"(x), [ro] "v"(ro), [lane16] "v"(lane16) : "memory");
         if (MODE == 10) asm volatile(MIX3_BODY_10 :: [x] "v"(x), [ro] "v"(ro), [lane16] "v"(lane16), [goff] "v"(goff), [gp] "s"(gp) : "memory", "scc", "s42", "s43", "v32", "v33", "v34", "v35", "v36", "v37", "v38");
+        if (MODE == 12) asm volatile(MIX3_BODY_12 :: [x] "v"(x), [ro] "v"(ro), [lane16] "v"(lane16), [goff] "v"(goff), [gp] "s"(gp) : "memory", "scc", "s42", "s43", "v32", "v33", "v34", "v35", "v36", "v37", "v38");
         if (MODE == 11) asm volatile(MIX3_BODY_11 :: [x] "v"(x), [ro] "v"(ro), [lane16] "v"(lane16), [goff] "v"(goff), [gp] "s"(gp) : "memory", "scc", "s42", "s43", "v32", "v33", "v34", "v35", "v36", "v37", "v38");
     }
-    if (MODE == 11) asm volatile("s_mov_b32 m0, 0\n s_set_gpr_idx_off" ::: "memory");
+    if (MODE == 11 || MODE == 12) asm volatile("s_mov_b32 m0, 0\n s_set_gpr_idx_off" ::: "memory");
     double s;
     asm volatile("v_add_f64 %0, v[112:113], v[114:115]\n v_add_f64 %0, %0, v[140:141]\n v_add_f64 %0, %0, v[48:49]" : "=v"(s));
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
@@ -72,11 +73,12 @@ int main(int argc, char** argv) {
         for (int rep = 0; rep < 3; ++rep) { run<7>("7 sustained", 512, it); run<11>("11 sustained", 512, it); }
         return 0;
     }
-    for (int th : {256, 512, 768}) {
+    for (int th : {256, 512}) {
         run<1>("1 reads only", th); run<2>("2 dpp FMAs only", th); run<3>("3 reads + dpp FMAs", th); run<4>("4 plain FMAs only", th);
         run<5>("5 reads + plain FMAs", th); run<6>("6 reads + sgpr-x FMAs", th); run<7>("7 dpp adds + reads + dpp FMAs", th);
         run<8>("8 = 7 with 2 accumulator chains", th); run<9>("9 = 7 with 4 accumulator chains", th);
         run<10>("10 whole set, hand-scheduled", th); run<11>("11 = 10, accumulators through M0", th);
+        run<12>("12 = 11, another pair every set", th);
     }
     return 0;
 }
