@@ -32,8 +32,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     const double* gp = (const double*)(((uintptr_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(gpu_ >> 32)) << 32) |
                                        (uintptr_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)gpu_));
     asm volatile("s_mov_b32 s42, 0x7fffffff\n s_mov_b32 s43, 0x8000" ::: "s42", "s43");
-    if (MODE == 11 || MODE == 12) asm volatile("s_mov_b32 m0, 0\n s_set_gpr_idx_on m0, 0\n s_mov_b32 m0, 0" ::: "memory");
-    const int iters2 = (MODE >= 10) ? iters / 2 : iters;   // a set = four octets = two "rounds" of the other modes
+    if (MODE >= 11) asm volatile("s_mov_b32 m0, 0\n s_set_gpr_idx_on m0, 0\n s_mov_b32 m0, 0" ::: "memory");
+    const int iters2 = (MODE == 14) ? iters / 16 : (MODE >= 10) ? iters / 2 : iters;   // mode 14: eight sets of code per iteration (12 KB)   // a set = four octets = two "rounds" of the other modes
     for (int it = 0; it < iters2; ++it) {
         if (MODE == 1) asm volatile(MIX3_BODY_1 :: [x] "v"(x), [ro] "v"(ro), [lane16] "v"(lane16) : "memory");
         if (MODE == 2) asm volatile(MIX3_BODY_2 :: [x] "v"(x), [ro] "v"(ro), [lane16] "v"(lane16) : "memory");
@@ -45,10 +45,12 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         if (MODE == 8) asm volatile(MIX3_BODY_8 :: [x] "v"(x), [ro] "v"(ro), [lane16] "v"(lane16) : "memory");
         if (MODE == 9) asm volatile(MIX3_BODY_9 :: [x] "v"(x), [ro] "v"(ro), [lane16] "v"(lane16) : "memory");
         if (MODE == 10) asm volatile(MIX3_BODY_10 :: [x] "v"(x), [ro] "v"(ro), [lane16] "v"(lane16), [goff] "v"(goff), [gp] "s"(gp) : "memory", "scc", "s42", "s43", "v32", "v33", "v34", "v35", "v36", "v37", "v38");
+        if (MODE == 14) asm volatile(MIX3_BODY_13 MIX3_BODY_13 MIX3_BODY_13 MIX3_BODY_13 MIX3_BODY_13 MIX3_BODY_13 MIX3_BODY_13 MIX3_BODY_13 :: [x] "v"(x), [ro] "v"(ro), [lane16] "v"(lane16), [goff] "v"(goff), [gp] "s"(gp) : "memory", "scc", "s42", "s43", "v32", "v33", "v34", "v35", "v36", "v37", "v38");
+        if (MODE == 13) asm volatile(MIX3_BODY_13 :: [x] "v"(x), [ro] "v"(ro), [lane16] "v"(lane16), [goff] "v"(goff), [gp] "s"(gp) : "memory", "scc", "s42", "s43", "v32", "v33", "v34", "v35", "v36", "v37", "v38");
         if (MODE == 12) asm volatile(MIX3_BODY_12 :: [x] "v"(x), [ro] "v"(ro), [lane16] "v"(lane16), [goff] "v"(goff), [gp] "s"(gp) : "memory", "scc", "s42", "s43", "v32", "v33", "v34", "v35", "v36", "v37", "v38");
         if (MODE == 11) asm volatile(MIX3_BODY_11 :: [x] "v"(x), [ro] "v"(ro), [lane16] "v"(lane16), [goff] "v"(goff), [gp] "s"(gp) : "memory", "scc", "s42", "s43", "v32", "v33", "v34", "v35", "v36", "v37", "v38");
     }
-    if (MODE == 11 || MODE == 12) asm volatile("s_mov_b32 m0, 0\n s_set_gpr_idx_off" ::: "memory");
+    if (MODE >= 11) asm volatile("s_mov_b32 m0, 0\n s_set_gpr_idx_off" ::: "memory");
     double s;
     asm volatile("v_add_f64 %0, v[112:113], v[114:115]\n v_add_f64 %0, %0, v[140:141]\n v_add_f64 %0, %0, v[48:49]" : "=v"(s));
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
@@ -78,7 +80,7 @@ int main(int argc, char** argv) {
         run<5>("5 reads + plain FMAs", th); run<6>("6 reads + sgpr-x FMAs", th); run<7>("7 dpp adds + reads + dpp FMAs", th);
         run<8>("8 = 7 with 2 accumulator chains", th); run<9>("9 = 7 with 4 accumulator chains", th);
         run<10>("10 whole set, hand-scheduled", th); run<11>("11 = 10, accumulators through M0", th);
-        run<12>("12 = 11, another pair every set", th);
+        run<12>("12 = 11, another pair every set", th); run<13>("13 the kernel: one buffer, reads behind FMAs", th); run<14>("14 = 13, eight copies of the set (12 KB of code)", th);
     }
     return 0;
 }
