@@ -315,19 +315,16 @@ __device__ __forceinline__ void acc_load(int idx4, double& v0, double& v1) {
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) void acc_tiled_kernel(
     const uint32_t* __restrict__ sroff, const double* __restrict__ sx, const int64_t* __restrict__ cstart,
     const uint8_t* __restrict__ cnt, int T, int64_t nwb, const double* __restrict__ F, int k, int TR, int64_t nrow,
-    int tiles_per_range, double* __restrict__ Bout, int64_t ncol, int KS, int ldf, int ldb, int64_t slab, int64_t wg_full,
-    int tail_w) {
+    int tiles_per_range, double* __restrict__ Bout, int64_t ncol, int KS, int ldf, int ldb, int64_t slab) {
     // k = factor rows handled by this launch (a part of the rank when it is above 64), KS = LDS row
     // stride the stream's offsets were built for, ldf / ldb = strides (doubles) between rows of F /
-    // columns of the output, slab = doubles between the outputs of two tile ranges (blockIdx.y);
-    // workgroups below wg_full own TILED_NW wave blocks each, the ones behind them tail_w (k_acc_tiled)
+    // columns of the output, slab = doubles between the outputs of two tile ranges (blockIdx.y)
     asm volatile("" ::: "v255");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* tile = reinterpret_cast<double*>(smem);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    int64_t wb = (int64_t)blockIdx.x * TILED_NW + wave;
-    if ((int64_t)blockIdx.x >= wg_full) wb = (wave < tail_w) ? wg_full * TILED_NW + ((int64_t)blockIdx.x - wg_full) * tail_w + wave : nwb;
+    const int64_t wb = (int64_t)blockIdx.x * TILED_NW + wave;
     const int t0 = blockIdx.y * tiles_per_range;
     const int t1 = (t0 + tiles_per_range < T) ? (t0 + tiles_per_range) : T;
     const bool wact = wb < nwb;
@@ -482,35 +479,13 @@ int k_acc_tiled(hipStream_t s, const DevTiled& S, const double* F, int ldf, doub
                                    hipFuncAttributeMaxDynamicSharedMemorySize, TILED_LDS_BYTES + 512));
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
-    int64_t nwg_x = (S.nwb + TILED_NW - 1) / TILED_NW;
-    // One workgroup per CU at a time (the tile takes the LDS), so the grid runs in rounds of `cus` workgroups and a
-    // last round that fills few CUs is wasted time on the others: when that round would be under 7/8 full, its wave
-    // blocks are dealt out over ALL CUs in workgroups of fewer active waves (the pass is LDS-bound per CU: fewer
-    // waves run proportionally faster).  Config 3: 1953 workgroups = 7.63 rounds -> 7 rounds + one of 6-wave groups.
-    int64_t wg_full = nwg_x;
-    int tail_w = TILED_NW;
-    if (S.R == 1 && !getenv("SGL_TILED_NO_TAIL")) {   // (env: A/B measurements)
-        static int cus_dev[64] = {0};
-        if (dev >= 0 && dev < 64 && cus_dev[dev] == 0) {
-            int v = 0;
-            HIPCHK(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
-            cus_dev[dev] = v > 0 ? v : 256;
-        }
-        const int64_t cus = (dev >= 0 && dev < 64) ? cus_dev[dev] : 256;
-        const int64_t full_rounds = S.nwb / (TILED_NW * cus);
-        const int64_t remw = S.nwb - full_rounds * TILED_NW * cus;
-        if (full_rounds >= 1 && remw > 0 && remw * 8 < 7 * TILED_NW * cus) {
-            wg_full = full_rounds * cus;
-            tail_w = (int)((remw + cus - 1) / cus);
-            nwg_x = wg_full + (remw + tail_w - 1) / tail_w;
-        }
-    }
+    const int64_t nwg_x = (S.nwb + TILED_NW - 1) / TILED_NW;
     const bool slabs = S.R > 1;
     double* out = slabs ? S.part : B;
     const int64_t n = (int64_t)kf * S.ncol;
     acc_tiled_kernel<<<dim3((unsigned)nwg_x, (unsigned)S.R), dim3(64 * TILED_NW), lds, s>>>(
         S.roff, xvals ? xvals : S.x, S.cstart, S.cnt, S.T, S.nwb, F, kf, S.TR, S.nrow, S.tiles_per_range, out, S.ncol, KS, ldf,
-        slabs ? kf : ldb, slabs ? n : 0, wg_full, tail_w);
+        slabs ? kf : ldb, slabs ? n : 0);
     HIPCHK(hipGetLastError());
     if (slabs) {
         int64_t blocks = (n + 255) / 256;
