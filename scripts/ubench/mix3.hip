@@ -27,8 +27,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     asm volatile("v_add_u32 v40, %0, %1\n v_add_u32 v41, 400, v40\n v_add_u32 v42, 800, v40\n v_add_u32 v43, 1200, v40\n"
                  "v_add_u32 v44, 1600, v40\n v_add_u32 v45, 2000, v40\n v_add_u32 v46, 2400, v40\n v_add_u32 v47, 2800, v40\n"
                  "s_mov_b64 s[40:41], 1.0" :: "v"(lane16), "v"(ro) : "s40", "s41", "memory");
-    const unsigned goff = lane * 8;
-    const uintptr_t gpu_ = (uintptr_t)(out + (size_t)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64);   // a wave-private line to re-load
+    unsigned goff = lane * 8;
+    const uintptr_t gpu_ = (MODE >= 15) ? (uintptr_t)((char*)out + (size_t)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * (4u << 20))
+                                         : (uintptr_t)(out + (size_t)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64);   // a wave-private line to re-load
     const double* gp = (const double*)(((uintptr_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(gpu_ >> 32)) << 32) |
                                        (uintptr_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)gpu_));
     asm volatile("s_mov_b32 s42, 0x7fffffff\n s_mov_b32 s43, 0x8000" ::: "s42", "s43");
@@ -45,6 +46,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         if (MODE == 8) asm volatile(MIX3_BODY_8 :: [x] "v"(x), [ro] "v"(ro), [lane16] "v"(lane16) : "memory");
         if (MODE == 9) asm volatile(MIX3_BODY_9 :: [x] "v"(x), [ro] "v"(ro), [lane16] "v"(lane16) : "memory");
         if (MODE == 10) asm volatile(MIX3_BODY_10 :: [x] "v"(x), [ro] "v"(ro), [lane16] "v"(lane16), [goff] "v"(goff), [gp] "s"(gp) : "memory", "scc", "s42", "s43", "v32", "v33", "v34", "v35", "v36", "v37", "v38");
+        if (MODE == 16) asm volatile(MIX3_BODY_16 : [goff] "+v"(goff) : [x] "v"(x), [ro] "v"(ro), [lane16] "v"(lane16), [gp] "s"(gp) : "memory", "scc", "s42", "s43", "v32", "v33", "v34", "v35", "v36", "v37", "v38");
+        if (MODE == 17) asm volatile(MIX3_BODY_17 : [goff] "+v"(goff) : [x] "v"(x), [ro] "v"(ro), [lane16] "v"(lane16), [gp] "s"(gp) : "memory", "scc", "s42", "s43", "v32", "v33", "v34", "v35", "v36", "v37", "v38");
+        if (MODE == 15) asm volatile(MIX3_BODY_15 : [goff] "+v"(goff) : [x] "v"(x), [ro] "v"(ro), [lane16] "v"(lane16), [gp] "s"(gp) : "memory", "scc", "s42", "s43", "v32", "v33", "v34", "v35", "v36", "v37", "v38");
         if (MODE == 14) asm volatile(MIX3_BODY_13 MIX3_BODY_13 MIX3_BODY_13 MIX3_BODY_13 MIX3_BODY_13 MIX3_BODY_13 MIX3_BODY_13 MIX3_BODY_13 :: [x] "v"(x), [ro] "v"(ro), [lane16] "v"(lane16), [goff] "v"(goff), [gp] "s"(gp) : "memory", "scc", "s42", "s43", "v32", "v33", "v34", "v35", "v36", "v37", "v38");
         if (MODE == 13) asm volatile(MIX3_BODY_13 :: [x] "v"(x), [ro] "v"(ro), [lane16] "v"(lane16), [goff] "v"(goff), [gp] "s"(gp) : "memory", "scc", "s42", "s43", "v32", "v33", "v34", "v35", "v36", "v37", "v38");
         if (MODE == 12) asm volatile(MIX3_BODY_12 :: [x] "v"(x), [ro] "v"(ro), [lane16] "v"(lane16), [goff] "v"(goff), [gp] "s"(gp) : "memory", "scc", "s42", "s43", "v32", "v33", "v34", "v35", "v36", "v37", "v38");
@@ -53,12 +57,12 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     if (MODE >= 11) asm volatile("s_mov_b32 m0, 0\n s_set_gpr_idx_off" ::: "memory");
     double s;
     asm volatile("v_add_f64 %0, v[112:113], v[114:115]\n v_add_f64 %0, %0, v[140:141]\n v_add_f64 %0, %0, v[48:49]" : "=v"(s));
-    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (MODE < 15) out[blockIdx.x * blockDim.x + threadIdx.x] = s; else if (s == 12345.678) out[0] = s;
 }
 
 template <int MODE>
 void run(const char* name, int threads, int iters = 10000) {
-    double* out; hipMalloc(&out, 256 * 1024 * 8);
+    double* out; hipMalloc(&out, MODE >= 15 ? ((size_t)256 * 16 * (4u << 20) + (1u << 20)) : (size_t)256 * 1024 * 8);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipFuncSetAttribute((const void*)kern<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 140000);
     kern<MODE><<<256, threads, 140000>>>(out, 100);
@@ -81,6 +85,7 @@ int main(int argc, char** argv) {
         run<8>("8 = 7 with 2 accumulator chains", th); run<9>("9 = 7 with 4 accumulator chains", th);
         run<10>("10 whole set, hand-scheduled", th); run<11>("11 = 10, accumulators through M0", th);
         run<12>("12 = 11, another pair every set", th); run<13>("13 the kernel: one buffer, reads behind FMAs", th); run<14>("14 = 13, eight copies of the set (12 KB of code)", th);
+        run<15>("15 = 13 + a real 768 B / set stream from HBM", th); run<16>("16 = 15 with 8 sets in flight", th); run<17>("17 = 15 with 16 sets in flight", th);
     }
     return 0;
 }
