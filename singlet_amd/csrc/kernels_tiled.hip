@@ -12,7 +12,7 @@
 // different non-zeros at once (two non-zeros per LDS instruction).
 //
 // Layout ("re-blocked stream", built once per (matrix, k) by sgl_tiled_build):
-//   * rows are cut into tiles of TR rows, TR * KS * 8 B <= 128 KiB (one LDS
+//   * rows are cut into tiles of TR rows, TR * KS * 8 B <= 160 KiB - 512 B (one LDS
 //     tile; KS = k rounded up to even so every row starts 16-byte aligned);
 //   * columns are cut into wave blocks of 64 columns; a workgroup of 8 waves
 //     owns 512 columns and keeps their k-vectors in VGPRs across all row tiles.
@@ -291,7 +291,7 @@ int sgl_tiled_mask_values(sgl_ctx* c, const DevCSC& M, DevTiled& S, uint64_t see
 // 0x8000 | 4 * pair) selects the running pair's registers for the FMAs (gen_acc_tiled.py).  Letting hipcc index
 // a register array dynamically was tried first: it either moved the array to scratch memory or copied whole
 // 32-register vectors around every slot change.  (Rounds 1 - 2 ran the loop as compiler-scheduled C++ with the
-// running pair swapped in and out of fixed registers: same arithmetic, 3 % slower; see DESIGN.md.)
+// running pair swapped in and out of fixed registers: same arithmetic, 6 % slower; see DESIGN.md.)
 //
 // Four stream sets are in flight per wave (3 KiB), refilled right after a set is prepared and waited with a
 // counted vmcnt (loads return in order); which ring slot is next is the wave-uniform `phase`.
