@@ -256,7 +256,12 @@ SGL_API int sgl_weight_by_split(sgl_ctx* ctx, const int32_t* split_by, int32_t n
 
 /* Start a fit at rank k.  w_init: k x nrow host array, or NULL to fill W on
  * the device with the synthetic init ((rand_{S+2}(f,g) >> 11) + 0.5) * 2^-53.
- * h = 0, d = 1 as in src/singlet.cpp:639-641. */
+ * h = 0, d = 1 as in src/singlet.cpp:639-641.
+ * May be called again and again on one resident matrix (R's ard_nmf / cross_validate_nmf refit one matrix tens
+ * of times, R/ard_nmf.R:95-160): the re-blocked entry streams of the matrix (2 x ~15 bytes per non-zero at
+ * k <= 128, + 8 per non-zero once a masked fit has run) are kept between fits -- a fit at an unchanged rank reuses
+ * them as they are, another rank rebuilds them in the same allocations -- and are released when the matrix changes
+ * (upload, synth, log-normalize, weight_by_split) or the context is destroyed. */
 SGL_API int sgl_fit_init(sgl_ctx* ctx, int32_t k, const double* w_init, uint64_t synth_seed);
 
 /* Link matrices of c_linked_nmf for the current fit (after sgl_fit_init; the
