@@ -84,6 +84,37 @@ def test_rhs_tiled_kernel_all_ranks(ctx, ora, sa, k):
     assert rel_fro(ctx.op_rhs(3, H), ora.rhs(At, H)) < 1e-14
 
 
+@pytest.mark.parametrize("shape", ["very_sparse", "dense_blocks", "one_pair_only"])
+def test_rhs_tiled_pair_bookkeeping_extremes(ctx, ora, sa, shape):
+    """The chunk loop of the tiled accumulate walks a byte queue of per-pair group counts (gen_acc_tiled.py): most
+    counts zero (long skips, queue rotation over empty 64-bit words), counts near the byte's limit (whole columns
+    dense inside a tile), and a chunk whose entries all belong to one pair.  Against the plain kernel and the oracle."""
+    rng = np.random.default_rng({"very_sparse": 1, "dense_blocks": 2, "one_pair_only": 3}[shape])
+    m, n, k = 2300, 200, 10                     # k = 10: tiles of 984 rows (the cap), 3 tiles
+    D = np.zeros((m, n))
+    if shape == "very_sparse":
+        idx = rng.integers(0, m * n, size=150)  # a handful of entries: almost every (chunk, pair) is empty
+        D.flat[idx] = rng.random(150) + 0.1
+        D[:, 64:128] = 0                        # a whole wave block without entries
+    elif shape == "dense_blocks":
+        D[:, 3] = rng.random(m) + 0.1           # 984 entries per tile in one column: 246 groups for its pair
+        D[:, 35] = rng.random(m) + 0.1          # ... and in its partner of the pair (3, 35)
+        D[100:1100, 70] = rng.random(1000) + 0.1
+        D[(rng.random((m, n)) < 0.02)] = 0.5
+    else:
+        D[:, 17] = (rng.random(m) < 0.5) * (rng.random(m) + 0.1)
+        D[:, 49] = (rng.random(m) < 0.1) * (rng.random(m) + 0.1)   # pair (17, 49) of wave block 0 only
+    A = ora.CSC(*_csc_from_dense(D))
+    At = A.t()
+    ctx.upload(to_dgc(sa, A), to_dgc(sa, At))
+    W = rng.random((m, k))
+    H = rng.random((n, k))
+    for which, F, M in ((2, W, A), (3, H, At)):
+        got, plain, want = ctx.op_rhs(which, F), ctx.op_rhs(which - 2, F), ora.rhs(M, F)
+        assert np.array_equal(got, plain), "tiled and plain kernels add the same products in the same order"
+        assert rel_fro(got, want) < 1e-14
+
+
 def test_rhs_ragged_and_empty_columns(ctx, ora, sa):
     rng = np.random.default_rng(3)
     D = (rng.random((90, 140)) < 0.3) * rng.random((90, 140))
