@@ -193,19 +193,35 @@ def main():
         mode = "native" if world > 1 else "none"
     if world > 1 and mode == "none":
         raise SystemExit("--comm none needs a single rank")
-    dist = None
+    # Host-side coordination (the 128-byte id, flags, the timing maximum) runs over a gloo group on CPU tensors when
+    # the exchange is the library's own RCCL communicator: no second RCCL communicator set in the process.  Only the
+    # hook path (--comm hook, or the fallback when the native initialisation fails) creates a torch NCCL group.
+    dist, hook_group = None, None
     if world > 1 or mode == "hook":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29541")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if mode == "native":
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    host_dev = "cuda" if (dist is not None and dist.get_backend() == "nccl") else "cpu"
 
     def barrier():
+        torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def reduce_host(vals, op):
+        """all-reduce of a few host doubles over the coordination group"""
+        if dist is None:
+            return [float(v) for v in vals]
+        t = torch.tensor(list(vals), dtype=torch.float64, device=host_dev)
+        dist.all_reduce(t, op=op)
+        return [float(v) for v in t.cpu()]
 
     ctx = sa.Context(local_rank)
     # one explicit (non-default) stream shared by the kernels and torch: RCCL orders its collective against
@@ -217,29 +233,42 @@ def main():
     from singlet_amd.sharded import shard_by_count, torch_allreduce_hook
     comm_note = None
     if mode == "native":
-        # rank 0 makes the RCCL id, the host side broadcasts its 128 bytes, every rank joins with its context;
-        # a rank that cannot (RCCL missing ...) makes ALL ranks take the hook path, and the JSON line says so
-        err, my_id = None, None
-        if rank == 0:
+        # (1) every rank checks that it can bind RCCL at all (no communication) and the ranks agree on it: the
+        #     communicator initialisation below is collective and would hang on the ranks that did join;
+        # (2) rank 0 makes the RCCL id, the host side broadcasts its 128 bytes, every rank joins with its context;
+        # a failure makes ALL ranks take the hook path, and the JSON line says so
+        err = None
+        if "SGL_RCCL_PATH" not in os.environ:   # the librccl this process has already mapped (torch's), not a second copy
             try:
-                my_id = sa.comm_unique_id()
-            except Exception as e:  # noqa: BLE001
-                err = repr(e)
-        ids = [my_id]
-        if dist is not None:
-            dist.broadcast_object_list(ids, src=0)      # always: the other ranks are waiting in it
-        if ids[0] is None:
-            err = err or "rank 0 could not create an RCCL id"
+                with open("/proc/self/maps") as f:
+                    libs = sorted({ln.split()[-1] for ln in f if "librccl" in ln and ln.split()[-1].startswith("/")})
+                if libs:
+                    os.environ["SGL_RCCL_PATH"] = libs[0]
+            except OSError:
+                pass
+        ok, rccl_path = sa.comm_available()
+        if not ok:
+            err = "rank %d cannot bind RCCL" % rank
+        if reduce_host([0.0 if ok else 1.0], dist.ReduceOp.MAX if dist else None)[0] == 0.0:
+            my_id = None
+            if rank == 0:
+                try:
+                    my_id = sa.comm_unique_id()
+                except Exception as e:  # noqa: BLE001
+                    err = repr(e)
+            ids = [my_id]
+            if dist is not None:
+                dist.broadcast_object_list(ids, src=0)      # always: the other ranks are waiting in it
+            if ids[0] is None:
+                err = err or "rank 0 could not create an RCCL id"
+            else:
+                try:
+                    ctx.comm_init_rank(world, rank, ids[0])
+                except Exception as e:  # noqa: BLE001
+                    err = repr(e)
         else:
-            try:
-                ctx.comm_init_rank(world, rank, ids[0])
-            except Exception as e:  # noqa: BLE001
-                err = repr(e)
-        failed = 1 if err else 0
-        if dist is not None:
-            flag = torch.tensor([failed], dtype=torch.int32, device="cuda")
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-            failed = int(flag[0])
+            err = err or "RCCL cannot be bound on another rank"
+        failed = reduce_host([1.0 if err else 0.0], dist.ReduceOp.MAX if dist else None)[0] != 0.0
         if failed:
             if world == 1:
                 raise SystemExit("native comm failed: %s" % err)
@@ -250,8 +279,9 @@ def main():
             ctx = sa.Context(local_rank)
             ctx.set_stream(stream.cuda_stream)
             mode = "hook"
+            hook_group = dist.new_group(backend="nccl")
     if mode == "hook":
-        ctx.set_allreduce(torch_allreduce_hook(dist, torch.device("cuda", local_rank)))
+        ctx.set_allreduce(torch_allreduce_hook(dist, torch.device("cuda", local_rank), group=hook_group))
 
     # contiguous equal-count cell blocks: the synthetic columns are i.i.d., so equal counts are equal
     # non-zeros to within 0.1 %
@@ -266,8 +296,19 @@ def main():
     def step():
         return ctx.nmf_iterate(args.L1, args.L1, 0.0, 0.0)
 
-    for _ in range(args.warmup):
-        step()
+    warm_tols = [step() for _ in range(args.warmup)]
+    comm_info = ctx.comm_info()
+    if dist is not None and warm_tols:
+        # W is replicated: tol = cor(w, w_prev) must come out bit-identical on every rank.  One 8-byte gather.
+        import struct
+        mine = struct.pack("<d", warm_tols[-1])
+        got = [None] * world
+        dist.all_gather_object(got, (mine, comm_info["nranks"]))
+        if any(g[0] != got[0][0] for g in got) or any(g[1] != got[0][1] for g in got):
+            raise SystemExit("bench.py: ranks disagree after warm-up (tol bits / communicator sizes): %r"
+                             % [(struct.unpack("<d", g[0])[0], g[1]) for g in got])
+    if mode == "native" and comm_info["nranks"] != world:
+        raise SystemExit("bench.py: the library's communicator spans %d ranks, launched with %d" % (comm_info["nranks"], world))
     ctx.sweeps_get(reset=True)
     ctx.timing_enable(True)
     ctx.timing_get(reset=True)
@@ -283,13 +324,8 @@ def main():
 
     nnz_total = nnz_local
     if dist is not None:
-        tt = torch.tensor([elapsed, float(nnz_local)], dtype=torch.float64, device="cuda")
-        mx = tt.clone()
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        sm = tt.clone()
-        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
-        elapsed = float(mx[0])
-        nnz_total = int(sm[1])
+        elapsed = reduce_host([elapsed], dist.ReduceOp.MAX)[0]
+        nnz_total = int(reduce_host([float(nnz_local)], dist.ReduceOp.SUM)[0])
 
     if rank == 0:
         k, n = args.k, args.cells
@@ -334,7 +370,10 @@ def main():
                          "whole_iteration": {"algorithmic_bytes": bytes_iter, "achieved": bytes_iter / (ms_step * 1e-3) / 1e9 / world,
                                              "frac": bytes_iter / (ms_step * 1e-3) / 1e9 / world / HBM_PEAK_GBS}},
             "phases_ms_per_step": ph_ms,
-            "comm": {"mode": mode, "note": comm_note,
+            "comm": {"mode": mode, "note": comm_note, "rccl_nranks": comm_info["nranks"] if comm_info["is_rccl"] else None,
+                     "rccl_path": comm_info["path"] or None,
+                     "host_coordination": None if dist is None else dist.get_backend(),
+                     "tol_bit_identical_across_ranks": None if dist is None else True,
                      "per_iteration": {"none": "no exchange (one shard)",
                                        "native": "RCCL inside the library: 1 grouped collective (reduce-scatter k x genes by gene "
                                                  "blocks + all-reduce [k x k | k]) + 1 all-gather of the W blocks",

@@ -366,6 +366,17 @@ SGL_API int sgl_multi_get_factors(sgl_multi* m, double* w, double* d, double* h)
 #define SGL_COMM_ID_BYTES 128
 SGL_API int sgl_comm_unique_id(void* id);
 SGL_API int sgl_comm_init_rank(sgl_ctx* ctx, int nranks, int rank, const void* id);
+/* sgl_comm_init_rank is collective (it blocks until all nranks have joined), so a rank that cannot bind RCCL must be
+ * found BEFORE anyone calls it: every rank calls sgl_comm_available (no communication; 0 or SGL_ECOMM; path_out, may
+ * be NULL, receives the library name that was opened -- SGL_RCCL_PATH in the environment names it, e.g. the librccl
+ * the host process has already loaded), the host agrees on the result, and only then all ranks join. */
+SGL_API int sgl_comm_available(char* path_out, int path_len);
+/* What the library's own communicator of this context reports: *nranks = ncclCommCount (the team size for ranks that
+ * share a device; 1 without a team), *is_rccl = 1 when the exchange runs over RCCL, path_out = the RCCL library bound. */
+SGL_API int sgl_comm_info(sgl_ctx* ctx, int32_t* nranks, int32_t* is_rccl, char* path_out, int path_len);
+/* The cell split sgl_multi_upload_csc uses: lo[0..n] boundaries of n contiguous blocks of (nearly) equal non-zero
+ * count, each at least one cell (p = the dgCMatrix p slot, ncol + 1 entries; ncol >= n).  Host only. */
+SGL_API int sgl_split_cells_by_nnz(const int32_t* p, int32_t ncol, int n, int64_t* lo);
 
 /* ------------------------------------------------------------------------
  * 3. Single operators, exposed for the parity tests (each is one kernel

@@ -107,6 +107,9 @@ SIGNATURES = {
     "sgl_multi_get_factors": (C.c_int, [C.c_void_p, f64p, f64p, f64p]),
     "sgl_comm_unique_id": (C.c_int, [C.c_void_p]),
     "sgl_comm_init_rank": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "sgl_comm_available": (C.c_int, [C.c_char_p, C.c_int]),
+    "sgl_comm_info": (C.c_int, [C.c_void_p, i32p, i32p, C.c_char_p, C.c_int]),
+    "sgl_split_cells_by_nnz": (C.c_int, [i32p, C.c_int32, C.c_int, i64p]),
     "sgl_get_factors": (C.c_int, [C.c_void_p, f64p, f64p, f64p]),
     "sgl_set_factors": (C.c_int, [C.c_void_p, f64p, f64p, f64p]),
     "sgl_op_rand": (C.c_int, [C.c_void_p, C.c_uint64, u64p, u64p, C.c_int64, u64p]),

@@ -42,6 +42,24 @@ def comm_unique_id():
     return buf.raw
 
 
+def comm_available():
+    """(ok, path): can RCCL be bound in this process (no communication), and which library was opened.
+    Ranks agree on this BEFORE comm_init_rank, which is collective and would otherwise hang on a rank
+    that cannot join."""
+    buf = C.create_string_buffer(512)
+    rc = _lib.load().sgl_comm_available(buf, 512)
+    return rc == 0, buf.value.decode("utf-8", "replace")
+
+
+def split_cells_by_nnz(p, n):
+    """The cell split of Multi.upload (sgl_multi_upload_csc): n + 1 boundaries of contiguous blocks of
+    nearly equal non-zero count, each at least one cell."""
+    p = np.ascontiguousarray(p, dtype=np.int32)
+    lo = np.zeros(n + 1, dtype=np.int64)
+    check(_lib.load().sgl_split_cells_by_nnz(ptr(p, i32p), int(p.shape[0] - 1), int(n), ptr(lo, i64p)))
+    return lo
+
+
 class Context:
     def __init__(self, device=0, _borrowed=None):
         self._L = _lib.load()
@@ -70,6 +88,13 @@ class Context:
             raise ValueError("comm_id must be %d bytes" % COMM_ID_BYTES)
         buf = C.create_string_buffer(bytes(comm_id), COMM_ID_BYTES)
         check(self._L.sgl_comm_init_rank(self._h, int(nranks), int(rank), buf))
+
+    def comm_info(self):
+        """What the library's own communicator reports: ranks (ncclCommCount), whether it is RCCL, the library bound."""
+        n, r = C.c_int32(), C.c_int32()
+        buf = C.create_string_buffer(512)
+        check(self._L.sgl_comm_info(self._h, C.byref(n), C.byref(r), buf, 512))
+        return {"nranks": n.value, "is_rccl": bool(r.value), "path": buf.value.decode("utf-8", "replace")}
 
     def nmf_iterate(self, L1_w, L1_h, L2_w, L2_h):
         """One ALS iteration (any exchange mode); returns tol."""

@@ -31,15 +31,18 @@
 #include <string.h>
 #include <stdlib.h>
 #include <algorithm>
+#include <mutex>
 #include <vector>
 
 // ---------------------------------------------------------------- RCCL binding --
 struct RcclApi {
     void* handle = nullptr;
+    char path[512] = "";
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*ReduceScatter)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
@@ -49,23 +52,31 @@ struct RcclApi {
 };
 
 static RcclApi* rccl_api() {
+    // bound once, whichever host thread comes first (the replica sweep runs one thread per device)
     static RcclApi api;
-    static bool tried = false;
-    if (!tried) {
-        tried = true;
+    static char why[256] = "not found";
+    static std::once_flag once;
+    std::call_once(once, [] {
         const char* names[] = {getenv("SGL_RCCL_PATH"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
         for (const char* n : names) {
             if (!n || !*n) continue;
             api.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-            if (api.handle) break;
+            if (api.handle) { snprintf(api.path, sizeof(api.path), "%s", n); break; }
+            const char* e = dlerror();   // one call: it clears the message
+            if (e) snprintf(why, sizeof(why), "%s", e);
         }
         if (api.handle) {
             bool ok = true;
-            auto bind = [&](const char* sym) { void* f = dlsym(api.handle, sym); if (!f) ok = false; return f; };
+            auto bind = [&](const char* sym) {
+                void* f = dlsym(api.handle, sym);
+                if (!f) { ok = false; snprintf(why, sizeof(why), "symbol %s missing in %s", sym, api.path); }
+                return f;
+            };
             api.GetUniqueId = (decltype(api.GetUniqueId))bind("ncclGetUniqueId");
             api.CommInitRank = (decltype(api.CommInitRank))bind("ncclCommInitRank");
             api.CommInitAll = (decltype(api.CommInitAll))bind("ncclCommInitAll");
             api.CommDestroy = (decltype(api.CommDestroy))bind("ncclCommDestroy");
+            api.CommCount = (decltype(api.CommCount))bind("ncclCommCount");
             api.AllReduce = (decltype(api.AllReduce))bind("ncclAllReduce");
             api.ReduceScatter = (decltype(api.ReduceScatter))bind("ncclReduceScatter");
             api.AllGather = (decltype(api.AllGather))bind("ncclAllGather");
@@ -74,8 +85,8 @@ static RcclApi* rccl_api() {
             api.GetErrorString = (decltype(api.GetErrorString))bind("ncclGetErrorString");
             if (!ok) { dlclose(api.handle); api.handle = nullptr; }
         }
-    }
-    if (!api.handle) { sgl_set_error("RCCL (librccl.so.1) could not be loaded: %s", dlerror() ? dlerror() : "not found"); return nullptr; }
+    });
+    if (!api.handle) { sgl_set_error("RCCL (librccl.so.1) could not be loaded: %s", why); return nullptr; }
     return &api;
 }
 
@@ -679,6 +690,38 @@ extern "C" int sgl_comm_init_rank(sgl_ctx* c, int nranks, int rank, const void* 
     return SGL_OK;
 }
 
+// RCCL can be bound in this process (no collective call: ranks agree on this BEFORE sgl_comm_init_rank, which blocks
+// until every rank has joined); path_out (may be NULL) receives the library name that was opened
+extern "C" int sgl_comm_available(char* path_out, int path_len) {
+    RcclApi* R = rccl_api();
+    if (path_out && path_len > 0) snprintf(path_out, (size_t)path_len, "%s", R ? R->path : "");
+    return R ? SGL_OK : SGL_ECOMM;
+}
+
+// what the library's own communicator says: ranks it spans (ncclCommCount; 1 without a team, the team size in
+// loopback mode), whether it is an RCCL communicator, and the RCCL library bound
+extern "C" int sgl_comm_info(sgl_ctx* c, int32_t* nranks, int32_t* is_rccl, char* path_out, int path_len) {
+    if (!c) { sgl_set_error("null context"); return SGL_EINVAL; }
+    if (nranks) *nranks = 1;
+    if (is_rccl) *is_rccl = 0;
+    if (path_out && path_len > 0) path_out[0] = 0;
+    sgl_team* T = c->team;
+    if (!T) return SGL_OK;
+    if (nranks) *nranks = T->nranks;
+    if (T->loopback || T->comm.empty()) return SGL_OK;
+    RcclApi* R = rccl_api();
+    if (!R) return SGL_ECOMM;
+    for (size_t i = 0; i < T->local.size(); ++i)
+        if (T->local[i] == c && i < T->comm.size() && T->comm[i]) {
+            int cnt = 0;
+            NCCLCHK(R->CommCount(T->comm[i], &cnt));
+            if (nranks) *nranks = cnt;
+            if (is_rccl) *is_rccl = 1;
+            if (path_out && path_len > 0) snprintf(path_out, (size_t)path_len, "%s", R->path);
+        }
+    return SGL_OK;
+}
+
 // One ALS iteration on a context, whatever its exchange: none (one shard), the all-reduce hook (two
 // all-reduces, the reference's operation order) or a native team (above).
 extern "C" int sgl_nmf_iterate(sgl_ctx* c, double L1_w, double L1_h, double L2_w, double L2_h, double* tol) {
@@ -762,17 +805,22 @@ extern "C" int sgl_multi_ctx(sgl_multi* M, int rank, sgl_ctx** out) {
     return SGL_OK;
 }
 
-// contiguous cell blocks with (nearly) equal non-zero counts
-static void split_by_nnz(const int32_t* p, int32_t ncol, int n, std::vector<int64_t>& b) {
-    b.assign(n + 1, 0);
+// Contiguous cell blocks with (nearly) equal non-zero counts, every block at least one cell: lo[0] = 0,
+// lo[n] = ncol stay fixed and only the interior boundaries are clamped into [lo[r-1] + 1, ncol - (n - r)]
+// (a heavy last cell used to push lo[n] past ncol: round-2 advice).  Host only; exported for the tests.
+extern "C" int sgl_split_cells_by_nnz(const int32_t* p, int32_t ncol, int n, int64_t* lo) {
+    if (!p || !lo || n < 1 || ncol < n) { sgl_set_error("sgl_split_cells_by_nnz: fewer cells (%d) than ranks (%d)", ncol, n); return SGL_EINVAL; }
     const int64_t total = p[ncol];
+    lo[0] = 0;
     for (int r = 1; r < n; ++r) {
         const int64_t target = total * r / n;
         int64_t c = std::lower_bound(p, p + ncol + 1, (int32_t)std::min<int64_t>(target, INT32_MAX)) - p;
-        c = std::min<int64_t>(std::max<int64_t>(c, b[r - 1]), ncol);
-        b[r] = c;
+        c = std::max<int64_t>(c, lo[r - 1] + 1);
+        c = std::min<int64_t>(c, (int64_t)ncol - (n - r));
+        lo[r] = c;
     }
-    b[n] = ncol;
+    lo[n] = ncol;
+    return SGL_OK;
 }
 
 extern "C" int sgl_multi_upload_csc(sgl_multi* M, const double* Ax, const int32_t* Ai, const int32_t* Ap, int32_t nrow, int32_t ncol) {
@@ -780,11 +828,8 @@ extern "C" int sgl_multi_upload_csc(sgl_multi* M, const double* Ax, const int32_
     if (!Ax || !Ai || !Ap || nrow <= 0 || ncol <= 0) { sgl_set_error("sgl_multi_upload_csc: missing slot or empty matrix"); return SGL_EINVAL; }
     const int n = M->nranks;
     if (ncol < n) { sgl_set_error("sgl_multi_upload_csc: fewer cells (%d) than devices (%d)", ncol, n); return SGL_EINVAL; }
-    split_by_nnz(Ap, ncol, n, M->cell_lo);
-    for (int r = 1; r <= n; ++r)   // every rank needs at least one cell
-        if (M->cell_lo[r] <= M->cell_lo[r - 1]) M->cell_lo[r] = M->cell_lo[r - 1] + 1;
-    for (int r = n - 1; r >= 0; --r)
-        if (M->cell_lo[r] >= M->cell_lo[r + 1]) M->cell_lo[r] = M->cell_lo[r + 1] - 1;
+    M->cell_lo.assign(n + 1, 0);
+    SGLCHK(sgl_split_cells_by_nnz(Ap, ncol, n, M->cell_lo.data()));
     M->nrow = nrow;
     M->ncells_total = ncol;
     std::vector<int32_t> p;

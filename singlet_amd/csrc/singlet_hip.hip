@@ -968,6 +968,7 @@ static int current_device_or_zero() {
 struct CachedCtx {
     sgl_ctx* c = nullptr;
     const void *ax = nullptr, *ai = nullptr, *ap = nullptr;
+    const void *atx = nullptr, *ati = nullptr, *atp = nullptr;   // the t(A) slots the resident transpose came from (NULL: built on the device)
     int32_t nrow = 0, ncol = 0;
     int64_t nnz = 0;
     uint64_t fp = 0;
@@ -1016,7 +1017,9 @@ static int acquire_ctx(const double* Ax, const int32_t* Ai, const int32_t* Ap, c
     if (!Ax || !Ai || !Ap || nrow <= 0 || ncol <= 0) { sgl_set_error("missing slot or empty matrix"); return SGL_EINVAL; }
     const uint64_t fp = fingerprint(Ax, Ai, Ap, ncol);
     if (g_cache.c && g_cache.ax == Ax && g_cache.ai == Ai && g_cache.ap == Ap && g_cache.nrow == nrow && g_cache.ncol == ncol &&
-        g_cache.nnz == (int64_t)Ap[ncol] && g_cache.fp == fp && g_cache.device == dev) {
+        g_cache.nnz == (int64_t)Ap[ncol] && g_cache.fp == fp && g_cache.device == dev &&
+        // a call that brings its own t(A) must bring the same one (by address) as the call that filled the cache
+        (!Atx || (g_cache.atx == Atx && g_cache.ati == Ati && g_cache.atp == Atp))) {
         *out = g_cache.c;
         *cached = true;
         return SGL_OK;
@@ -1028,6 +1031,7 @@ static int acquire_ctx(const double* Ax, const int32_t* Ai, const int32_t* Ap, c
     if (rc != SGL_OK) { sgl_destroy(c); return rc; }
     g_cache.c = c;
     g_cache.ax = Ax; g_cache.ai = Ai; g_cache.ap = Ap;
+    g_cache.atx = Atx; g_cache.ati = Ati; g_cache.atp = Atp;
     g_cache.nrow = nrow; g_cache.ncol = ncol; g_cache.nnz = Ap[ncol];
     g_cache.fp = fp;
     g_cache.device = dev;
@@ -1039,7 +1043,14 @@ struct AcquiredCtx {   // destroys a non-cached context on scope exit; serialise
     std::unique_lock<std::mutex> lk{g_cache_mu};
     sgl_ctx* c = nullptr;
     bool cached = false;
-    ~AcquiredCtx() { if (c && !cached) sgl_destroy(c); }
+    bool ok = false;   // set by the entry point when its call succeeded
+    ~AcquiredCtx() {
+        if (!c) return;
+        if (!cached) sgl_destroy(c);
+        // a cached context whose call failed (interrupt, sticky HIP error ...) is not handed to the next call
+        else if (!ok && g_cache.c == c) { sgl_destroy(c); g_cache = CachedCtx(); }
+    }
+    int done(int rc) { ok = (rc == SGL_OK); return rc; }
 };
 
 // releases the cached context (if any); also what a host calls before unloading the library
@@ -1069,7 +1080,7 @@ extern "C" int sgl_c_nmf(const double* Ax, const int32_t* Ai, const int32_t* Ap,
     SGLCHK(acquire_ctx(Ax, Ai, Ap, Atx, Ati, Atp, nrow, ncol, &hd.c, &hd.cached));
     SGLCHK(sgl_fit_init(hd.c, k, w_init, 0));
     SGLCHK(sgl_nmf_run(hd.c, tol, maxit, L1_w, L1_h, L2_w, L2_h, n_iter, tol_trace, cb));
-    return sgl_get_factors(hd.c, w_out, d_out, h_out);
+    return hd.done(sgl_get_factors(hd.c, w_out, d_out, h_out));
 }
 
 // c_linked_nmf's link matrices (src/singlet.cpp:1059-1065): each is used only if its column count
@@ -1167,7 +1178,7 @@ extern "C" int sgl_c_ard_nmf(const double* Ax, const int32_t* Ai, const int32_t*
     int32_t nit = 0;
     SGLCHK(sgl_ard_run(hd.c, tol, maxit, L1, L2, seed, inv_density, overfit_threshold, trace_test_mse, test_mse, iter,
                        tol_out, score_overfit, n_trace, &nit, cb));
-    return sgl_get_factors(hd.c, w_out, d_out, h_out);
+    return hd.done(sgl_get_factors(hd.c, w_out, d_out, h_out));
 }
 
 // dense matrix -> the slots of its CSC image (zeros dropped)

@@ -271,6 +271,14 @@ static dgc_list view_dgc_list(SEXP lst, const char* what) {
     return L;
 }
 
+/* h is allocated k x nrow(At[[1]]) as the reference does (l.723), and the library writes k x (total columns of the A
+ * chunks): the two must agree or the write would run past the R vector */
+static void check_list_cells(const dgc_list* A, int n_from_At) {
+    long tot = 0;
+    for (int q = 0; q < A->n; ++q) tot += A->ncol[q];
+    if (tot != (long)n_from_At) Rf_error("the chunks of A hold %ld columns in all but the chunks of At have %d rows", tot, n_from_At);
+}
+
 /* ---- c_nmf_sparse_list(A_, At_, tol, maxit, verbose, L1, L2, threads, w)  (src/singlet.cpp:715-743) ---- */
 SEXP _singlet_c_nmf_sparse_list(SEXP A_, SEXP At_, SEXP tol_, SEXP maxit_, SEXP verbose_, SEXP L1_, SEXP L2_, SEXP threads_,
                                 SEXP w_) {
@@ -279,6 +287,7 @@ SEXP _singlet_c_nmf_sparse_list(SEXP A_, SEXP At_, SEXP tol_, SEXP maxit_, SEXP 
     const int k = Rf_nrows(w_);
     if (Rf_ncols(w_) != A.nrow) Rf_error("w must be k x nrow(A)");
     const int n = At.nrow;   /* n = At[0].rows(), l.723 */
+    check_list_cells(&A, n);
     const int verbose = Rf_asLogical(verbose_);
     const int maxit = Rf_asInteger(maxit_);
     SEXP w = PROTECT(Rf_allocMatrix(REALSXP, k, A.nrow)), d = PROTECT(Rf_allocVector(REALSXP, k)),
@@ -325,6 +334,7 @@ SEXP _singlet_c_ard_nmf_sparse_list(SEXP A_, SEXP At_, SEXP tol_, SEXP maxit_, S
     const int k = Rf_nrows(w_);
     if (Rf_ncols(w_) != A.nrow) Rf_error("w must be k x nrow(A)");
     const int n = At.nrow;
+    check_list_cells(&A, n);
     const int verbose = Rf_asLogical(verbose_);
     const int maxit = Rf_asInteger(maxit_);
     SEXP w = PROTECT(Rf_allocMatrix(REALSXP, k, A.nrow)), d = PROTECT(Rf_allocVector(REALSXP, k)),

@@ -66,7 +66,7 @@ class DevView:
         self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr, False), "version": 2}
 
 
-def torch_allreduce_hook(dist, device):
+def torch_allreduce_hook(dist, device, group=None):
     """All-reduce hook for singlet_amd.Context.set_allreduce: sums `count` doubles at a device
     pointer over the default process group (RCCL when the backend is "nccl").  The context must
     launch on torch's current stream (Context.set_stream) so the collective is ordered after the
@@ -79,6 +79,6 @@ def torch_allreduce_hook(dist, device):
         if t is None:
             t = torch.as_tensor(DevView(ptr, count), device=device)
             views[(ptr, count)] = t
-        dist.all_reduce(t)
+        dist.all_reduce(t, group=group)
 
     return hook

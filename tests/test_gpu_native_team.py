@@ -13,7 +13,8 @@ from conftest import rel_fro, same_zero_pattern, to_dgc
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("m,n,k,ranks", [(300, 1000, 8, 2), (257, 700, 30, 3), (500, 640, 50, 2), (130, 900, 70, 4), (96, 400, 5, 7)])
+@pytest.mark.parametrize("m,n,k,ranks", [(300, 1000, 8, 2), (257, 700, 30, 3), (500, 640, 50, 2), (130, 900, 70, 4), (96, 400, 5, 7), (210, 520, 100, 2),
+                                          (230, 500, 120, 3)])
 def test_team_on_one_device_matches_the_oracle_and_the_single_shard(sa, ora, m, n, k, ranks):
     A = ora.synth_csc(m, n, 20)
     At = A.t()

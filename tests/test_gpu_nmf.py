@@ -20,7 +20,11 @@ def _check(got, ref, keys=("w", "h", "d")):
 @pytest.mark.parametrize("m,n,k,L1,L2,maxit", [
     (300, 400, 8, 0.0, 0.0, 5), (300, 400, 8, 0.01, 0.0, 5), (300, 400, 8, 0.01, 0.01, 5),
     (500, 260, 30, 0.01, 0.0, 4), (257, 1031, 50, 0.01, 0.0, 3), (200, 300, 1, 0.0, 0.0, 3),
-    (150, 200, 64, 0.01, 0.0, 2), (150, 220, 70, 0.01, 0.0, 2)])
+    (150, 200, 64, 0.01, 0.0, 2), (150, 220, 70, 0.01, 0.0, 2),
+    # ranks above 64: two-part tiled accumulate, split Gram, lane NNLS with x in scratch (100), one wave per SIMD
+    # (120, 128), and above 128 the plain CSC accumulate + wave-per-column NNLS (130, 200)
+    (260, 330, 100, 0.01, 0.0, 2), (250, 300, 120, 0.01, 0.0, 2), (270, 310, 128, 0.01, 0.01, 2),
+    (280, 300, 130, 0.01, 0.0, 2), (300, 420, 200, 0.01, 0.0, 2)])
 def test_c_nmf_parity(sa, ora, m, n, k, L1, L2, maxit):
     A = ora.synth_csc(m, n, 20)
     At = A.t()
@@ -64,10 +68,11 @@ def test_c_nmf_empty_columns_keep_stale_values(sa, ora):
     assert np.all(got["h"][:, 7] == 0) and np.all(got["w"][:, 33] > 0)
 
 
+@pytest.mark.parametrize("k", [11, 90, 140])
 @pytest.mark.parametrize("orient", ["m_by_k", "k_by_m"])
-def test_c_project_model(sa, ora, orient):
+def test_c_project_model(sa, ora, orient, k):
     A = ora.synth_csc(300, 410, 20)
-    w = np.random.default_rng(1).random((300, 11))
+    w = np.random.default_rng(1).random((300, k))
     win = w if orient == "m_by_k" else w.T.copy()
     ref = ora.c_project_model(A, win, 0.01, 0.0)
     got = sa.c_project_model(to_dgc(sa, A), win, 0.01, 0.0, 0)

@@ -141,7 +141,10 @@ def _csc_from_dense(D):
     return np.concatenate(xs), np.concatenate(is_), np.array(p), nrow, ncol
 
 
-@pytest.mark.parametrize("k", [2, 8, 10, 30, 50, 52, 64, 65, 100])
+# every kernel family of the shared-Gram solve (kernels_nnls.hip dispatch): lane kernel with G as scalar operands (k <= 40),
+# DPP rows (42 - 64), x in memory scratch (66 - 104: instances 72, 80, 88, 96, 104), one wave per SIMD (112, 120, 128),
+# wave per column above 128 up to SGL_MAX_K
+@pytest.mark.parametrize("k", [2, 8, 10, 30, 40, 42, 50, 52, 64, 65, 72, 80, 88, 96, 100, 104, 105, 112, 120, 127, 128, 129, 200, 256])
 @pytest.mark.parametrize("L1,L2", [(0.0, 0.0), (0.01, 0.0), (0.01, 0.05)])
 def test_nnls(ctx, ora, k, L1, L2):
     rng = np.random.default_rng(k)

@@ -81,7 +81,7 @@ def test_two_rank_sharded_loop_matches_unsharded():
     assert np.allclose(t0, ref["tol"], rtol=1e-9)
 
 
-def _team_worker(rank, world, port, q):
+def _team_worker(rank, world, port, q, m=121):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch
@@ -93,7 +93,7 @@ def _team_worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    m, n, k = 121, 301, 7          # 121 genes over 2 ranks: unequal last block (the padding path)
+    n, k = 301, 7          # 121 genes over 2 ranks / 123 over 4: unequal last block (the padding path)
     A = ora.synth_csc(m, n, 10)
     bounds = shard_by_nnz(A.p, world)
     lo, hi = bounds[rank], bounds[rank + 1]
@@ -156,6 +156,58 @@ def test_two_rank_team_exchange_pattern_matches_unsharded():
     rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)
     assert rel(W0, ref["w"]) < 1e-11 and rel(H, ref["h"]) < 1e-11 and rel(d0, ref["d"]) < 1e-12
     assert np.allclose(t0, ref["tol"], rtol=1e-8)
+
+
+@pytest.mark.timeout(300)
+def test_four_rank_team_exchange_uneven_last_gene_block():
+    """World size 4 with 123 genes: gene blocks of 31, the last one short (30 real genes + 1 pad row) -- the
+    reduce-scatter / all-gather units of multi.hip are padded to equal blocks and the pad must never leak into W."""
+    import torch.multiprocessing as mp
+    from oracle import oracle as ora
+    world, m, n, k = 4, 123, 301, 7
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_team_worker, args=(r, world, port, q, m)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    A = ora.synth_csc(m, n, 10)
+    ref = ora.c_nmf(A, A.t(), 0.0, 4, 0.01, 0.01, 0.0, 0.0, 0, ora.synth_winit(k, m))
+    assert res[0][1] == 0 and res[-1][2] == n and all(res[r][2] == res[r + 1][1] for r in range(world - 1))
+    for r in range(1, world):   # replicated bit-for-bit
+        assert np.array_equal(res[0][3], res[r][3]) and np.array_equal(res[0][4], res[r][4]) and np.array_equal(res[0][6], res[r][6])
+    H = np.vstack([t[5] for t in res])
+    rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)
+    assert res[0][3].shape == (m, k)
+    assert rel(res[0][3], ref["w"]) < 1e-11 and rel(H, ref["h"]) < 1e-11 and rel(res[0][4], ref["d"]) < 1e-12
+    assert np.allclose(res[0][6], ref["tol"], rtol=1e-8)
+
+
+def test_cell_split_keeps_every_block_non_empty(sa):
+    """sgl_split_cells_by_nnz (the split of sgl_multi_upload_csc): a heavy LAST cell used to push the last boundary
+    past ncol (round-2 advice: n = 2, p = [0, 1, 2, 10] gave [0, 3, 4])."""
+    assert list(sa.split_cells_by_nnz([0, 1, 2, 10], 2)) == [0, 2, 3]
+    rng = np.random.default_rng(5)
+    for n in range(2, 9):
+        for trial in range(40):
+            ncol = int(rng.integers(n, 3 * n + 2))
+            cnt = rng.integers(0, 4, size=ncol)
+            which = trial % 4
+            if which == 0:
+                cnt[-1] = 1000       # heavy last cell
+            elif which == 1:
+                cnt[0] = 1000        # heavy first cell
+            elif which == 2:
+                cnt[:] = 0           # an all-empty matrix
+            p = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32)
+            lo = sa.split_cells_by_nnz(p, n)
+            assert lo[0] == 0 and lo[-1] == ncol and np.all(np.diff(lo) >= 1), (n, p.tolist(), lo.tolist())
+    with pytest.raises(sa.SingletHipError):
+        sa.split_cells_by_nnz([0, 1, 2], 3)
 
 
 def test_shard_helpers():
