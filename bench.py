@@ -38,6 +38,9 @@ def parse():
     ap.add_argument("--k", type=int, default=50)
     ap.add_argument("--inv-density", type=int, default=20)
     ap.add_argument("--L1", type=float, default=0.01)
+    ap.add_argument("--data", choices=("iid", "skewed"), default="iid",
+                    help="iid = BASELINE's synthetic matrix (the headline); skewed = the same generator with log-normal weights "
+                         "per cell (sigma 0.5) and per gene (sigma 1.5): heavy-tailed row and column counts (secondary record)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-cells", type=int, default=200000, help="cells of the CPU baseline sample (0 = all)")
     ap.add_argument("--comm", choices=("auto", "native", "hook", "none"), default="auto",
@@ -287,7 +290,8 @@ def main():
     # non-zeros to within 0.1 %
     lo, n_local = shard_by_count(args.cells, world, rank)
     t0 = time.perf_counter()
-    ctx.synth(args.genes, n_local, args.inv_density, cell_offset=lo, ncells_total=args.cells)
+    ctx.synth(args.genes, n_local, args.inv_density, cell_offset=lo, ncells_total=args.cells,
+              skew=(0.5, 1.5) if args.data == "skewed" else None)
     torch.cuda.synchronize()
     gen_s = time.perf_counter() - t0
     m, n_loc, nnz_local = ctx.dims()
@@ -350,19 +354,37 @@ def main():
         stream_bytes = lay["entries"] * 12 + lay["col_blocks"] * lay["tiles"] * (32 + 8)
         out_bytes = 8 * k * ncols_dom * (lay["tile_ranges"] + (2 if lay["tile_ranges"] > 1 else 0))
         staged_bytes = 8 * k * nrows_dom * ((lay["col_blocks"] + 7) // 8)
-        traffic = measured_traffic(args, world, dom, lay)
+        traffic = measured_traffic(args, world, dom, lay) if args.data == "iid" else None
+        # Why 0.60 of the HBM peak is out of reach for this formulation in FP64 at k = 50 (DESIGN.md "The sparse update
+        # against its rooflines"): every entry pair costs one ds_read_b128 (the LDS retires one wave instruction per
+        # 1.76 ns per CU whatever its width) and 2 FP64 FMAs + 1 address add; micro-benchmark rates of this part,
+        # applied to THIS run's stored entry pairs on 256 CUs
+        pairs = lay["entries"] / 2.0
+        ceiling = {"lds_floor_ms": pairs * 1.76e-9 / 256 * 1e3, "loop_floor_ms": pairs * (153e-9 / 64) / 256 * 1e3,
+                   "hbm_floor_ms": dom_bytes / (HBM_PEAK_GBS * 1e9) * 1e3,
+                   "fp64_fma_floor_ms": lay["entries"] * 4.9 / 2.4e9 / 1024 * 1e3,
+                   "source": "scripts/ubench/lds_rate, valu_rate, mix3 (profiles/r2_acc_tiled_tuning.md): 1.76 ns per LDS "
+                             "wave-instruction per CU; 153 ns per round of 8 waves x 8 entry pairs for the complete 64-entry set "
+                             "loop; 4.9 cycles per v_fmac_f64 wave-instruction per SIMD",
+                   "note": "the kernel is bound by LDS operand delivery + FP64 issue, not by HBM: the frac below cannot exceed "
+                           "hbm_floor_ms / loop_floor_ms with one LDS read per entry pair"}
+        ceiling["max_frac_of_this_formulation"] = ceiling["hbm_floor_ms"] / ceiling["loop_floor_ms"]
         out = {
             "metric": "ALS iterations/sec (1M cells x 30k genes, 5% nnz, k=50)",
             "value": args.steps / elapsed, "unit": "iter/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "synthetic CSC %d genes x %d cells, 1/%d non-zero (nnz %d), k=%d, L1=%g, tol=0 "
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic" if args.data == "iid" else "synthetic-skewed",
+            "config": {"workload": "synthetic CSC %d genes x %d cells, %s (nnz %d), k=%d, L1=%g, tol=0 "
                                    "(no early stop), cells sharded over %d GPU(s)"
-                                   % (m, n, args.inv_density, nnz_total, k, args.L1, world),
+                                   % (m, n, "1/%d non-zero" % args.inv_density if args.data == "iid" else
+                                      "mean density 1/%d with log-normal cell (sigma 0.5) and gene (sigma 1.5) weights" % args.inv_density,
+                                      nnz_total, k, args.L1, world),
                        "genes": m, "cells": n, "k": k, "nnz": nnz_total, "parallelism": "cells/%d" % world},
             "roofline": {"bound": "hbm", "kernel": "acc_tiled_kernel (%s: sparse accumulate of predict, one launch = one pass over the matrix)" % dom,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "frac_of_measured_copy": achieved / HBM_MEASURED_GBS, "traffic": traffic,
+                         "frac_of_measured_copy": achieved / HBM_MEASURED_GBS, "traffic": traffic, "ceiling": ceiling,
+                         "entries_per_nonzero": {"rhs_h": layout["A"]["entries"] / max(nnz_local, 1),
+                                                 "rhs_w": layout["At"]["entries"] / max(nnz_local, 1)},
                          "stream_layout": dict(lay, stream_bytes=stream_bytes, output_bytes=out_bytes,
                                                factor_tile_bytes_staged_from_l2=staged_bytes),
                          "stream_layouts": {"rhs_h": layout["A"], "rhs_w": layout["At"]},

@@ -236,6 +236,13 @@ SGL_API int sgl_upload_csc_list(sgl_ctx* ctx, int32_t n_chunks, const double* co
  * levels16[(rand_{S+1}(c,g) >> 11) % 16].  Both orientations are produced. */
 SGL_API int sgl_synth_csc(sgl_ctx* ctx, uint64_t S, uint64_t inv_density, const double* levels16,
                   int32_t ngenes, int64_t cell_offset, int32_t ncells_local, int64_t ncells_total);
+/* The same with SKEWED rows and columns (a benchmark matrix nearer to count data than the i.i.d. one; the
+ * reference's own fixture pbmc3k has 3 ... 2700 non-zeros per gene): entry (g, c) is non-zero iff
+ * u(c, g) < cell_w16[level(c)] * gene_w16[level(g)] / inv_density, u = (rand_S(c, g) >> 11) * 2^-53, the levels
+ * 4-bit hashes of the cell / gene index alone.  Both tables NULL = sgl_synth_csc. */
+SGL_API int sgl_synth_csc_skewed(sgl_ctx* ctx, uint64_t S, uint64_t inv_density, const double* levels16,
+                  int32_t ngenes, int64_t cell_offset, int32_t ncells_local, int64_t ncells_total,
+                  const double* cell_w16, const double* gene_w16);
 
 /* Shape / size queries. */
 SGL_API int sgl_dims(const sgl_ctx* ctx, int32_t* nrow, int32_t* ncol, int64_t* nnz);

@@ -74,6 +74,8 @@ SIGNATURES = {
     "sgl_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "sgl_upload_csc": (C.c_int, [C.c_void_p] + _CSC + _CSC + [C.c_int32, C.c_int32, C.c_int64, C.c_int64]),
     "sgl_synth_csc": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, f64p, C.c_int32, C.c_int64, C.c_int32, C.c_int64]),
+    "sgl_synth_csc_skewed": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, f64p, C.c_int32, C.c_int64, C.c_int32, C.c_int64,
+                                       f64p, f64p]),
     "sgl_dims": (C.c_int, [C.c_void_p, i32p, i32p, i64p]),
     "sgl_download_csc": (C.c_int, [C.c_void_p, C.c_int, f64p, i32p, i64p]),
     "sgl_log_normalize": (C.c_int, [C.c_void_p, C.c_double]),

@@ -12,6 +12,15 @@ SYNTH_SEED = 0x5EED
 LEVELS16 = np.log1p(1.0 + np.arange(16, dtype=np.float64))
 
 
+def skew_weights16(sigma):
+    """16 log-normal quantile levels exp(sigma * z_q), z_q the normal quantile of (q + 1/2) / 16, scaled to mean 1."""
+    # normal quantiles of (q + 0.5) / 16, q = 0..15 (symmetric)
+    z = np.array([-1.8627318674, -1.3180108973, -1.0099901692, -0.7764217611, -0.5791321623, -0.4022500653, -0.2372021093, -0.0784124127])
+    z = np.concatenate([z, -z[::-1]])
+    w = np.exp(float(sigma) * z)
+    return w / w.mean()
+
+
 def _f(a):
     return np.ascontiguousarray(a, dtype=np.float64)
 
@@ -126,10 +135,16 @@ class Context:
         check(self._L.sgl_upload_csc(self._h, *a, *t, A.nrow, A.ncol, int(cell_offset), int(ncells_total)))
         self.k = 0
 
-    def synth(self, ngenes, ncells_local, inv_density=20, seed=SYNTH_SEED, cell_offset=0, ncells_total=0):
+    def synth(self, ngenes, ncells_local, inv_density=20, seed=SYNTH_SEED, cell_offset=0, ncells_total=0, skew=None):
+        """skew = (sigma_cells, sigma_genes): the skewed generator (log-normal weights per cell and per gene)."""
         lv = _f(LEVELS16)
-        check(self._L.sgl_synth_csc(self._h, seed, inv_density, ptr(lv, f64p), int(ngenes), int(cell_offset),
-                                    int(ncells_local), int(ncells_total)))
+        if skew is None:
+            check(self._L.sgl_synth_csc(self._h, seed, inv_density, ptr(lv, f64p), int(ngenes), int(cell_offset),
+                                        int(ncells_local), int(ncells_total)))
+        else:
+            cw, gw = _f(skew_weights16(skew[0])), _f(skew_weights16(skew[1]))
+            check(self._L.sgl_synth_csc_skewed(self._h, seed, inv_density, ptr(lv, f64p), int(ngenes), int(cell_offset),
+                                               int(ncells_local), int(ncells_total), ptr(cw, f64p), ptr(gw, f64p)))
         self.k = 0
 
     def dims(self):

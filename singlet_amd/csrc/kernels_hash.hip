@@ -41,11 +41,21 @@ int k_mask(hipStream_t s, uint64_t state, uint64_t inv_density, int64_t cell0, i
 // One wave per column.  transposed = 0: column = cell, rows = genes;
 // transposed = 1: column = gene, rows = local cells.  The hash always takes
 // (global cell, gene) in that order (src/singlet.cpp:450).
+//
+// Skewed variant (skew != nullptr; bench.py --data skewed, the secondary record SURVEY.md 8d asks for next to the
+// i.i.d. headline): entry (gene g, cell c) is non-zero iff  u(c, g) < p0 * wc[lc(c)] * wg[lg(g)]  with u the hash
+// mapped to [0, 1), p0 = 1 / inv_density and wc / wg two 16-level weight tables (log-normal quantiles, mean 1)
+// indexed by a hash of the cell / gene index alone: columns AND rows get heavy-tailed non-zero counts, as
+// single-cell count matrices have (pbmc3k: 3 ... 2700 non-zeros per gene).  skew = [wc[16] | wg[16]] on the device.
+__device__ __forceinline__ int synth_level_cell(uint64_t S, uint64_t cell) { return (int)((sgl_rand2(S + 3, cell, 0x5EEDull) >> 11) & 15); }
+__device__ __forceinline__ int synth_level_gene(uint64_t S, uint64_t gene) { return (int)((sgl_rand2(S + 4, 0x5EEDull, gene) >> 11) & 15); }
+
 template <bool FILL>
 __global__ __launch_bounds__(256) void synth_kernel(uint64_t S, SglDiv inv_density, const double* __restrict__ levels,
                                                     int transposed, int64_t cell_offset, int32_t ncells, int32_t ngenes,
                                                     int64_t* __restrict__ counts, const int64_t* __restrict__ p,
-                                                    int32_t* __restrict__ idx, double* __restrict__ x) {
+                                                    int32_t* __restrict__ idx, double* __restrict__ x,
+                                                    const double* __restrict__ skew) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -58,13 +68,22 @@ __global__ __launch_bounds__(256) void synth_kernel(uint64_t S, SglDiv inv_densi
         if (!transposed) xi = sgl_rand_i(S, (uint64_t)(cell_offset + col));
         uint64_t xi1 = 0;
         if (FILL && !transposed) xi1 = sgl_rand_i(S + 1, (uint64_t)(cell_offset + col));
+        double wcol = 0.0;
+        if (skew)
+            wcol = (1.0 / (double)inv_density.d) *
+                   (transposed ? skew[16 + synth_level_gene(S, (uint64_t)col)] : skew[synth_level_cell(S, (uint64_t)(cell_offset + col))]);
         for (int64_t r0 = 0; r0 < nrow; r0 += 64) {
             const int64_t r = r0 + lane;
             bool drawn = false;
             if (r < nrow) {
                 const uint64_t h = transposed ? sgl_rand2(S, (uint64_t)(cell_offset + r), (uint64_t)col)
                                               : sgl_rand_j(xi, (uint64_t)r);
-                drawn = sgl_divides(h, inv_density);
+                if (skew) {
+                    const double wrow = transposed ? skew[synth_level_cell(S, (uint64_t)(cell_offset + r))] : skew[16 + synth_level_gene(S, (uint64_t)r)];
+                    drawn = (double)(h >> 11) * 0x1p-53 < wcol * wrow;   // same product (commutative) in both orientations
+                } else {
+                    drawn = sgl_divides(h, inv_density);
+                }
             }
             const unsigned long long m = __ballot(drawn);
             if (FILL) {
@@ -92,21 +111,22 @@ static unsigned wave_grid(int64_t ncol) {
 }
 
 int k_synth_count(hipStream_t s, uint64_t S, uint64_t inv_density, int transposed, int64_t cell_offset,
-                  int32_t ncells, int32_t ngenes, int64_t* counts) {
+                  int32_t ncells, int32_t ngenes, int64_t* counts, const double* skew_dev) {
     const int64_t ncol = transposed ? ngenes : ncells;
     if (ncol <= 0) return SGL_OK;
     synth_kernel<false><<<dim3(wave_grid(ncol)), dim3(256), 0, s>>>(S, sgl_div_make(inv_density), nullptr, transposed, cell_offset,
-                                                                    ncells, ngenes, counts, nullptr, nullptr, nullptr);
+                                                                    ncells, ngenes, counts, nullptr, nullptr, nullptr, skew_dev);
     HIPCHK(hipGetLastError());
     return SGL_OK;
 }
 
 int k_synth_fill(hipStream_t s, uint64_t S, uint64_t inv_density, const double* levels16_dev, int transposed,
-                 int64_t cell_offset, int32_t ncells, int32_t ngenes, const int64_t* p, int32_t* idx, double* x) {
+                 int64_t cell_offset, int32_t ncells, int32_t ngenes, const int64_t* p, int32_t* idx, double* x,
+                 const double* skew_dev) {
     const int64_t ncol = transposed ? ngenes : ncells;
     if (ncol <= 0) return SGL_OK;
     synth_kernel<true><<<dim3(wave_grid(ncol)), dim3(256), 0, s>>>(S, sgl_div_make(inv_density), levels16_dev, transposed,
-                                                                   cell_offset, ncells, ngenes, nullptr, p, idx, x);
+                                                                   cell_offset, ncells, ngenes, nullptr, p, idx, x, skew_dev);
     HIPCHK(hipGetLastError());
     return SGL_OK;
 }

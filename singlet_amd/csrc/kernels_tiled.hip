@@ -35,6 +35,7 @@
 // the tile range is split over blockIdx.y; each split writes a partial k x ncol
 // slab and acc_tiled_reduce sums the slabs in a fixed order.
 #include "sgl_internal.h"
+#include <hipcub/hipcub.hpp>
 #include <stdlib.h>
 #include <utility>
 #include <type_traits>
@@ -46,7 +47,16 @@
 
 // ---------------------------------------------------------------- build -----
 // groups per (wb, t, pair) and entries per chunk
-__global__ void tiled_count_kernel(const int64_t* __restrict__ seg, int64_t ncol, int T, int64_t nwb,
+// Slot (half h, pair p) of wave block wb holds the column at SORTED position wb * 64 + 2p + h: the columns are taken in
+// the order of descending non-zero count (perm), so the two columns of a pair are neighbours in that order and the
+// runs they are padded to are of similar length whatever the skew of the matrix.
+__device__ __forceinline__ int64_t tiled_slot_col(const int32_t* __restrict__ perm, int64_t ncol, int64_t wb, int h, int p) {
+    const int64_t pos = wb * TILED_CW + 2 * p + h;
+    if (pos >= ncol) return -1;
+    return perm ? (int64_t)perm[pos] : pos;
+}
+
+__global__ void tiled_count_kernel(const int64_t* __restrict__ seg, const int32_t* __restrict__ perm, int64_t ncol, int T, int64_t nwb,
                                    uint8_t* __restrict__ cnt, int64_t* __restrict__ chunk_entries) {
     const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // u = wb * T + t
     if (u >= nwb * T) return;
@@ -56,8 +66,8 @@ __global__ void tiled_count_kernel(const int64_t* __restrict__ seg, int64_t ncol
     for (int p = 0; p < TILED_NP; ++p) {
         int64_t n = 0;
         for (int h = 0; h < 2; ++h) {
-            const int64_t col = wb * TILED_CW + h * TILED_NP + p;
-            if (col < ncol) {
+            const int64_t col = tiled_slot_col(perm, ncol, wb, h, p);
+            if (col >= 0) {
                 const int64_t c = seg[(int64_t)(t + 1) * ncol + col] - seg[(int64_t)t * ncol + col];
                 n = c > n ? c : n;
             }
@@ -72,8 +82,8 @@ __global__ void tiled_count_kernel(const int64_t* __restrict__ seg, int64_t ncol
 
 // one wave per chunk (wb, t): copy / pad the runs of the 32 column pairs
 __global__ __launch_bounds__(256) void tiled_fill_kernel(const double* __restrict__ x, const int32_t* __restrict__ idx,
-                                                         const int64_t* __restrict__ seg, int64_t ncol, int T,
-                                                         int64_t nwb, int TR, int row_bytes,
+                                                         const int64_t* __restrict__ seg, const int32_t* __restrict__ perm,
+                                                         int64_t ncol, int T, int64_t nwb, int TR, int row_bytes,
                                                          const uint8_t* __restrict__ cnt,
                                                          const int64_t* __restrict__ cstart,
                                                          uint32_t* __restrict__ sroff, double* __restrict__ sx,
@@ -91,9 +101,9 @@ __global__ __launch_bounds__(256) void tiled_fill_kernel(const double* __restric
             const int n4 = 4 * (int)cnt[u * TILED_NP + p];
             if (n4 == 0) continue;
             for (int h = 0; h < 2; ++h) {
-                const int64_t col = wb * TILED_CW + h * TILED_NP + p;
+                const int64_t col = tiled_slot_col(perm, ncol, wb, h, p);
                 int64_t a = 0, b = 0;
-                if (col < ncol) { a = seg[(int64_t)t * ncol + col]; b = seg[(int64_t)(t + 1) * ncol + col]; }
+                if (col >= 0) { a = seg[(int64_t)t * ncol + col]; b = seg[(int64_t)(t + 1) * ncol + col]; }
                 for (int q = lane; q < n4; q += 64) {
                     uint32_t ro = 0;
                     double xv = 0.0;
@@ -146,6 +156,7 @@ static int t_reserve(T_** p, size_t* cap, size_t count) {
 
 void sgl_tiled_free(DevTiled& S) {
     if (S.seg) (void)hipFree(S.seg);
+    if (S.perm) (void)hipFree(S.perm);
     if (S.roff) (void)hipFree(S.roff);
     if (S.x) (void)hipFree(S.x);
     if (S.cstart) (void)hipFree(S.cstart);
@@ -155,10 +166,54 @@ void sgl_tiled_free(DevTiled& S) {
     S = DevTiled();
 }
 
+// SGL_TILED_SORT=0 keeps the columns in matrix order (the round-2 layout; kept for A/B measurements and the tests)
+static bool tiled_sort_columns() {
+    const char* e = getenv("SGL_TILED_SORT");
+    return !(e && *e == '0');
+}
+
+__global__ void tiled_col_keys_kernel(const int64_t* __restrict__ p, int64_t ncol, uint32_t* __restrict__ keys, int32_t* __restrict__ iota) {
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < ncol; c += (int64_t)gridDim.x * blockDim.x) {
+        keys[c] = (uint32_t)(p[c + 1] - p[c]);
+        iota[c] = (int32_t)c;
+    }
+}
+
+// S.perm[pos] = column at position pos of the descending-count order
+static int tiled_build_perm(sgl_ctx* c, const DevCSC& M, DevTiled& S) {
+    hipStream_t s = c->stream;
+    const int64_t n = M.ncol;
+    SGLCHK(t_reserve(&S.perm, &S.cap_perm, (size_t)n));
+    uint32_t *keys = nullptr, *keys_out = nullptr;
+    int32_t* iota = nullptr;
+    void* tmp = nullptr;
+    int rc = t_alloc(&keys, (size_t)n);
+    if (rc == SGL_OK) rc = t_alloc(&keys_out, (size_t)n);
+    if (rc == SGL_OK) rc = t_alloc(&iota, (size_t)n);
+    if (rc == SGL_OK && n > 0) {
+        const int64_t blocks = std::min<int64_t>((n + 255) / 256, 4096);
+        tiled_col_keys_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(M.p, n, keys, iota);
+        size_t tmp_bytes = 0;
+        if (hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tmp_bytes, keys, keys_out, iota, S.perm, n, 0, 32, s) != hipSuccess) rc = SGL_EHIP;
+        if (rc == SGL_OK && hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 1) != hipSuccess) { (void)hipGetLastError(); rc = SGL_ENOMEM; }
+        if (rc == SGL_OK && hipcub::DeviceRadixSort::SortPairsDescending(tmp, tmp_bytes, keys, keys_out, iota, S.perm, n, 0, 32, s) != hipSuccess) rc = SGL_EHIP;
+    }
+    const hipError_t e = hipStreamSynchronize(s);
+    if (keys) (void)hipFree(keys);
+    if (keys_out) (void)hipFree(keys_out);
+    if (iota) (void)hipFree(iota);
+    if (tmp) (void)hipFree(tmp);
+    if (rc == SGL_OK && e != hipSuccess) rc = SGL_EHIP;
+    if (rc != SGL_OK) { sgl_set_error("tiled build: sorting the columns by their non-zero count failed"); return rc; }
+    S.perm_nnz = M.nnz;
+    return SGL_OK;
+}
+
 int sgl_tiled_build(sgl_ctx* c, const DevCSC& M, int k, DevTiled& S) {
     hipStream_t s = c->stream;
     // same matrix (any change of it frees the streams), same part size: the stream is still valid
-    if (S.built && S.k == k && S.ncol == M.ncol && S.nrow == M.nrow && S.src_nnz == M.nnz) return SGL_OK;
+    if (S.built && S.k == k && S.ncol == M.ncol && S.nrow == M.nrow && S.src_nnz == M.nnz && (S.perm != nullptr) == tiled_sort_columns())
+        return SGL_OK;
     S.built = false;
     S.xm_mask_t = -1;   // the masked value array follows the stream layout
     S.k = k;
@@ -176,8 +231,16 @@ int sgl_tiled_build(sgl_ctx* c, const DevCSC& M, int k, DevTiled& S) {
     S.src_nnz = M.nnz;
     const int64_t nchunks = S.nwb * S.T;
 
+    // column order of the stream: descending non-zero count (stable: ties in matrix order); depends on the matrix
+    // only, so a rank sweep computes it once
+    int rc = SGL_OK;
+    if (!tiled_sort_columns()) {
+        if (S.perm) { (void)hipFree(S.perm); S.perm = nullptr; S.cap_perm = 0; }
+    } else if (!S.perm || S.perm_nnz != M.nnz || S.cap_perm < (size_t)M.ncol) {
+        rc = tiled_build_perm(c, M, S);
+    }
     // segment starts per (tile, column); kept for the masked value array
-    int rc = t_reserve(&S.seg, &S.cap_seg, (size_t)(S.T + 1) * (size_t)M.ncol);
+    if (rc == SGL_OK) rc = t_reserve(&S.seg, &S.cap_seg, (size_t)(S.T + 1) * (size_t)M.ncol);
     DevCSC tmp = M;
     tmp.tile_rows = TR;
     tmp.ntiles = S.T;
@@ -188,7 +251,7 @@ int sgl_tiled_build(sgl_ctx* c, const DevCSC& M, int k, DevTiled& S) {
     if (rc == SGL_OK) rc = t_reserve(&S.cnt, &S.cap_cnt, (size_t)nchunks * TILED_NP);
     if (rc == SGL_OK) rc = t_reserve(&S.cstart, &S.cap_cstart, (size_t)nchunks + 1);
     if (rc == SGL_OK) {
-        tiled_count_kernel<<<dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, s>>>(S.seg, M.ncol, S.T, S.nwb, S.cnt,
+        tiled_count_kernel<<<dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, s>>>(S.seg, S.perm, M.ncol, S.T, S.nwb, S.cnt,
                                                                                          chunk_entries);
         if (hipGetLastError() != hipSuccess) { sgl_set_error("tiled build: count kernel launch failed"); rc = SGL_EHIP; }
     }
@@ -210,7 +273,7 @@ int sgl_tiled_build(sgl_ctx* c, const DevCSC& M, int k, DevTiled& S) {
     if (rc == SGL_OK && nchunks > 0) {
         int64_t blocks = (nchunks + 3) / 4;
         if (blocks > 256 * 64) blocks = 256 * 64;
-        tiled_fill_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(M.x, M.i, S.seg, M.ncol, S.T, S.nwb, TR, KS * 8,
+        tiled_fill_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(M.x, M.i, S.seg, S.perm, M.ncol, S.T, S.nwb, TR, KS * 8,
                                                                        S.cnt, S.cstart, S.roff, S.x, 0, 0, sgl_div_make(1), 0, 0, 0);
         if (hipGetLastError() != hipSuccess) { sgl_set_error("tiled build: fill kernel launch failed"); rc = SGL_EHIP; }
     }
@@ -261,7 +324,7 @@ int sgl_tiled_mask_values(sgl_ctx* c, const DevCSC& M, DevTiled& S, uint64_t see
         const int KS = (S.k + 1) & ~1;
         int64_t blocks = (nchunks + 3) / 4;
         if (blocks > 256 * 64) blocks = 256 * 64;
-        tiled_fill_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(M.x, M.i, S.seg, M.ncol, S.T, S.nwb, S.TR, KS * 8, S.cnt,
+        tiled_fill_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(M.x, M.i, S.seg, S.perm, M.ncol, S.T, S.nwb, S.TR, KS * 8, S.cnt,
                                                                        S.cstart, nullptr, S.xm, 1, seed, sgl_div_make(inv_density),
                                                                        mask_t, col_off, row_off);
         HIPCHK(hipGetLastError());
@@ -315,7 +378,8 @@ __device__ __forceinline__ void acc_load(int idx4, double& v0, double& v1) {
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) void acc_tiled_kernel(
     const uint32_t* __restrict__ sroff, const double* __restrict__ sx, const int64_t* __restrict__ cstart,
     const uint8_t* __restrict__ cnt, int T, int64_t nwb, const double* __restrict__ F, int k, int TR, int64_t nrow,
-    int tiles_per_range, double* __restrict__ Bout, int64_t ncol, int KS, int ldf, int ldb, int64_t slab) {
+    int tiles_per_range, double* __restrict__ Bout, int64_t ncol, int KS, int ldf, int ldb, int64_t slab,
+    const int32_t* __restrict__ perm) {
     // k = factor rows handled by this launch (a part of the rank when it is above 64), KS = LDS row
     // stride the stream's offsets were built for, ldf / ldb = strides (doubles) between rows of F /
     // columns of the output, slab = doubles between the outputs of two tile ranges (blockIdx.y)
@@ -440,8 +504,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         for (int p = 0; p < TILED_NP; ++p) {
             double v0, v1;
             acc_load(4 * p, v0, v1);
-            const int64_t col = wb * TILED_CW + p + ((lane >> 5) ? TILED_NP : 0);
-            if (col < ncol) {
+            const int64_t col = tiled_slot_col(perm, ncol, wb, lane >> 5, p);
+            if (col >= 0) {
                 if (f < k) out[col * ldb + f] = v0;
                 if (f + 1 < k) out[col * ldb + f + 1] = v1;
             }
@@ -485,7 +549,7 @@ int k_acc_tiled(hipStream_t s, const DevTiled& S, const double* F, int ldf, doub
     const int64_t n = (int64_t)kf * S.ncol;
     acc_tiled_kernel<<<dim3((unsigned)nwg_x, (unsigned)S.R), dim3(64 * TILED_NW), lds, s>>>(
         S.roff, xvals ? xvals : S.x, S.cstart, S.cnt, S.T, S.nwb, F, kf, S.TR, S.nrow, S.tiles_per_range, out, S.ncol, KS, ldf,
-        slabs ? kf : ldb, slabs ? n : 0);
+        slabs ? kf : ldb, slabs ? n : 0, S.perm);
     HIPCHK(hipGetLastError());
     if (slabs) {
         int64_t blocks = (n + 255) / 256;

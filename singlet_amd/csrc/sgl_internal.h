@@ -56,6 +56,9 @@ struct DevTiled {
     uint64_t xm_seed = 0, xm_inv = 0;
     int xm_mask_t = -1;
     int64_t* seg = nullptr;     // [(T + 1) * ncol] first non-zero of column c at or below row t * TR (kept for the masked values)
+    int32_t* perm = nullptr;    // [ncol] column at position pos of the descending-non-zero-count order (nullptr: matrix order)
+    size_t cap_perm = 0;
+    int64_t perm_nnz = -1;      // the matrix (by its non-zero count) perm was computed for
     // The buffers outlive a fit: a rank sweep re-inits the fit tens of times on one matrix, and hipMalloc / hipFree of
     // tens of GB cost up to seconds each at config-5 size.  cap_* = allocated element counts; `built` = the stream
     // content is valid for (k, src_nnz); any change of the matrix frees everything (sgl_tiled_free).
@@ -184,9 +187,10 @@ int k_mask(hipStream_t s, uint64_t state, uint64_t inv_density, int64_t cell0, i
 // counts per column of the synthetic matrix.  transposed = 0: column = cell
 // (rows = genes); 1: column = gene (rows = local cells).
 int k_synth_count(hipStream_t s, uint64_t S, uint64_t inv_density, int transposed, int64_t cell_offset,
-                  int32_t ncells, int32_t ngenes, int64_t* counts);
+                  int32_t ncells, int32_t ngenes, int64_t* counts, const double* skew_dev = nullptr);
 int k_synth_fill(hipStream_t s, uint64_t S, uint64_t inv_density, const double* levels16_dev, int transposed,
-                 int64_t cell_offset, int32_t ncells, int32_t ngenes, const int64_t* p, int32_t* idx, double* x);
+                 int64_t cell_offset, int32_t ncells, int32_t ngenes, const int64_t* p, int32_t* idx, double* x,
+                 const double* skew_dev = nullptr);
 int k_synth_winit(hipStream_t s, uint64_t S, int k, int32_t ngenes, double* W);
 int k_exclusive_scan(sgl_ctx* c, const int64_t* in, int64_t* out, int64_t n);  // out has n+1 entries
 int k_scan_total(hipStream_t s, const int64_t* in, int64_t* out, int64_t n);

@@ -427,8 +427,25 @@ static int sgl_upload_csc_A_only(sgl_ctx* c, const double* Ax, const int32_t* Ai
 
 extern "C" int sgl_synth_csc(sgl_ctx* c, uint64_t S, uint64_t inv_density, const double* levels16, int32_t ngenes,
                              int64_t cell_offset, int32_t ncells_local, int64_t ncells_total) {
+    return sgl_synth_csc_skewed(c, S, inv_density, levels16, ngenes, cell_offset, ncells_local, ncells_total, nullptr, nullptr);
+}
+
+extern "C" int sgl_synth_csc_skewed(sgl_ctx* c, uint64_t S, uint64_t inv_density, const double* levels16, int32_t ngenes,
+                                    int64_t cell_offset, int32_t ncells_local, int64_t ncells_total, const double* cell_w16,
+                                    const double* gene_w16) {
     CTX_GUARD(c);
     if (!levels16 || ngenes <= 0 || ncells_local <= 0 || inv_density == 0) { sgl_set_error("sgl_synth_csc: bad arguments"); return SGL_EINVAL; }
+    if ((cell_w16 == nullptr) != (gene_w16 == nullptr)) { sgl_set_error("sgl_synth_csc_skewed: both weight tables or neither"); return SGL_EINVAL; }
+    double* skew = nullptr;
+    if (cell_w16) {
+        double tab[32];
+        for (int q = 0; q < 16; ++q) { tab[q] = cell_w16[q]; tab[16 + q] = gene_w16[q]; }
+        for (int q = 0; q < 32; ++q)
+            if (!(tab[q] >= 0.0)) { sgl_set_error("sgl_synth_csc_skewed: weights must be >= 0"); return SGL_EINVAL; }
+        SGLCHK(dev_alloc(&skew, 32));
+        HIPCHK(hipMemcpy(skew, tab, sizeof(tab), hipMemcpyHostToDevice));
+    }
+    struct SkewFree { double* p; ~SkewFree() { if (p) (void)hipFree(p); } } skew_free{skew};
     free_fit(c);
     free_matrix(c);
     c->cell_offset = cell_offset;
@@ -443,7 +460,7 @@ extern "C" int sgl_synth_csc(sgl_ctx* c, uint64_t S, uint64_t inv_density, const
         int64_t* counts = nullptr;
         SGLCHK(dev_alloc(&counts, (size_t)M.ncol));
         SGLCHK(dev_alloc(&M.p, (size_t)M.ncol + 1));
-        SGLCHK(k_synth_count(c->stream, S, inv_density, tr, cell_offset, ncells_local, ngenes, counts));
+        SGLCHK(k_synth_count(c->stream, S, inv_density, tr, cell_offset, ncells_local, ngenes, counts, skew));
         SGLCHK(k_exclusive_scan(c, counts, M.p, M.ncol));
         SGLCHK(k_scan_total(c->stream, counts, M.p, M.ncol));
         int64_t nnz = 0;
@@ -453,7 +470,7 @@ extern "C" int sgl_synth_csc(sgl_ctx* c, uint64_t S, uint64_t inv_density, const
         M.nnz = nnz;
         SGLCHK(dev_alloc(&M.x, (size_t)nnz));
         SGLCHK(dev_alloc(&M.i, (size_t)nnz));
-        SGLCHK(k_synth_fill(c->stream, S, inv_density, lv, tr, cell_offset, ncells_local, ngenes, M.p, M.i, M.x));
+        SGLCHK(k_synth_fill(c->stream, S, inv_density, lv, tr, cell_offset, ncells_local, ngenes, M.p, M.i, M.x, skew));
     }
     HIPCHK(hipStreamSynchronize(c->stream));
     dev_free(lv);
