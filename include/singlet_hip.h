@@ -260,6 +260,11 @@ SGL_API int sgl_download_csc(sgl_ctx* ctx, int which, double* x, int32_t* i, int
  *   (all-reduce hook). */
 SGL_API int sgl_log_normalize(sgl_ctx* ctx, double scale_factor);
 SGL_API int sgl_weight_by_split(sgl_ctx* ctx, const int32_t* split_by, int32_t n_groups);
+/* The one-shot form the Rcpp glue binds (`_singlet_weight_by_split`, src/RcppExports.cpp:17-27, 445; called from
+ * R/RunNMF.R:86-93): dgCMatrix slots in, the re-weighted values out.  x_out (nnz doubles) may be the x slot itself:
+ * the reference rewrites the values of A in place (src/singlet.cpp:136-141). */
+SGL_API int sgl_c_weight_by_split(const double* Ax, const int32_t* Ai, const int32_t* Ap, int32_t nrow, int32_t ncol,
+                                  const int32_t* split_by, int32_t n_groups, double* x_out);
 
 /* Start a fit at rank k.  w_init: k x nrow host array, or NULL to fill W on
  * the device with the synthetic init ((rand_{S+2}(f,g) >> 11) + 0.5) * 2^-53.

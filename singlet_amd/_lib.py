@@ -80,6 +80,7 @@ SIGNATURES = {
     "sgl_download_csc": (C.c_int, [C.c_void_p, C.c_int, f64p, i32p, i64p]),
     "sgl_log_normalize": (C.c_int, [C.c_void_p, C.c_double]),
     "sgl_weight_by_split": (C.c_int, [C.c_void_p, i32p, C.c_int32]),
+    "sgl_c_weight_by_split": (C.c_int, _CSC + [C.c_int32, C.c_int32, i32p, C.c_int32, f64p]),
     "sgl_fit_init": (C.c_int, [C.c_void_p, C.c_int32, f64p, C.c_uint64]),
     "sgl_set_links": (C.c_int, [C.c_void_p, f64p, C.c_int32, C.c_int32, f64p, C.c_int32, C.c_int32]),
     "sgl_set_allreduce": (C.c_int, [C.c_void_p, ALLREDUCE_FN, C.c_void_p]),

@@ -346,7 +346,14 @@ def PreprocessData(A, scale_factor=10000.0):
 def weight_by_split(A_, split_by, n_groups):
     """.Call(`_singlet_weight_by_split`, A_, split_by, n_groups)  (src/singlet.cpp:119-144):
     returns a rescaled copy; split_by is the 0-based group of every column (R/RunNMF.R:86)."""
-    return _staged(A_, lambda c: c.weight_by_split(split_by, n_groups))
+    A = as_dgCMatrix(A_)
+    sb = np.ascontiguousarray(split_by, dtype=np.int32)
+    if sb.shape[0] != A.ncol:
+        raise ValueError("split_by needs one entry per column of A")
+    x = np.empty(A.nnz, dtype=np.float64)
+    check(_lib.load().sgl_c_weight_by_split(ptr(A.x, f64p), ptr(A.i, i32p), ptr(A.p, i32p), A.nrow, A.ncol, ptr(sb, i32p),
+                                            int(n_groups), ptr(x, f64p)))
+    return dgCMatrix(x, A.i, A.p, A.Dim, A.Dimnames)
 
 
 def project_model(A, w, L1=0.01, L2=0, threads=0):

@@ -198,7 +198,17 @@ static int tiled_build_perm(sgl_ctx* c, const DevCSC& M, DevTiled& S) {
         if (rc == SGL_OK && hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 1) != hipSuccess) { (void)hipGetLastError(); rc = SGL_ENOMEM; }
         if (rc == SGL_OK && hipcub::DeviceRadixSort::SortPairsDescending(tmp, tmp_bytes, keys, keys_out, iota, S.perm, n, 0, 32, s) != hipSuccess) rc = SGL_EHIP;
     }
+    // share of the non-zeros held by the heaviest workgroup's columns (the first 8 x 64 of the order): the tile-range
+    // split below sizes its work units by it
+    uint32_t top[TILED_NW * TILED_CW];
+    const int64_t ntop = std::min<int64_t>(n, TILED_NW * TILED_CW);
+    if (rc == SGL_OK && ntop > 0 && hipMemcpyAsync(top, keys_out, sizeof(uint32_t) * (size_t)ntop, hipMemcpyDeviceToHost, s) != hipSuccess) rc = SGL_EHIP;
     const hipError_t e = hipStreamSynchronize(s);
+    if (rc == SGL_OK && e == hipSuccess) {
+        int64_t tn = 0;
+        for (int64_t q = 0; q < ntop; ++q) tn += top[q];
+        S.top_share = M.nnz > 0 ? (double)tn / (double)M.nnz : 0.0;
+    }
     if (keys) (void)hipFree(keys);
     if (keys_out) (void)hipFree(keys_out);
     if (iota) (void)hipFree(iota);
@@ -278,12 +288,18 @@ int sgl_tiled_build(sgl_ctx* c, const DevCSC& M, int k, DevTiled& S) {
         if (hipGetLastError() != hipSuccess) { sgl_set_error("tiled build: fill kernel launch failed"); rc = SGL_EHIP; }
     }
     // split of the tile range over blockIdx.y so that the grid fills 256 CUs (1 workgroup per CU)
+    // Two reasons to split: too few column groups to fill the chip (W-update: 30 k genes = 59 workgroups), and -- with
+    // the columns sorted by count -- a heaviest workgroup that alone would outlast the average CU's whole share (skewed
+    // genes: the top 512 of 30 000 held 11 % of the non-zeros and the pass took 22 ms instead of 11): its tile range is
+    // cut until one unit is about a third of a CU's share; workgroups are dispatched heaviest first.
     const int64_t nwg_x = (S.nwb + TILED_NW - 1) / TILED_NW;
     int R = 1;
-    if (nwg_x < 1024) {
+    const int r_fill = nwg_x < 1024 ? (int)std::max<int64_t>(1, (512 + nwg_x - 1) / nwg_x) : 1;
+    const int r_bal = S.perm ? (int)std::min<double>(256.0, ceil(S.top_share * 256.0 / 0.35)) : 1;
+    if (std::max(r_fill, r_bal) > 1) {
         double best = -1.0;
-        const int rmin = (int)std::max<int64_t>(1, (512 + nwg_x - 1) / nwg_x);
-        for (int r = rmin; r <= std::min<int64_t>(S.T, 4 * rmin); ++r) {
+        const int rmin = (int)std::min<int64_t>(std::max(r_fill, r_bal), std::max(1, S.T));
+        for (int r = rmin; r <= std::min<int64_t>(S.T, r_bal > r_fill ? rmin + rmin / 4 + 4 : 4 * rmin); ++r) {
             const int tpr = (S.T + r - 1) / r;
             const int reff = (S.T + tpr - 1) / tpr;  // ranges actually non-empty
             const double wgs = (double)nwg_x * reff;
@@ -291,6 +307,7 @@ int sgl_tiled_build(sgl_ctx* c, const DevCSC& M, int k, DevTiled& S) {
             if (eff > best + 1e-9) { best = eff; R = reff; }
         }
     }
+    S.range_fastest = r_bal > r_fill;
     S.tiles_per_range = (S.T + R - 1) / R;
     S.R = (S.T + S.tiles_per_range - 1) / S.tiles_per_range;
     if (rc == SGL_OK && S.R > 1) rc = t_reserve(&S.part, &S.cap_part, (size_t)S.R * (size_t)k * (size_t)M.ncol);
@@ -379,7 +396,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const uint32_t* __restrict__ sroff, const double* __restrict__ sx, const int64_t* __restrict__ cstart,
     const uint8_t* __restrict__ cnt, int T, int64_t nwb, const double* __restrict__ F, int k, int TR, int64_t nrow,
     int tiles_per_range, double* __restrict__ Bout, int64_t ncol, int KS, int ldf, int ldb, int64_t slab,
-    const int32_t* __restrict__ perm) {
+    const int32_t* __restrict__ perm, int range_fastest) {
     // k = factor rows handled by this launch (a part of the rank when it is above 64), KS = LDS row
     // stride the stream's offsets were built for, ldf / ldb = strides (doubles) between rows of F /
     // columns of the output, slab = doubles between the outputs of two tile ranges (blockIdx.y)
@@ -388,8 +405,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     double* tile = reinterpret_cast<double*>(smem);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t wb = (int64_t)blockIdx.x * TILED_NW + wave;
-    const int t0 = blockIdx.y * tiles_per_range;
+    // work units in the order (column group, tile range), the range running fastest: the column groups come heaviest
+    // first (sorted columns), so the longest units are dispatched first whatever the number of ranges
+    // (only when the split was sized by that imbalance: otherwise the column groups run fastest, so that the
+    // workgroups resident on one XCD stage the SAME factor tiles at about the same time and share them in its L2)
+    unsigned bx = blockIdx.x, by = blockIdx.y;
+    if (range_fastest) {
+        const unsigned unit = blockIdx.x + gridDim.x * blockIdx.y, nranges = gridDim.y;
+        bx = unit / nranges;
+        by = unit - bx * nranges;
+    }
+    const int64_t wb = (int64_t)bx * TILED_NW + wave;
+    const int t0 = by * tiles_per_range;
     const int t1 = (t0 + tiles_per_range < T) ? (t0 + tiles_per_range) : T;
     const bool wact = wb < nwb;
     typedef __attribute__((address_space(3))) char lds_char;
@@ -499,7 +526,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     // they write the ring registers v64..v75 only, which nothing below touches
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (wact) {
-        double* out = Bout + (size_t)blockIdx.y * (size_t)slab;
+        double* out = Bout + (size_t)by * (size_t)slab;
         const int f = 2 * (lane & 31);
         for (int p = 0; p < TILED_NP; ++p) {
             double v0, v1;
@@ -549,7 +576,7 @@ int k_acc_tiled(hipStream_t s, const DevTiled& S, const double* F, int ldf, doub
     const int64_t n = (int64_t)kf * S.ncol;
     acc_tiled_kernel<<<dim3((unsigned)nwg_x, (unsigned)S.R), dim3(64 * TILED_NW), lds, s>>>(
         S.roff, xvals ? xvals : S.x, S.cstart, S.cnt, S.T, S.nwb, F, kf, S.TR, S.nrow, S.tiles_per_range, out, S.ncol, KS, ldf,
-        slabs ? kf : ldb, slabs ? n : 0, S.perm);
+        slabs ? kf : ldb, slabs ? n : 0, S.perm, S.range_fastest ? 1 : 0);
     HIPCHK(hipGetLastError());
     if (slabs) {
         int64_t blocks = (n + 255) / 256;

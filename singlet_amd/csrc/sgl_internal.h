@@ -59,6 +59,8 @@ struct DevTiled {
     int32_t* perm = nullptr;    // [ncol] column at position pos of the descending-non-zero-count order (nullptr: matrix order)
     size_t cap_perm = 0;
     int64_t perm_nnz = -1;      // the matrix (by its non-zero count) perm was computed for
+    bool range_fastest = false; // work units ordered (column group, tile range) instead of (tile range, column group)
+    double top_share = 0.0;     // share of the non-zeros in the first 512 columns of that order (the heaviest workgroup)
     // The buffers outlive a fit: a rank sweep re-inits the fit tens of times on one matrix, and hipMalloc / hipFree of
     // tens of GB cost up to seconds each at config-5 size.  cap_* = allocated element counts; `built` = the stream
     // content is valid for (k, src_nnz); any change of the matrix frees everything (sgl_tiled_free).

@@ -570,6 +570,21 @@ extern "C" int sgl_weight_by_split(sgl_ctx* c, const int32_t* split_by, int32_t 
     return rc;
 }
 
+static int current_device_or_zero();
+// One-shot form for the Rcpp glue (`_singlet_weight_by_split`, src/RcppExports.cpp:17-27): the dgCMatrix slots in,
+// the re-weighted values out (x_out may alias Ax: the reference rewrites the values of A in place, l.136-141).
+extern "C" int sgl_c_weight_by_split(const double* Ax, const int32_t* Ai, const int32_t* Ap, int32_t nrow, int32_t ncol,
+                                     const int32_t* split_by, int32_t n_groups, double* x_out) {
+    if (!x_out) { sgl_set_error("sgl_c_weight_by_split: NULL output"); return SGL_EINVAL; }
+    sgl_ctx* c = nullptr;
+    SGLCHK(sgl_create(current_device_or_zero(), &c));
+    int rc = sgl_upload_csc_A_only(c, Ax, Ai, Ap, nrow, ncol);
+    if (rc == SGL_OK) rc = sgl_weight_by_split(c, split_by, n_groups);
+    if (rc == SGL_OK) rc = sgl_download_csc(c, 0, x_out, nullptr, nullptr);
+    sgl_destroy(c);
+    return rc;
+}
+
 // Genes per rank block of a native team (multi.hip): the W-side solve is dealt out in contiguous gene
 // blocks of this many columns (the last ranks' blocks may be partly or wholly past the end).
 static int64_t team_gene_block(const sgl_ctx* c) {

@@ -388,7 +388,20 @@ SEXP _singlet_c_ard_nmf_dense(SEXP A_, SEXP At_, SEXP tol_, SEXP maxit_, SEXP ve
     return out;
 }
 
+/* ---- weight_by_split(A_, split_by, n_groups)  (src/singlet.cpp:118-144; R/RunNMF.R:86-93) ----
+ * The reference rewrites the x slot of A_ in place and returns the same S4 object (R forces a private copy of A@x
+ * before the call, R/RunNMF.R:90-92); so does this. */
+SEXP _singlet_weight_by_split(SEXP A_, SEXP split_by_, SEXP n_groups_) {
+    dgc_view A = view_dgc(A_, "A");
+    if (TYPEOF(split_by_) != INTSXP || XLENGTH(split_by_) != A.ncol) Rf_error("split_by must be an integer vector with one entry per column of A");
+    SEXP x = R_do_slot(A_, Rf_install("x"));
+    int rc = sgl_c_weight_by_split(A.x, A.i, A.p, A.nrow, A.ncol, INTEGER(split_by_), Rf_asInteger(n_groups_), REAL(x));
+    fail_if(rc);
+    return A_;
+}
+
 static const R_CallMethodDef call_entries[] = {
+    {"_singlet_weight_by_split", (DL_FUNC)&_singlet_weight_by_split, 3},
     {"_singlet_c_nmf", (DL_FUNC)&_singlet_c_nmf, 11},
     {"_singlet_c_ard_nmf", (DL_FUNC)&_singlet_c_ard_nmf, 13},
     {"_singlet_c_linked_nmf", (DL_FUNC)&_singlet_c_linked_nmf, 11},
