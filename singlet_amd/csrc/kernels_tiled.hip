@@ -298,7 +298,8 @@ int sgl_tiled_build(sgl_ctx* c, const DevCSC& M, int k, DevTiled& S) {
     const int r_bal = S.perm ? (int)std::min<double>(256.0, ceil(S.top_share * 256.0 / 0.35)) : 1;
     if (std::max(r_fill, r_bal) > 1) {
         double best = -1.0;
-        const int rmin = (int)std::min<int64_t>(std::max(r_fill, r_bal), std::max(1, S.T));
+        // (a fill factor beyond the tile count leaves the range whole, as it always did: such a matrix is tiny)
+        const int rmin = std::max(r_fill, (int)std::min<int64_t>(r_bal, std::max(1, S.T)));
         for (int r = rmin; r <= std::min<int64_t>(S.T, r_bal > r_fill ? rmin + rmin / 4 + 4 : 4 * rmin); ++r) {
             const int tpr = (S.T + r - 1) / r;
             const int reff = (S.T + tpr - 1) / tpr;  // ranges actually non-empty
