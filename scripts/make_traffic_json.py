@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/traffic.json from the FETCH_SIZE / WRITE_SIZE summaries of scripts/prof_r2.sh
+"""profiles/traffic.json from the FETCH_SIZE / WRITE_SIZE summaries of scripts/prof_r3.sh
 (usage: make_traffic_json.py fetch.csv write.csv bench.json out.json; bench.json = the JSON line the profiled
 bench run printed: its entry-stream layout is stored next to the bytes, and bench.py reports the bytes only
 for a run with the same workload AND layout).
@@ -36,6 +36,6 @@ for (kern, gy), v in f.items():
 json.dump({"workload": {"genes": 30000, "cells": 1000000, "k": 50, "inv_density": 20},
            "layout": layouts,
            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python3 bench.py --steps 2 --warmup 1 "
-                     "--no-cpu-baseline`, scripts/prof_r2.sh; per launch of acc_tiled_kernel, averaged over its dispatches",
+                     "--no-cpu-baseline`, scripts/prof_r3.sh; per launch of acc_tiled_kernel, averaged over its dispatches",
            "bytes_per_launch": res}, open(out, "w"), indent=1)
 print(open(out).read())
