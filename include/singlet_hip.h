@@ -23,8 +23,10 @@
  *    outputs go to caller-allocated buffers.
  *  - all arithmetic on the path is FP64 on the GPU; there is no CPU fallback:
  *    without a usable gfx950 device every entry point fails with SGL_ENODEV.
- *  - rank limits: c_nmf / c_project_model k <= 256 (fast paths up to 128); the masked
- *    (c_ard_nmf*) entry points k <= 128, refused with SGL_EINVAL before any upload.
+ *  - ranks: every entry point takes 1 <= k <= 1024 (SGL_EINVAL above, before anything is uploaded; the
+ *    reference's nnls / predict_mask have no limit, src/singlet.cpp:229-250, 436-466).  The tuned kernels cover
+ *    k <= 128 (LDS-tiled accumulate, MFMA Grams and Gram downdates, lane NNLS); above that generic kernels run
+ *    (plain CSC accumulate, wave-per-column NNLS, VALU Grams in several launches): correct, several times slower.
  *  - several GPUs: section 2b; the one-shot sgl_c_nmf / sgl_c_ard_nmf honour SINGLET_NGPU.
  */
 #ifndef SINGLET_HIP_H
@@ -101,8 +103,7 @@ SGL_API int sgl_cache_release(void);
  * Replaces _singlet_c_ard_nmf (src/RcppExports.cpp:284-304).
  * Trace arrays (test_mse, iter, tol, score_overfit) must hold maxit + 1
  * entries; *n_trace receives their used length (the reference returns them as
- * R vectors, src/singlet.cpp:1144-1151).  The masked path supports ranks k <= 128
- * (SGL_EINVAL above, before anything is uploaded). */
+ * R vectors, src/singlet.cpp:1144-1151).  Ranks as in the header's preamble (k <= 1024). */
 SGL_API int sgl_c_ard_nmf(const double* Ax, const int32_t* Ai, const int32_t* Ap,
                   const double* Atx, const int32_t* Ati, const int32_t* Atp,
                   int32_t nrow, int32_t ncol,

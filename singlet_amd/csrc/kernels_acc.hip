@@ -111,13 +111,13 @@ static int launch_acc(hipStream_t s, const DevCSC& M, int tile, const double* F,
     const int accumulate = tile > 0;
     dim3 g((unsigned)blocks), b(256);
 #define SGL_ACC(RR) acc_kernel<RR, MASK><<<g, b, 0, s>>>(M.x, M.i, lo, hi, M.ncol, F, k, B, accumulate, seed, sgl_div_make(inv_density), col_off, row_off)
-    switch (R) {
-        case 1: SGL_ACC(1); break;
-        case 2: SGL_ACC(2); break;
-        case 3: SGL_ACC(3); break;
-        case 4: SGL_ACC(4); break;
-        default: sgl_set_error("k_acc: k=%d too large", k); return SGL_EINVAL;
-    }
+    if (R == 1) SGL_ACC(1);
+    else if (R == 2) SGL_ACC(2);
+    else if (R == 3) SGL_ACC(3);
+    else if (R == 4) SGL_ACC(4);
+    else if (R <= 8) SGL_ACC(8);       // ranks above 256: the generic instances (SGL_MAX_K = 1024)
+    else if (R <= 16) SGL_ACC(16);
+    else { sgl_set_error("k_acc: k=%d too large", k); return SGL_EINVAL; }
 #undef SGL_ACC
     HIPCHK(hipGetLastError());
     return SGL_OK;

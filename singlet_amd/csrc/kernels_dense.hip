@@ -149,9 +149,11 @@ __global__ __launch_bounds__(256) void gram_mfma_split_kernel(const double* __re
     }
 }
 
-// generic VALU fallback for k > 64 (NT > 4 would need > 10 accumulator tiles).
+// generic VALU fallback for k > 128: each launch forms the entries [pair0, pair0 + 256 * GV_MAXP) of the k x k
+// product (a rank above 256 takes several launches, each reading F again: the slow, any-rank path).
+#define GV_MAXP 256
 __global__ __launch_bounds__(256) void gram_valu_kernel(const double* __restrict__ F, int k, int64_t cols,
-                                                        int64_t cols_per_block, double* __restrict__ part) {
+                                                        int64_t cols_per_block, double* __restrict__ part, int pair0) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double* tile = reinterpret_cast<double*>(smem_raw);  // [TC][k]
     constexpr int TC = 16;
@@ -159,17 +161,17 @@ __global__ __launch_bounds__(256) void gram_valu_kernel(const double* __restrict
     int64_t c_end = c_begin + cols_per_block;
     if (c_end > cols) c_end = cols;
     const int npairs = k * k;
-    constexpr int MAXP = (SGL_MAX_K * SGL_MAX_K + 255) / 256;
-    double acc[MAXP];
+    const int pend = (pair0 + 256 * GV_MAXP < npairs) ? pair0 + 256 * GV_MAXP : npairs;
+    double acc[GV_MAXP];
 #pragma unroll 1
-    for (int q = 0; q < MAXP; ++q) acc[q] = 0.0;
+    for (int q = 0; q < GV_MAXP; ++q) acc[q] = 0.0;
     for (int64_t c0 = c_begin; c0 < c_end; c0 += TC) {
         const int nc = (int)((c_end - c0 < TC) ? (c_end - c0) : TC);
         __syncthreads();
         for (int e = threadIdx.x; e < nc * k; e += 256) tile[e] = F[c0 * k + e];
         __syncthreads();
         int q = 0;
-        for (int pr = threadIdx.x; pr < npairs; pr += 256, ++q) {
+        for (int pr = pair0 + (int)threadIdx.x; pr < pend; pr += 256, ++q) {
             const int i = pr % k, j = pr / k;
             double a = acc[q];
             for (int cc = 0; cc < nc; ++cc) a = fma(tile[cc * k + i], tile[cc * k + j], a);
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(256) void gram_valu_kernel(const double* __restrict
     }
     double* out = part + (size_t)blockIdx.x * k * k;
     int q = 0;
-    for (int pr = threadIdx.x; pr < npairs; pr += 256, ++q) out[pr] = acc[q];
+    for (int pr = pair0 + (int)threadIdx.x; pr < pend; pr += 256, ++q) out[pr] = acc[q];
 }
 
 __global__ void gram_reduce_kernel(const double* __restrict__ part, int nblocks, int k, double diag_add,
@@ -196,6 +198,7 @@ int k_gram(sgl_ctx* c, const double* F, int k, int64_t cols, double* G, double d
     if (k <= 0 || k > SGL_MAX_K) { sgl_set_error("k_gram: k=%d out of range", k); return SGL_EINVAL; }
     int nblocks = (int)((cols + 1023) / 1024);
     if (nblocks > 1024) nblocks = 1024;
+    if (k > 128 && nblocks > 128) nblocks = 128;   // generic path: k x k doubles of workspace per block
     if (nblocks < 1) nblocks = 1;
     int64_t cpb = (cols + nblocks - 1) / nblocks;
     cpb = (cpb + 15) / 16 * 16;  // whole 16-column steps per block
@@ -212,7 +215,12 @@ int k_gram(sgl_ctx* c, const double* F, int k, int64_t cols, double* G, double d
     else if (NT == 6) gram_mfma_split_kernel<6><<<dim3(nblocks), dim3(256), 0, s>>>(F, k, cols, cpb, c->ws);
     else if (NT == 7) gram_mfma_split_kernel<7><<<dim3(nblocks), dim3(256), 0, s>>>(F, k, cols, cpb, c->ws);
     else if (NT == 8) gram_mfma_split_kernel<8><<<dim3(nblocks), dim3(256), 0, s>>>(F, k, cols, cpb, c->ws);
-    else gram_valu_kernel<<<dim3(nblocks), dim3(256), sizeof(double) * 16 * k, s>>>(F, k, cols, cpb, c->ws);
+    else {
+        const size_t lds = sizeof(double) * 16 * (size_t)k;
+        if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_valu_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+        for (int pair0 = 0; pair0 < k * k; pair0 += 256 * GV_MAXP)
+            gram_valu_kernel<<<dim3(nblocks), dim3(256), lds, s>>>(F, k, cols, cpb, c->ws, pair0);
+    }
     HIPCHK(hipGetLastError());
     gram_reduce_kernel<<<dim3((k * k + 255) / 256), dim3(256), 0, s>>>(c->ws, nblocks, k, diag_add, G);
     HIPCHK(hipGetLastError());

@@ -24,7 +24,10 @@ __global__ __launch_bounds__(256) void mask_gram_kernel(int64_t col0, int64_t nc
                                                         const int64_t* __restrict__ col_nnz,
                                                         const double* __restrict__ F, const double* __restrict__ G,
                                                         int k, uint64_t seed, SglDiv inv_density, int mask_t,
-                                                        int64_t col_off, int64_t row_off, double* __restrict__ Gout, int raw) {
+                                                        int64_t col_off, int64_t row_off, double* __restrict__ Gout, int raw,
+                                                        int pair0) {
+    // pair0: first lower-triangle pair of this launch (ranks whose triangle exceeds 256 * PMAX pairs take several
+    // launches, each hashing the rows again: the slow, any-rank path)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     int* list = reinterpret_cast<int*>(smem_raw);                 // [256] drawn rows of the current chunk
     int* wcount = list + 256;                                      // [4] per-wave counts (+pad to 8 ints)
@@ -41,7 +44,7 @@ __global__ __launch_bounds__(256) void mask_gram_kernel(int64_t col0, int64_t nc
     double acc[PMAX];
 #pragma unroll
     for (int q = 0; q < PMAX; ++q) {
-        const int p = tid + 256 * q;
+        const int p = pair0 + tid + 256 * q;
         pi[q] = 0; pj[q] = 0; acc[q] = 0.0;
         if (p < npairs) tri_unrank(p, pi[q], pj[q]);
     }
@@ -71,7 +74,7 @@ __global__ __launch_bounds__(256) void mask_gram_kernel(int64_t col0, int64_t nc
             __syncthreads();
 #pragma unroll
             for (int q = 0; q < PMAX; ++q) {
-                if (tid + 256 * q < npairs) {
+                if (pair0 + tid + 256 * q < npairs) {
                     double a = acc[q];
                     for (int t = 0; t < nb; ++t) a = fma(tile[t * k + pi[q]], tile[t * k + pj[q]], a);
                     acc[q] = a;
@@ -82,7 +85,7 @@ __global__ __launch_bounds__(256) void mask_gram_kernel(int64_t col0, int64_t nc
     }
 #pragma unroll
     for (int q = 0; q < PMAX; ++q) {
-        if (tid + 256 * q < npairs) {
+        if (pair0 + tid + 256 * q < npairs) {
             const int i = pi[q], j = pj[q];
             double sub = acc[q];
             if (i == j && !raw) sub += 1e-15;  // AAt(wsub) adds it too (quirk 8)
@@ -343,12 +346,14 @@ int k_mask_gram_cols(hipStream_t s, int64_t col0, int64_t ncols, int32_t nrow, c
     const int npairs = k * (k + 1) / 2;
     const int P = (npairs + 255) / 256;
     const size_t smem = 264 * 4 + sizeof(double) * 16 * (size_t)k;
-#define SGL_MG(PM) mask_gram_kernel<PM><<<g, b, smem, s>>>(col0, ncols, nrow, col_nnz, F, G, k, seed, sgl_div_make(inv_density), mask_t, col_offset, row_offset, Gcols, raw)
-    if (P <= 4) SGL_MG(4);
-    else if (P <= 9) SGL_MG(9);
-    else if (P <= 20) SGL_MG(20);
-    else if (P <= 33) SGL_MG(33);
-    else { sgl_set_error("masked path supports k <= 128 (got %d)", k); return SGL_EINVAL; }
+#define SGL_MG(PM, P0) mask_gram_kernel<PM><<<g, b, smem, s>>>(col0, ncols, nrow, col_nnz, F, G, k, seed, sgl_div_make(inv_density), mask_t, col_offset, row_offset, Gcols, raw, P0)
+    if (P <= 4) SGL_MG(4, 0);
+    else if (P <= 9) SGL_MG(9, 0);
+    else if (P <= 20) SGL_MG(20, 0);
+    else {
+        if (smem > 48 * 1024) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mask_gram_kernel<33>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+        for (int p0 = 0; p0 < npairs; p0 += 256 * 33) SGL_MG(33, p0);   // k > 128: one launch per 8448 pairs of the triangle
+    }
 #undef SGL_MG
     HIPCHK(hipGetLastError());
     return SGL_OK;
@@ -517,9 +522,12 @@ int k_mse_test(sgl_ctx* c, const double* Wd, const double* H, int k, uint64_t se
     else if (k <= 128)
         mse_test_kernel<2><<<dim3((unsigned)blocks), dim3(256), 0, c->stream>>>(c->A.x, c->A.i, c->A.p, c->A.nrow, n, c->cell_offset,
                                                                                 Wd, H, k, seed, sgl_div_make(inv_density), losses);
-    else
+    else if (k <= 256)
         mse_test_kernel<4><<<dim3((unsigned)blocks), dim3(256), 0, c->stream>>>(c->A.x, c->A.i, c->A.p, c->A.nrow, n, c->cell_offset,
                                                                                 Wd, H, k, seed, sgl_div_make(inv_density), losses);
+    else
+        mse_test_kernel<16><<<dim3((unsigned)blocks), dim3(256), 0, c->stream>>>(c->A.x, c->A.i, c->A.p, c->A.nrow, n, c->cell_offset,
+                                                                                 Wd, H, k, seed, sgl_div_make(inv_density), losses);
     HIPCHK(hipGetLastError());
     sum_partial_kernel<<<dim3(nblocks), dim3(256), 0, c->stream>>>(losses, n, part);
     HIPCHK(hipGetLastError());

@@ -343,7 +343,11 @@ int k_nnls_wave(hipStream_t s, const double* G, int64_t gstride, const double* B
         case 1: nnls_wave_kernel<1><<<g, b, 0, s>>>(G, gstride, B, X, col_nnz, k, ncols, L1, L2, sweep_counter); break;
         case 2: nnls_wave_kernel<2><<<g, b, 0, s>>>(G, gstride, B, X, col_nnz, k, ncols, L1, L2, sweep_counter); break;
         case 3: nnls_wave_kernel<3><<<g, b, 0, s>>>(G, gstride, B, X, col_nnz, k, ncols, L1, L2, sweep_counter); break;
-        default: nnls_wave_kernel<4><<<g, b, 0, s>>>(G, gstride, B, X, col_nnz, k, ncols, L1, L2, sweep_counter); break;
+        case 4: nnls_wave_kernel<4><<<g, b, 0, s>>>(G, gstride, B, X, col_nnz, k, ncols, L1, L2, sweep_counter); break;
+        default:   // ranks above 256 (the reference has no limit; SGL_MAX_K = 1024)
+            if (R <= 8) nnls_wave_kernel<8><<<g, b, 0, s>>>(G, gstride, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
+            else nnls_wave_kernel<16><<<g, b, 0, s>>>(G, gstride, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
+            break;
     }
     HIPCHK(hipGetLastError());
     return SGL_OK;

@@ -295,7 +295,10 @@ int sgl_tiled_build(sgl_ctx* c, const DevCSC& M, int k, DevTiled& S) {
     const int64_t nwg_x = (S.nwb + TILED_NW - 1) / TILED_NW;
     int R = 1;
     const int r_fill = nwg_x < 1024 ? (int)std::max<int64_t>(1, (512 + nwg_x - 1) / nwg_x) : 1;
-    const int r_bal = S.perm ? (int)std::min<double>(256.0, ceil(S.top_share * 256.0 / 0.35)) : 1;
+    // (only when that workgroup really stands out: on i.i.d. columns its share is 1 / nwg_x and the fill rule decides,
+    // with the column groups running fastest -- sizing by balance there cost 8 GB of factor-tile traffic per pass)
+    const bool skewed = S.perm && S.top_share * (double)nwg_x > 1.5;
+    const int r_bal = skewed ? (int)std::min<double>(256.0, ceil(S.top_share * 256.0 / 0.35)) : 1;
     if (std::max(r_fill, r_bal) > 1) {
         double best = -1.0;
         // (a fill factor beyond the tile count leaves the range whole, as it always did: such a matrix is tiny)

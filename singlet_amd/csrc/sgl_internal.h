@@ -11,7 +11,7 @@
 #include "../../include/singlet_hip.h"
 
 #define SGL_WAVE 64
-#define SGL_MAX_K 256          // generic (wave-per-column) NNLS handles k <= 256
+#define SGL_MAX_K 1024         // rank limit of the library: above 128 (plain fit) / 128 (masked fit) the generic kernels run
 #define SGL_LANE_NNLS_MAX_K 128  // lane-per-column NNLS: k <= 64 all in registers, k <= 128 with x in a memory scratch
 
 void sgl_set_error(const char* fmt, ...);
@@ -171,7 +171,7 @@ int sgl_c_ard_nmf_multi(int ndev, const double* Ax, const int32_t* Ai, const int
                         double overfit_threshold, uint16_t trace_test_mse, double* w_out, double* d_out, double* h_out,
                         double* test_mse, int32_t* iter, double* tol_out, double* score_overfit, int32_t* n_trace,
                         const sgl_callbacks* cb);
-#define SGL_MASK_MAX_K 128   // rank limit of the masked (ARD) path: the Gram downdate kernels cover k <= 128
+#define SGL_MASK_MAX_K SGL_MAX_K   // the masked (ARD) path: MFMA Gram downdates up to k = 128, the generic VALU kernel above
 void sgl_team_detach(sgl_ctx* c);               // called by sgl_destroy
 int sgl_c_nmf_multi(int ndev, const double* Ax, const int32_t* Ai, const int32_t* Ap, int32_t nrow, int32_t ncol, double tol,
                     uint16_t maxit, double L1_w, double L1_h, double L2_w, double L2_h, const double* w_init, int32_t k,

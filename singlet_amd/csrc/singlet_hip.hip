@@ -1099,6 +1099,7 @@ extern "C" int sgl_c_nmf(const double* Ax, const int32_t* Ai, const int32_t* Ap,
                          const sgl_callbacks* cb) {
     (void)verbose; (void)threads;
     if (!w_init || !w_out || !d_out || !h_out) { sgl_set_error("sgl_c_nmf: NULL factor buffer"); return SGL_EINVAL; }
+    if (k <= 0 || k > SGL_MAX_K) { sgl_set_error("rank k=%d unsupported (1..%d)", k, SGL_MAX_K); return SGL_EINVAL; }   // before any upload
     // SINGLET_NGPU=N (N > 1): shard the cells over the first N devices of this process (section 2b of the
     // header); the R side does not change.  Asking for more devices than there are is an error, not a fallback.
     if (const char* e = getenv("SINGLET_NGPU")) {

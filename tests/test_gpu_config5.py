@@ -156,12 +156,17 @@ def test_replica_sweep_equals_the_one_device_sweep(sa, ora):
     assert len(a) == len(b) == 4 * 3 * len([r for r in a if r["k"] == 3 and r["rep"] == 1]) and all(ra == rb for ra, rb in zip(a, b))
 
 
-def test_ard_rank_limit_is_checked_before_the_upload(sa, ora):
+def test_rank_limit_is_checked_before_the_upload(sa, ora):
+    """The reference has no rank limit; the library's is 1024 (generic kernels above 128), and it is checked before
+    anything is uploaded, with the limit in the message."""
     A = ora.synth_csc(200, 150, 10)
-    w0 = ora.synth_winit(130, 200)
+    w0 = np.ones((200, 1025))
     with pytest.raises(sa.SingletHipError) as e:
         sa.c_ard_nmf(to_dgc(sa, A), None, 0.0, 2, False, 0.01, 0.0, 0, w0.T, 1, 20, 1e9, 1)
-    assert "128" in str(e.value)
+    assert "1024" in str(e.value)
+    with pytest.raises(sa.SingletHipError) as e:
+        sa.c_nmf(to_dgc(sa, A), None, 0.0, 2, False, 0.01, 0.01, 0.0, 0.0, 0, w0.T)
+    assert "1024" in str(e.value)
 
 
 def test_one_shot_cache_keeps_the_matrix_resident(sa, ora, monkeypatch):

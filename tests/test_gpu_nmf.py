@@ -24,7 +24,9 @@ def _check(got, ref, keys=("w", "h", "d")):
     # ranks above 64: two-part tiled accumulate, split Gram, lane NNLS with x in scratch (100), one wave per SIMD
     # (120, 128), and above 128 the plain CSC accumulate + wave-per-column NNLS (130, 200)
     (260, 330, 100, 0.01, 0.0, 2), (250, 300, 120, 0.01, 0.0, 2), (270, 310, 128, 0.01, 0.01, 2),
-    (280, 300, 130, 0.01, 0.0, 2), (300, 420, 200, 0.01, 0.0, 2)])
+    (280, 300, 130, 0.01, 0.0, 2), (300, 420, 200, 0.01, 0.0, 2),
+    # above 256: the any-rank instances (16 coordinates per lane in the wave NNLS, Gram in several launches)
+    (400, 520, 300, 0.01, 0.0, 2), (700, 640, 600, 0.0, 0.0, 1)])
 def test_c_nmf_parity(sa, ora, m, n, k, L1, L2, maxit):
     A = ora.synth_csc(m, n, 20)
     At = A.t()
@@ -90,7 +92,9 @@ def test_rcpp_predict(sa, ora, shape):
     assert rel_fro(got.T, ref) < TOL and same_zero_pattern(got.T, ref)
 
 
-@pytest.mark.parametrize("k,trace,maxit", [(6, 1, 4), (8, 2, 5), (5, 3, 4), (17, 2, 3), (20, 1, 3), (30, 2, 3), (36, 2, 2), (49, 2, 2), (50, 2, 2), (52, 2, 2), (66, 2, 2), (70, 2, 2), (83, 2, 2), (90, 1, 2), (100, 2, 2), (116, 2, 2)])
+@pytest.mark.parametrize("k,trace,maxit", [(6, 1, 4), (8, 2, 5), (5, 3, 4), (17, 2, 3), (20, 1, 3), (30, 2, 3), (36, 2, 2), (49, 2, 2), (50, 2, 2), (52, 2, 2), (66, 2, 2), (70, 2, 2), (83, 2, 2), (90, 1, 2), (100, 2, 2), (116, 2, 2),
+                                            # above 128: Gram downdates on the VALU in pair ranges, wave NNLS (any-rank path)
+                                            (140, 2, 2), (260, 1, 1)])
 def test_c_ard_nmf_parity(sa, ora, k, trace, maxit):
     m, n = (220, 260) if k <= 100 else (900, 1000)   # enough data for every factor to stay alive
     A = ora.synth_csc(m, n, 20)

@@ -41,7 +41,8 @@ def test_mask_bit_exact(ctx, ora, inv_density):
     assert np.array_equal(got, exp)
 
 
-@pytest.mark.parametrize("k,cols", [(1, 5), (8, 400), (16, 33), (30, 2000), (50, 777), (64, 300), (70, 129), (100, 50)])
+@pytest.mark.parametrize("k,cols", [(1, 5), (8, 400), (16, 33), (30, 2000), (50, 777), (64, 300), (70, 129), (100, 50), (128, 300),
+                                    (129, 200), (300, 700), (520, 90)])
 def test_gram(ctx, ora, k, cols):
     F = np.random.default_rng(k * 1000 + cols).random((cols, k))
     G = ctx.op_gram(F)
@@ -58,7 +59,7 @@ def test_gram_transpose_detecting(ctx, ora):
     assert rel_fro(ctx.op_gram(F), ora.aat(F)) < 1e-14
 
 
-@pytest.mark.parametrize("k", [1, 7, 30, 50, 64, 65, 100, 130])
+@pytest.mark.parametrize("k", [1, 7, 30, 50, 64, 65, 100, 130, 257, 700])
 def test_rhs_both_orientations(ctx, ora, sa, k):
     A = ora.synth_csc(300, 450, 20)
     At = A.t()
@@ -209,7 +210,7 @@ def _csc_from_dense(D):
 # every kernel family of the shared-Gram solve (kernels_nnls.hip dispatch): lane kernel with G as scalar operands (k <= 40),
 # DPP rows (42 - 64), x in memory scratch (66 - 104: instances 72, 80, 88, 96, 104), one wave per SIMD (112, 120, 128),
 # wave per column above 128 up to SGL_MAX_K
-@pytest.mark.parametrize("k", [2, 8, 10, 30, 40, 42, 50, 52, 64, 65, 72, 80, 88, 96, 100, 104, 105, 112, 120, 127, 128, 129, 200, 256])
+@pytest.mark.parametrize("k", [2, 8, 10, 30, 40, 42, 50, 52, 64, 65, 72, 80, 88, 96, 100, 104, 105, 112, 120, 127, 128, 129, 200, 256, 257, 500])
 @pytest.mark.parametrize("L1,L2", [(0.0, 0.0), (0.01, 0.0), (0.01, 0.05)])
 def test_nnls(ctx, ora, k, L1, L2):
     rng = np.random.default_rng(k)
