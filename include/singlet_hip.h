@@ -358,6 +358,11 @@ SGL_API int sgl_multi_upload_csc(sgl_multi* m, const double* Ax, const int32_t* 
 SGL_API int sgl_multi_synth_csc(sgl_multi* m, uint64_t S, uint64_t inv_density, const double* levels16, int32_t ngenes,
                                 int64_t ncells_total);
 SGL_API int sgl_multi_fit_init(sgl_multi* m, int32_t k, const double* w_init, uint64_t synth_seed);
+/* c_linked_nmf on the team: the link matrices of the WHOLE matrix (arguments as sgl_set_links); link_h's columns follow
+ * their cells to the ranks.  Call after sgl_multi_fit_init.  (One process per GPU: sgl_set_links on the rank's context with
+ * the columns of link_h that belong to its cells.) */
+SGL_API int sgl_multi_set_links(sgl_multi* m, const double* link_h, int32_t link_h_rows, int32_t link_h_cols,
+                                const double* link_w, int32_t link_w_rows, int32_t link_w_cols);
 SGL_API int sgl_multi_iterate(sgl_multi* m, double L1_w, double L1_h, double L2_w, double L2_h, double* tol);
 SGL_API int sgl_multi_nmf_run(sgl_multi* m, double tol, int32_t maxit, double L1_w, double L1_h, double L2_w, double L2_h,
                               int32_t* n_iter, double* tol_trace, const sgl_callbacks* cb);

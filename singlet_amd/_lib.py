@@ -102,6 +102,7 @@ SIGNATURES = {
     "sgl_multi_upload_csc": (C.c_int, [C.c_void_p] + _CSC + [C.c_int32, C.c_int32]),
     "sgl_multi_synth_csc": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, f64p, C.c_int32, C.c_int64]),
     "sgl_multi_fit_init": (C.c_int, [C.c_void_p, C.c_int32, f64p, C.c_uint64]),
+    "sgl_multi_set_links": (C.c_int, [C.c_void_p, f64p, C.c_int32, C.c_int32, f64p, C.c_int32, C.c_int32]),
     "sgl_multi_iterate": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, f64p]),
     "sgl_multi_nmf_run": (C.c_int, [C.c_void_p, C.c_double, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double,
                                     i32p, f64p, _CB]),

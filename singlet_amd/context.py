@@ -403,6 +403,18 @@ class Multi:
         check(self._L.sgl_multi_fit_init(self._h, int(k), ptr(w, f64p), synth_seed))
         self.k = int(k)
 
+    def set_links(self, link_h=None, link_w=None):
+        """c_linked_nmf's link matrices (rows x cols, as R holds them) for the whole matrix; call after fit_init."""
+        def img(Lk):
+            if Lk is None:
+                return None, 0, 0, None
+            Lk = np.asarray(Lk, dtype=np.float64)
+            buf = np.ascontiguousarray(Lk.T)   # column-major image of the R matrix
+            return ptr(buf, f64p), Lk.shape[0], Lk.shape[1], buf
+        lh, lhr, lhc, k1 = img(link_h)
+        lw, lwr, lwc, k2 = img(link_w)
+        check(self._L.sgl_multi_set_links(self._h, lh, lhr, lhc, lw, lwr, lwc))
+
     def iterate(self, L1_w, L1_h, L2_w, L2_h):
         t = C.c_double()
         check(self._L.sgl_multi_iterate(self._h, L1_w, L1_h, L2_w, L2_h, C.byref(t)))

@@ -196,7 +196,7 @@ __global__ void gram_reduce_kernel(const double* __restrict__ part, int nblocks,
 
 int k_gram(sgl_ctx* c, const double* F, int k, int64_t cols, double* G, double diag_add) {
     if (k <= 0 || k > SGL_MAX_K) { sgl_set_error("k_gram: k=%d out of range", k); return SGL_EINVAL; }
-    int nblocks = (int)((cols + 1023) / 1024);
+    int nblocks = (int)((cols + 255) / 256);        // (at least 16 columns per block; fills the chip from ~65 000 columns on)
     if (nblocks > 1024) nblocks = 1024;
     if (k > 128 && nblocks > 128) nblocks = 128;   // generic path: k x k doubles of workspace per block
     if (nblocks < 1) nblocks = 1;
@@ -275,8 +275,9 @@ __global__ void rowsum_reduce_kernel(const double* __restrict__ part, int nblock
 }
 
 int k_rowsum(sgl_ctx* c, const double* F, int k, int64_t cols, double* d_out) {
-    int nblocks = (int)((cols + 2047) / 2048);
-    if (nblocks > 2048) nblocks = 2048;
+    // enough blocks to fill the chip at shard sizes too (125 000 cells used to get 62: 72 us for a 50 MB read)
+    int nblocks = (int)((cols + 511) / 512);
+    if (nblocks > 512) nblocks = 512;
     if (nblocks < 1) nblocks = 1;
     const int64_t cpb = (cols + nblocks - 1) / nblocks;
     SGLCHK(sgl_ws_reserve(c, sizeof(double) * (size_t)nblocks * k));
@@ -336,10 +337,26 @@ __global__ __launch_bounds__(256) void cor_partial_kernel(const double* __restri
 }
 
 __global__ void cor_final_kernel(const double* __restrict__ part, int nblocks, int64_t n, double* __restrict__ out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    double s[5] = {0, 0, 0, 0, 0};
-    for (int b = 0; b < nblocks; ++b)
-        for (int q = 0; q < 5; ++q) s[q] += part[(size_t)b * 5 + q];
+    if (blockIdx.x != 0) return;
+    // the five sums in block order (one lane each, loads eight blocks ahead: one thread walking all 5 x nblocks
+    // partials took 64 us -- more than the reduction it finishes)
+    const int lane = threadIdx.x;
+    double mine = 0.0;
+    if (lane < 5) {
+        int b = 0;
+        for (; b + 8 <= nblocks; b += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(b + u) * 5 + lane];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) mine += v[u];
+        }
+        for (; b < nblocks; ++b) mine += part[(size_t)b * 5 + lane];
+    }
+    double s[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) s[q] = __shfl(mine, q, 64);
+    if (lane != 0) return;
     const double nn = (double)n;
     // 1 - (n*sum_xy - sum_x*sum_y) / sqrt((n*sum_x2 - sum_x^2) * (n*sum_y2 - sum_y^2)), src/singlet.cpp:196;
     // written without contraction so the final formula rounds as the reference's does.

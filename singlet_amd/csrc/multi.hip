@@ -325,7 +325,8 @@ static int team_iterate(sgl_team* T, double L1_w, double L1_h, double L2_w, doub
     const int N = T->nranks;
     for (auto c : T->local) {
         if (c->k == 0) { sgl_set_error("team: no fit initialised"); return SGL_ESTATE; }
-        if (c->link_h || c->link_w || c->solve_empty) { sgl_set_error("team: linked / dense fits are not supported"); return SGL_EINVAL; }
+        // c_linked_nmf on a team (src/singlet.cpp:1059-1086): link_h holds the columns of this rank's cells and is applied
+        // inside the local H-update (sgl_step_h); link_w multiplies the rank's gene block of the summed right-hand sides
     }
     const int k = T->local[0]->k;
     const int64_t m = T->nrow;
@@ -385,9 +386,11 @@ static int team_iterate(sgl_team* T, double L1_w, double L1_h, double L2_w, doub
         if (ng > 0) {
             double* Bblk = c->red + (size_t)g0 * k;
             SGLCHK(k_scale_apply(c->stream, Bblk, k, ng, c->d, 0));
+            if (c->link_w) SGLCHK(k_link_mul(c->stream, Bblk, c->link_w + (size_t)g0 * c->link_w_rows, k, c->link_w_rows, ng));  // predict_link l.429-430
             const int64_t* gene_nnz = (N > 1) ? c->col_nnz_At_global : c->col_nnz_At;
             if (N > 1 && !c->gene_nnz_global) { sgl_set_error("team: global gene counts missing"); return SGL_ESTATE; }
-            SGLCHK(sgl_nnls_shared(c, c->G, Bblk, c->W + (size_t)g0 * k, gene_nnz + g0, ng, L1_w, L2_w, c->sweep_counters + 1));
+            // (the dense front-end solves every column, src/singlet.cpp:370-381: no skip list)
+            SGLCHK(sgl_nnls_shared(c, c->G, Bblk, c->W + (size_t)g0 * k, c->solve_empty ? nullptr : gene_nnz + g0, ng, L1_w, L2_w, c->sweep_counters + 1));
         }
         SGLCHK(sgl_phase_end(c, &pe));
     }
@@ -864,6 +867,22 @@ extern "C" int sgl_multi_fit_init(sgl_multi* M, int32_t k, const double* w_init,
     for (auto c : M->local) SGLCHK(sgl_fit_init(c, k, w_init, synth_seed));
     for (auto c : M->local) c->gene_nnz_global = false;
     return team_gene_counts(M);
+}
+
+// link matrices of c_linked_nmf for the whole matrix (column-major rows x cols as R holds them): link_h's columns are
+// dealt out to the ranks with their cells, link_w goes to every rank; a link whose column count does not match its
+// side is ignored, as in the reference (src/singlet.cpp:1059-1065)
+extern "C" int sgl_multi_set_links(sgl_multi* M, const double* link_h, int32_t link_h_rows, int32_t link_h_cols, const double* link_w,
+                                   int32_t link_w_rows, int32_t link_w_cols) {
+    TEAM_GUARD(M);
+    if (M->cell_lo.empty()) { sgl_set_error("sgl_multi_set_links: no matrix resident"); return SGL_ESTATE; }
+    const bool use_h = link_h && link_h_rows > 0 && (int64_t)link_h_cols == M->ncells_total;
+    for (int r = 0; r < M->nranks; ++r) {
+        const int64_t lo = M->cell_lo[r], nloc = M->cell_lo[r + 1] - lo;
+        SGLCHK(sgl_set_links(M->local[r], use_h ? link_h + (size_t)lo * link_h_rows : nullptr, link_h_rows, use_h ? (int32_t)nloc : 0, link_w,
+                             link_w_rows, link_w_cols));
+    }
+    return SGL_OK;
 }
 
 extern "C" int sgl_multi_iterate(sgl_multi* M, double L1_w, double L1_h, double L2_w, double L2_h, double* tol) {

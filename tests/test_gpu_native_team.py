@@ -98,6 +98,32 @@ def test_c_nmf_honours_singlet_ngpu(sa, ora, monkeypatch):
     assert r["iter"] == 2
 
 
+@pytest.mark.parametrize("which,ranks", [("both", 2), ("h_only", 3), ("w_only", 4)])
+def test_linked_nmf_on_a_team(sa, ora, which, ranks):
+    """c_linked_nmf (src/singlet.cpp:1059-1086) with the cells sharded: link_h's columns follow their cells, link_w
+    multiplies each rank's gene block of the summed right-hand sides."""
+    m, n, k = 263, 530, 9          # 263 genes: uneven last gene block
+    A = ora.synth_csc(m, n, 15)
+    w0 = ora.synth_winit(k, m)
+    rng = np.random.default_rng(4)
+    lh = (rng.random((k, n)) < 0.7) * (0.5 + rng.random((k, n)))
+    lw = (rng.random((k, m)) < 0.8).astype(np.float64)
+    off = np.ones((1, 1))
+    link_h = lh if which in ("both", "h_only") else off
+    link_w = lw if which in ("both", "w_only") else off
+    ref = ora.c_linked_nmf(A, A.t(), 0.0, 4, 0.01, 0.0, 0, w0, link_h, link_w)
+    with sa.Multi([0] * ranks) as M:
+        M.upload(to_dgc(sa, A))
+        M.fit_init(k, w0)
+        M.set_links(link_h, link_w)
+        M.nmf_run(0.0, 4, 0.01, 0.01, 0.0, 0.0)
+        W, d, H = M.get_factors()
+    assert rel_fro(W, ref["w"]) < 1e-9 and rel_fro(H, ref["h"]) < 1e-9 and rel_fro(d, ref["d"]) < 1e-9
+    assert same_zero_pattern(W, ref["w"]) and same_zero_pattern(H, ref["h"])
+    if which in ("both", "h_only"):
+        assert np.all(H[lh.T == 0] == 0)
+
+
 def test_team_refuses_what_it_does_not_support(sa, ora):
     A = ora.synth_csc(40, 90, 5)
     with sa.Multi([0, 0]) as M:

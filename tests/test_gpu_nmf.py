@@ -466,7 +466,7 @@ def test_edge_arguments(sa, ora, ctx):
     with pytest.raises(sa.SingletHipError):
         ctx.fit_init(0, None)
     with pytest.raises(sa.SingletHipError):
-        ctx.fit_init(300, None)                       # above SGL_MAX_K
+        ctx.fit_init(1025, None)                      # above SGL_MAX_K
     ctx.fit_init(5, w0)
     with pytest.raises(sa.SingletHipError):
         ctx.ard_run(0.0, 3, 0.01, 0.0, 1, 0, 1e9, 1)  # inv_density = 0
