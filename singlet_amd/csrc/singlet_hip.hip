@@ -1122,7 +1122,6 @@ extern "C" int sgl_c_nmf(const double* Ax, const int32_t* Ai, const int32_t* Ap,
 extern "C" int sgl_set_links(sgl_ctx* c, const double* link_h, int32_t link_h_rows, int32_t link_h_cols, const double* link_w,
                              int32_t link_w_rows, int32_t link_w_cols) {
     FIT_GUARD(c);
-    if (c->team && (link_h || link_w)) { sgl_set_error("sgl_set_links: linked NMF is not supported on a native team; use the all-reduce hook"); return SGL_EINVAL; }
     dev_free(c->link_h);
     dev_free(c->link_w);
     c->link_h = c->link_w = nullptr;
