@@ -69,9 +69,8 @@ __global__ __launch_bounds__(256) void synth_kernel(uint64_t S, SglDiv inv_densi
         uint64_t xi1 = 0;
         if (FILL && !transposed) xi1 = sgl_rand_i(S + 1, (uint64_t)(cell_offset + col));
         double wcol = 0.0;
-        if (skew)
-            wcol = (1.0 / (double)inv_density.d) *
-                   (transposed ? skew[16 + synth_level_gene(S, (uint64_t)col)] : skew[synth_level_cell(S, (uint64_t)(cell_offset + col))]);
+        const double p0 = 1.0 / (double)inv_density.d;
+        if (skew) wcol = transposed ? skew[16 + synth_level_gene(S, (uint64_t)col)] : skew[synth_level_cell(S, (uint64_t)(cell_offset + col))];
         for (int64_t r0 = 0; r0 < nrow; r0 += 64) {
             const int64_t r = r0 + lane;
             bool drawn = false;
@@ -80,7 +79,7 @@ __global__ __launch_bounds__(256) void synth_kernel(uint64_t S, SglDiv inv_densi
                                               : sgl_rand_j(xi, (uint64_t)r);
                 if (skew) {
                     const double wrow = transposed ? skew[synth_level_cell(S, (uint64_t)(cell_offset + r))] : skew[16 + synth_level_gene(S, (uint64_t)r)];
-                    drawn = (double)(h >> 11) * 0x1p-53 < wcol * wrow;   // same product (commutative) in both orientations
+                    drawn = (double)(h >> 11) * 0x1p-53 < p0 * (wcol * wrow);   // wc * wg first: commutative, so both orientations round alike
                 } else {
                     drawn = sgl_divides(h, inv_density);
                 }

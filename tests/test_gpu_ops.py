@@ -181,6 +181,49 @@ def test_entry_stream_padding_on_pbmc3k(sa, ora, k):
     assert lay["A"]["entries"] / nnz <= 1.20 and lay["At"]["entries"] / nnz <= 1.20, (lay, nnz)
 
 
+def test_skewed_generator_is_a_valid_consistent_matrix(sa, ora):
+    """sgl_synth_csc_skewed (bench.py --data skewed): both orientations describe the same matrix, rows ascend, the
+    draw test is the documented one (host emulation with the same hash), and rows / columns ARE skewed."""
+    from singlet_amd.context import skew_weights16, SYNTH_SEED
+    m, n, inv, off = 700, 520, 10, 3000
+    c = sa.Context(0)
+    try:
+        c.synth(m, n, inv, cell_offset=off, ncells_total=10000, skew=(0.5, 1.5))
+        x, i, p = c.download(0)
+        xt, it, pt = c.download(1)
+    finally:
+        c.close()
+    A = ora.CSC(x, i, p.astype(np.int32), m, n)
+    At = A.t()
+    assert np.array_equal(pt, At.p.astype(np.int64)) and np.array_equal(it, At.i) and np.array_equal(xt, At.x)
+    for col in range(n):
+        assert np.all(np.diff(i[p[col]:p[col + 1]]) > 0)
+    cw, gw = skew_weights16(0.5), skew_weights16(1.5)
+    S = SYNTH_SEED
+    D = np.zeros((m, n), dtype=bool)
+    for col in range(0, n, 37):          # a sample of the cells, every gene
+        cell = off + col
+        lc = (ora.rng_rand(S + 3, cell, 0x5EED) >> 11) & 15
+        for g in range(m):
+            lg = (ora.rng_rand(S + 4, 0x5EED, g) >> 11) & 15
+            u = float(ora.rng_rand(S, cell, g) >> 11) * 2.0 ** -53
+            D[g, col] = u < (1.0 / inv) * (cw[lc] * gw[lg])
+        got = np.zeros(m, dtype=bool)
+        got[i[p[col]:p[col + 1]]] = True
+        assert np.array_equal(got, D[:, col]), col
+    per_gene = np.diff(pt)
+    assert per_gene.max() > 8 * max(np.median(per_gene), 1)     # heavy-tailed gene counts
+
+
+def test_weight_by_split_one_shot(sa, ora):
+    """sgl_c_weight_by_split, the entry `_singlet_weight_by_split` binds (src/singlet.cpp:118-144)."""
+    A = ora.synth_csc(300, 257, 10)
+    sb = np.random.default_rng(5).integers(0, 4, A.ncol).astype(np.int32)
+    ref = ora.weight_by_split(A, sb, 4)
+    got = sa.weight_by_split(to_dgc(sa, A), sb, 4)
+    assert rel_fro(got.x, ref.x) < 1e-14 and np.array_equal(got.i, A.i) and np.array_equal(got.p, A.p)
+
+
 def test_rhs_ragged_and_empty_columns(ctx, ora, sa):
     rng = np.random.default_rng(3)
     D = (rng.random((90, 140)) < 0.3) * rng.random((90, 140))
