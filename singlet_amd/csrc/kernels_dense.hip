@@ -183,15 +183,40 @@ __global__ __launch_bounds__(256) void gram_valu_kernel(const double* __restrict
     for (int pr = pair0 + (int)threadIdx.x; pr < pend; pr += 256, ++q) out[pr] = acc[q];
 }
 
-__global__ void gram_reduce_kernel(const double* __restrict__ part, int nblocks, int k, double diag_add,
-                                   double* __restrict__ G) {
+// Fixed-order sum of per-block partials in two stages (one thread walking 1024 partials of an entry took 0.24 ms per
+// Gram at config 3 -- more than the MFMA kernel that made them):  stage 1, blockIdx.y = segment s of SEG consecutive
+// blocks: tmp[s][e] = sum of its blocks in order;  stage 2: out[e] = sum over the segments in order (+ the ridge on
+// the diagonal of a k x k result when diag_k > 0).
+#define SGL_RED_SEG 32
+__global__ void partial_sum_stage1_kernel(const double* __restrict__ part, int nblocks, int n, double* __restrict__ tmp) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= k * k) return;
+    if (e >= n) return;
+    const int b0 = blockIdx.y * SGL_RED_SEG;
+    const int b1 = (b0 + SGL_RED_SEG < nblocks) ? b0 + SGL_RED_SEG : nblocks;
     double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += part[(size_t)b * k * k + e];
-    const int i = e % k, j = e / k;
-    if (i == j) s += diag_add;
-    G[e] = s;
+    for (int b = b0; b < b1; ++b) s += part[(size_t)b * n + e];
+    tmp[(size_t)blockIdx.y * n + e] = s;
+}
+__global__ void partial_sum_stage2_kernel(const double* __restrict__ tmp, int nseg, int n, int diag_k, double diag_add,
+                                          double* __restrict__ out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    double s = 0.0;
+    for (int q = 0; q < nseg; ++q) s += tmp[(size_t)q * n + e];
+    if (diag_k > 0 && e % diag_k == e / diag_k) s += diag_add;
+    out[e] = s;
+}
+// part: nblocks x n partials at the start of c->ws; the segment sums go behind them (the caller reserved
+// sgl_partial_ws(nblocks, n) doubles)
+static size_t sgl_partial_ws(int nblocks, int n) { return (size_t)nblocks * n + (size_t)((nblocks + SGL_RED_SEG - 1) / SGL_RED_SEG) * n; }
+static int sgl_partial_sum(sgl_ctx* c, int nblocks, int n, int diag_k, double diag_add, double* out) {
+    const int nseg = (nblocks + SGL_RED_SEG - 1) / SGL_RED_SEG;
+    double* tmp = c->ws + (size_t)nblocks * n;
+    partial_sum_stage1_kernel<<<dim3((n + 255) / 256, nseg), dim3(256), 0, c->stream>>>(c->ws, nblocks, n, tmp);
+    HIPCHK(hipGetLastError());
+    partial_sum_stage2_kernel<<<dim3((n + 255) / 256), dim3(256), 0, c->stream>>>(tmp, nseg, n, diag_k, diag_add, out);
+    HIPCHK(hipGetLastError());
+    return SGL_OK;
 }
 
 int k_gram(sgl_ctx* c, const double* F, int k, int64_t cols, double* G, double diag_add) {
@@ -204,7 +229,7 @@ int k_gram(sgl_ctx* c, const double* F, int k, int64_t cols, double* G, double d
     cpb = (cpb + 15) / 16 * 16;  // whole 16-column steps per block
     nblocks = (int)((cols + cpb - 1) / cpb);
     if (nblocks < 1) nblocks = 1;
-    SGLCHK(sgl_ws_reserve(c, sizeof(double) * (size_t)nblocks * k * k));
+    SGLCHK(sgl_ws_reserve(c, sizeof(double) * sgl_partial_ws(nblocks, k * k)));
     hipStream_t s = c->stream;
     const int NT = (k + 15) / 16;
     if (NT == 1) gram_mfma_kernel<1><<<dim3(nblocks), dim3(256), 0, s>>>(F, k, cols, cpb, c->ws);
@@ -222,9 +247,7 @@ int k_gram(sgl_ctx* c, const double* F, int k, int64_t cols, double* G, double d
             gram_valu_kernel<<<dim3(nblocks), dim3(256), lds, s>>>(F, k, cols, cpb, c->ws, pair0);
     }
     HIPCHK(hipGetLastError());
-    gram_reduce_kernel<<<dim3((k * k + 255) / 256), dim3(256), 0, s>>>(c->ws, nblocks, k, diag_add, G);
-    HIPCHK(hipGetLastError());
-    return SGL_OK;
+    return sgl_partial_sum(c, nblocks, k * k, k, diag_add, G);
 }
 
 __global__ void add_diag_kernel(double* __restrict__ G, int k, double v) {
@@ -266,13 +289,6 @@ __global__ __launch_bounds__(256) void rowsum_kernel(const double* __restrict__ 
     }
 }
 
-__global__ void rowsum_reduce_kernel(const double* __restrict__ part, int nblocks, int k, double* __restrict__ d) {
-    const int row = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= k) return;
-    double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += part[(size_t)b * k + row];
-    d[row] = s;
-}
 
 int k_rowsum(sgl_ctx* c, const double* F, int k, int64_t cols, double* d_out) {
     // enough blocks to fill the chip at shard sizes too (125 000 cells used to get 62: 72 us for a 50 MB read)
@@ -280,12 +296,10 @@ int k_rowsum(sgl_ctx* c, const double* F, int k, int64_t cols, double* d_out) {
     if (nblocks > 512) nblocks = 512;
     if (nblocks < 1) nblocks = 1;
     const int64_t cpb = (cols + nblocks - 1) / nblocks;
-    SGLCHK(sgl_ws_reserve(c, sizeof(double) * (size_t)nblocks * k));
+    SGLCHK(sgl_ws_reserve(c, sizeof(double) * sgl_partial_ws(nblocks, k)));
     rowsum_kernel<<<dim3(nblocks), dim3(256), 0, c->stream>>>(F, k, cols, cpb, c->ws);
     HIPCHK(hipGetLastError());
-    rowsum_reduce_kernel<<<dim3((k + 63) / 64), dim3(64), 0, c->stream>>>(c->ws, nblocks, k, d_out);
-    HIPCHK(hipGetLastError());
-    return SGL_OK;
+    return sgl_partial_sum(c, nblocks, k, 0, 0.0, d_out);
 }
 
 // d[i] += 1e-15 (once, by the add_eps kernel) and F[i, c] /= d[i]  (src/singlet.cpp:221-224)
