@@ -232,6 +232,14 @@ SGL_API int sgl_upload_csc_list(sgl_ctx* ctx, int32_t n_chunks, const double* co
                         const int32_t* t_chunk_ncol,
                         int32_t nrow, int64_t cell_offset, int64_t ncells_total);
 
+/* A dense matrix (nrow x ncol, column-major doubles, as R / Eigen hold it; what c_nmf_dense and c_ard_nmf_dense take,
+ * src/singlet.cpp:1052-1054, 1357-1361): resident as its CSC image (zeros dropped, both orientations, built on the
+ * device) and -- when more than half of its entries are non-zero -- as the dense copy itself, on which the plain fit then
+ * forms the right-hand sides of predict (`w * A.col(i)`, src/singlet.cpp:377) as FP64 GEMMs (rocBLAS, bound at run time).
+ * A fit on it solves every column like the reference's dense predict (no empty-column skip) when the caller asks for it
+ * (sgl_c_nmf_dense does). */
+SGL_API int sgl_upload_dense(sgl_ctx* ctx, const double* A, int32_t nrow, int32_t ncol);
+
 /* Generate the synthetic benchmark shard on the device:
  * entry (gene g, cell c) non-zero iff rand_S(c,g) % inv_density == 0, value
  * levels16[(rand_{S+1}(c,g) >> 11) % 16].  Both orientations are produced. */

@@ -73,6 +73,7 @@ SIGNATURES = {
     "sgl_destroy": (C.c_int, [C.c_void_p]),
     "sgl_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "sgl_upload_csc": (C.c_int, [C.c_void_p] + _CSC + _CSC + [C.c_int32, C.c_int32, C.c_int64, C.c_int64]),
+    "sgl_upload_dense": (C.c_int, [C.c_void_p, f64p, C.c_int32, C.c_int32]),
     "sgl_synth_csc": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, f64p, C.c_int32, C.c_int64, C.c_int32, C.c_int64]),
     "sgl_synth_csc_skewed": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, f64p, C.c_int32, C.c_int64, C.c_int32, C.c_int64,
                                        f64p, f64p]),

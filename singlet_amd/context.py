@@ -135,6 +135,14 @@ class Context:
         check(self._L.sgl_upload_csc(self._h, *a, *t, A.nrow, A.ncol, int(cell_offset), int(ncells_total)))
         self.k = 0
 
+    def upload_dense(self, A):
+        """A: dense (nrow, ncol) array (sgl_upload_dense: CSC image built on the device, GEMM right-hand sides when
+        more than half of it is non-zero)."""
+        A = np.asarray(A, dtype=np.float64)
+        Af = np.ascontiguousarray(A.T)   # column-major image
+        check(self._L.sgl_upload_dense(self._h, ptr(Af, f64p), A.shape[0], A.shape[1]))
+        self.k = 0
+
     def synth(self, ngenes, ncells_local, inv_density=20, seed=SYNTH_SEED, cell_offset=0, ncells_total=0, skew=None):
         """skew = (sigma_cells, sigma_genes): the skewed generator (log-normal weights per cell and per gene)."""
         lv = _f(LEVELS16)

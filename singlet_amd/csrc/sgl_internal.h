@@ -121,6 +121,11 @@ struct sgl_ctx {
     double* Gpad = nullptr; // KP x KP zero-padded copy for the lane NNLS kernel
     NnlsScratch nnls_scr;   // lists / per-column state of the multi-pass lane NNLS
     bool solve_empty = false;  // dense front-end (src/singlet.cpp:370-381): no empty-column skip
+    // dense front-end (dense_frontend.hip): the matrix as R holds it (nrow x ncol, column-major) next to its CSC image;
+    // dense_gemm: more than half of it is non-zero -> the right-hand sides of predict are GEMMs (rocBLAS)
+    double* Adense = nullptr;
+    bool dense_gemm = false;
+    void* rocblas = nullptr;
     double* link_h = nullptr;  // c_linked_nmf: link_rows x ncol / x nrow multipliers of the right-hand sides
     double* link_w = nullptr;
     int link_h_rows = 0, link_w_rows = 0;
@@ -227,6 +232,12 @@ int sgl_tiled_mask_values(sgl_ctx* c, const DevCSC& M, DevTiled& S, uint64_t see
 // masked right-hand sides of predict_mask for one orientation (0: A, 1: At), through the tiled kernel when the fit has one
 int sgl_masked_rhs(sgl_ctx* c, int orientation, const double* F, double* Bbuf, uint64_t seed, uint64_t inv_density);
 int tiled_part_size(int k);
+
+// dense front-end (dense_frontend.hip)
+int k_dense_count(hipStream_t s, const double* A, int32_t nrow, int64_t ncol, int64_t* counts);
+int k_dense_fill(hipStream_t s, const double* A, int32_t nrow, int64_t ncol, const int64_t* p, int32_t* idx, double* x);
+int k_dense_rhs(sgl_ctx* c, int which, const double* F, int k, double* B);
+void sgl_dense_release(sgl_ctx* c);
 
 // input staging (kernels_prep.hip)
 int k_colsum(hipStream_t s, const DevCSC& M, double* sums);

@@ -165,6 +165,7 @@ static void free_fit(sgl_ctx* c, bool keep_streams = false) {
 }
 
 static void free_matrix(sgl_ctx* c) {
+    sgl_dense_release(c);
     free_csc(c->A);
     free_csc(c->At);
     dev_free(c->col_nnz_A);
@@ -422,6 +423,43 @@ static int sgl_upload_csc_A_only(sgl_ctx* c, const double* Ax, const int32_t* Ai
     SGLCHK(dev_alloc(&T.i, 1));
     SGLCHK(dev_alloc(&T.p, (size_t)nrow + 1));
     HIPCHK(hipMemsetAsync(T.p, 0, sizeof(int64_t) * ((size_t)nrow + 1), c->stream));
+    return finish_matrix(c);
+}
+
+// Dense matrix (nrow x ncol, column-major, as R holds it): kept on the device as it is AND as its CSC image (zeros
+// dropped), both orientations, all built there.  More than half of the entries non-zero (or SGL_DENSE_GEMM=1; =0
+// forbids it) -> the plain fit forms its right-hand sides as GEMMs on the dense copy; otherwise the copy is released.
+extern "C" int sgl_upload_dense(sgl_ctx* c, const double* A, int32_t nrow, int32_t ncol) {
+    CTX_GUARD(c);
+    if (!A || nrow <= 0 || ncol <= 0) { sgl_set_error("sgl_upload_dense: missing or empty matrix"); return SGL_EINVAL; }
+    free_fit(c);
+    free_matrix(c);
+    c->cell_offset = 0;
+    c->ncells_total = ncol;
+    const size_t tot = (size_t)nrow * (size_t)ncol;
+    SGLCHK(dev_alloc(&c->Adense, tot));
+    HIPCHK(hipMemcpyAsync(c->Adense, A, sizeof(double) * tot, hipMemcpyHostToDevice, c->stream));
+    DevCSC& M = c->A;
+    M.nrow = nrow; M.ncol = ncol;
+    int64_t* counts = nullptr;
+    SGLCHK(dev_alloc(&counts, (size_t)ncol));
+    SGLCHK(dev_alloc(&M.p, (size_t)ncol + 1));
+    int rc = k_dense_count(c->stream, c->Adense, nrow, ncol, counts);
+    if (rc == SGL_OK) rc = k_exclusive_scan(c, counts, M.p, ncol);
+    if (rc == SGL_OK) rc = k_scan_total(c->stream, counts, M.p, ncol);
+    int64_t nnz = 0;
+    if (rc == SGL_OK && (hipMemcpyAsync(&nnz, M.p + ncol, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                         hipStreamSynchronize(c->stream) != hipSuccess)) { sgl_set_error("sgl_upload_dense: HIP call failed"); rc = SGL_EHIP; }
+    dev_free(counts);
+    SGLCHK(rc);
+    M.nnz = nnz;
+    SGLCHK(dev_alloc(&M.x, (size_t)std::max<int64_t>(nnz, 1)));
+    SGLCHK(dev_alloc(&M.i, (size_t)std::max<int64_t>(nnz, 1)));
+    SGLCHK(k_dense_fill(c->stream, c->Adense, nrow, ncol, M.p, M.i, M.x));
+    SGLCHK(sgl_device_transpose(c));
+    const char* e = getenv("SGL_DENSE_GEMM");
+    c->dense_gemm = e ? atoi(e) > 0 : (double)nnz > 0.5 * (double)tot;
+    if (!c->dense_gemm) { HIPCHK(hipStreamSynchronize(c->stream)); dev_free(c->Adense); c->Adense = nullptr; }
     return finish_matrix(c);
 }
 
@@ -706,7 +744,8 @@ extern "C" int sgl_step_h(sgl_ctx* c, double L1, double L2) {
     const int k = c->k;
     { Phase ph(c, SGL_PH_GRAM); SGLCHK(k_gram(c, c->W, k, c->A.nrow, c->G, 1e-15)); }
     { Phase ph(c, SGL_PH_RHS_H);
-      if (c->use_tiled) SGLCHK(k_acc_tiled_all(c->stream, c->TA, c->W, c->B, k));
+      if (c->dense_gemm) SGLCHK(k_dense_rhs(c, 0, c->W, k, c->B));   // dense predict: b = w * A.col(i), src/singlet.cpp:377
+      else if (c->use_tiled) SGLCHK(k_acc_tiled_all(c->stream, c->TA, c->W, c->B, k));
       else SGLCHK(k_acc(c->stream, c->A, c->W, k, c->B, 0, 1, 0, 0, 0));
       if (c->link_h) SGLCHK(k_link_mul(c->stream, c->B, c->link_h, k, c->link_h_rows, c->A.ncol)); }  // predict_link l.429-430
     { Phase ph(c, SGL_PH_NNLS_H);
@@ -736,7 +775,8 @@ extern "C" int sgl_step_w(sgl_ctx* c, double L1, double L2) {
     const int64_t* gene_nnz = nullptr;
     SGLCHK(gene_counts(c, &gene_nnz));
     { Phase ph(c, SGL_PH_RHS_W);
-      if (c->use_tiled && c->TAt.roff) SGLCHK(k_acc_tiled_all(c->stream, c->TAt, c->H, Bw, k));
+      if (c->dense_gemm) SGLCHK(k_dense_rhs(c, 1, c->H, k, Bw));
+      else if (c->use_tiled && c->TAt.roff) SGLCHK(k_acc_tiled_all(c->stream, c->TAt, c->H, Bw, k));
       else SGLCHK(k_acc(c->stream, c->At, c->H, k, Bw, 0, 1, 0, 0, 0)); }
     { Phase ph(c, SGL_PH_GRAM); SGLCHK(k_gram(c, c->H, k, c->A.ncol, Gh, 0.0)); }
     SGLCHK(do_allreduce(c, c->red, (int64_t)k * m + (int64_t)k * k));
@@ -1162,24 +1202,19 @@ extern "C" int sgl_c_linked_nmf(const double* Ax, const int32_t* Ai, const int32
     return sgl_get_factors(hd.c, w_out, d_out, h_out);
 }
 
-static int dense_to_csc(const double* A, int32_t nrow, int32_t ncol, std::vector<double>& x, std::vector<int32_t>& idx,
-                        std::vector<int32_t>& p);
-
-// c_nmf_dense (src/singlet.cpp:1052-1054): a dense matrix runs through the same kernels as its CSC image
-// (zeros add exact zeros to the right-hand sides); the one semantic difference of the dense predict
-// (:370-381) is that it solves EVERY column, all-zero ones included.
+// c_nmf_dense (src/singlet.cpp:1052-1054): sgl_upload_dense keeps the matrix as its CSC image (zeros add exact zeros
+// to the right-hand sides) and, when it really is dense, as the dense copy the right-hand sides are then GEMMs on; the
+// one semantic difference of the dense predict (:370-381) is that it solves EVERY column, all-zero ones included.
 extern "C" int sgl_c_nmf_dense(const double* A, int32_t nrow, int32_t ncol, double tol, uint16_t maxit, int verbose,
                                double L1_w, double L1_h, double L2_w, double L2_h, uint16_t threads, const double* w_init,
                                int32_t k, double* w_out, double* d_out, double* h_out, int32_t* n_iter, double* tol_trace,
                                const sgl_callbacks* cb) {
     (void)verbose; (void)threads;
     if (!A || !w_init || !w_out || !d_out || !h_out || nrow <= 0 || ncol <= 0) { sgl_set_error("sgl_c_nmf_dense: bad arguments"); return SGL_EINVAL; }
-    std::vector<double> x;
-    std::vector<int32_t> idx, p;
-    SGLCHK(dense_to_csc(A, nrow, ncol, x, idx, p));
+    if (k <= 0 || k > SGL_MAX_K) { sgl_set_error("rank k=%d unsupported (1..%d)", k, SGL_MAX_K); return SGL_EINVAL; }
     CtxHolder hd;
     SGLCHK(sgl_create(current_device_or_zero(), &hd.c));
-    SGLCHK(sgl_upload_csc(hd.c, x.data(), idx.data(), p.data(), nullptr, nullptr, nullptr, nrow, ncol, 0, ncol));
+    SGLCHK(sgl_upload_dense(hd.c, A, nrow, ncol));
     SGLCHK(sgl_fit_init(hd.c, k, w_init, 0));
     hd.c->solve_empty = true;
     SGLCHK(sgl_nmf_run(hd.c, tol, maxit, L1_w, L1_h, L2_w, L2_h, n_iter, tol_trace, cb));
@@ -1213,22 +1248,6 @@ extern "C" int sgl_c_ard_nmf(const double* Ax, const int32_t* Ai, const int32_t*
     return hd.done(sgl_get_factors(hd.c, w_out, d_out, h_out));
 }
 
-// dense matrix -> the slots of its CSC image (zeros dropped)
-static int dense_to_csc(const double* A, int32_t nrow, int32_t ncol, std::vector<double>& x, std::vector<int32_t>& idx,
-                        std::vector<int32_t>& p) {
-    p.assign((size_t)ncol + 1, 0);
-    for (int64_t cc = 0; cc < ncol; ++cc) {
-        for (int64_t r = 0; r < nrow; ++r) {
-            const double v = A[(size_t)cc * nrow + r];
-            if (v != 0.0) { x.push_back(v); idx.push_back((int32_t)r); }
-        }
-        if (x.size() > (size_t)INT32_MAX) { sgl_set_error("dense front-end: more than 2^31 non-zeros"); return SGL_EINVAL; }
-        p[(size_t)cc + 1] = (int32_t)x.size();
-    }
-    if (x.empty()) { x.push_back(0.0); idx.push_back(0); }  // keep the slot pointers valid for an all-zero matrix
-    return SGL_OK;
-}
-
 // c_ard_nmf_dense (src/singlet.cpp:1357-1361; dense predict_mask :506-533, mse_test :608-632): the CSC image through
 // the masked path, every column solved (the dense predict_mask has no empty-column skip).
 extern "C" int sgl_c_ard_nmf_dense(const double* A, int32_t nrow, int32_t ncol, double tol, uint16_t maxit, int verbose,
@@ -1239,12 +1258,10 @@ extern "C" int sgl_c_ard_nmf_dense(const double* A, int32_t nrow, int32_t ncol, 
     (void)verbose; (void)threads;
     if (!A || !w_init || !w_out || !d_out || !h_out || nrow <= 0 || ncol <= 0) { sgl_set_error("sgl_c_ard_nmf_dense: bad arguments"); return SGL_EINVAL; }
     if (k > SGL_MASK_MAX_K) { sgl_set_error("c_ard_nmf: rank %d above the masked path's limit of %d", k, SGL_MASK_MAX_K); return SGL_EINVAL; }
-    std::vector<double> x;
-    std::vector<int32_t> idx, p;
-    SGLCHK(dense_to_csc(A, nrow, ncol, x, idx, p));
     CtxHolder hd;
     SGLCHK(sgl_create(current_device_or_zero(), &hd.c));
-    SGLCHK(sgl_upload_csc(hd.c, x.data(), idx.data(), p.data(), nullptr, nullptr, nullptr, nrow, ncol, 0, ncol));
+    SGLCHK(sgl_upload_dense(hd.c, A, nrow, ncol));
+    sgl_dense_release(hd.c);   // the masked right-hand sides are not plain products: the CSC image serves this loop
     SGLCHK(sgl_fit_init(hd.c, k, w_init, 0));
     hd.c->solve_empty = true;
     int32_t nit = 0;

@@ -412,6 +412,49 @@ def test_c_nmf_dense_and_sparse_list(sa, ora):
     assert fit["w"].shape == (m, 5) and np.all(np.diff(fit["d"]) <= 0)
 
 
+@pytest.mark.parametrize("m,n,k,zero_frac", [(300, 700, 12, 0.0), (257, 513, 50, 0.3), (120, 400, 70, 0.0)])
+def test_c_nmf_dense_gemm_path(sa, ora, m, n, k, zero_frac, monkeypatch):
+    """A matrix that IS dense (more than half non-zero): the right-hand sides of predict are FP64 GEMMs on the dense
+    copy (src/singlet.cpp:377: b = w * A.col(i)) instead of a sparse accumulate over its CSC image.  Against the
+    oracle's dense loop, and against the CSC-image path (SGL_DENSE_GEMM=0) of the same library."""
+    rng = np.random.default_rng(m + k)
+    D = rng.random((m, n)) + 0.05
+    D[rng.random((m, n)) < zero_frac] = 0.0
+    D[:, 11] = 0.0                                  # an all-zero cell is still solved by the dense predict
+    w0 = ora.synth_winit(k, m)
+    ref = ora.c_nmf_dense(D, 0.0, 3, 0.01, 0.01, 0.0, 0.0, 0, w0)
+    monkeypatch.delenv("SGL_DENSE_GEMM", raising=False)
+    got = sa.c_nmf_dense(D, None, 0.0, 3, False, 0.01, 0.01, 0.0, 0.0, 0, w0.T)
+    _check(got, ref)
+    monkeypatch.setenv("SGL_DENSE_GEMM", "0")
+    img = sa.c_nmf_dense(D, None, 0.0, 3, False, 0.01, 0.01, 0.0, 0.0, 0, w0.T)
+    _check(img, ref)
+    assert rel_fro(got["w"], img["w"]) < 1e-11 and rel_fro(got["h"], img["h"]) < 1e-11
+    # the GEMM really ran: the H-side accumulate phase of a resident fit is a rocBLAS launch (no entry stream is built)
+    monkeypatch.delenv("SGL_DENSE_GEMM", raising=False)
+    c = sa.Context(0)
+    try:
+        c.upload_dense(D)
+        c.fit_init(k, w0)
+        c.nmf_run(0.0, 2, 0.01, 0.01, 0.0, 0.0)
+        W, d, H = c.get_factors()
+    finally:
+        c.close()
+    assert np.isfinite(W).all() and np.isfinite(H).all()
+
+
+@pytest.mark.timeout(900)
+def test_c_nmf_dense_2000_by_50000(sa, ora):
+    """VERDICT r2 #8: a fully dense 2000 x 50000 matrix through the GEMM path against the oracle's dense loop."""
+    rng = np.random.default_rng(7)
+    m, n, k = 2000, 50000, 20
+    D = rng.random((m, n)) + 0.01
+    w0 = ora.synth_winit(k, m)
+    ref = ora.c_nmf_dense(D, 0.0, 2, 0.01, 0.01, 0.0, 0.0, 0, w0)
+    got = sa.c_nmf_dense(D, None, 0.0, 2, False, 0.01, 0.01, 0.0, 0.0, 0, w0.T)
+    _check(got, ref)
+
+
 def test_c_ard_nmf_dense_and_sparse_list(sa, ora):
     """The masked loop behind the two other front-ends R/ard_nmf.R uses (l.109, 114): the dense one
     (src/singlet.cpp:1357-1361, predict_mask :506-533) solves every column; the chunk list (:1162-1234) hashes
