@@ -1,4 +1,8 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests -m gpu -q -x 2>&1 | grep -E "passed|failed|FAILED|Error" | tail -5
-python bench.py --no-cpu-baseline --steps 10 | python -c "import json,sys; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(j['value'],2), {a:round(b,3) for a,b in j['phases_ms_per_step'].items()})"
-python bench.py --no-cpu-baseline --steps 30 --cells 125000 | python -c "import json,sys; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(j['value'],2), {a:round(b,3) for a,b in j['phases_ms_per_step'].items()})"
+python -m pytest tests -m gpu -q -k "ard or mask or config5" 2>&1 | grep -E "passed|failed|FAILED|Error" | tail -5
+for k in 56 64 80 100 128; do
+  for v in 1 0; do
+    if [ $v = 1 ]; then export SGL_NNLS_NO_QUAD_GLOBAL=1; else unset SGL_NNLS_NO_QUAD_GLOBAL; fi
+    echo "k=$k old_wave=$v $(python scripts/ard_rate.py 200000 30000 $k 2 | python -c "import json,sys; j=json.loads(sys.stdin.read()); print(round(j['ms_per_iter'],1), {a:round(b,1) for a,b in j['phases_ms_per_iter'].items() if b>0.05}, j['test_mse'][-1])")"
+  done
+done

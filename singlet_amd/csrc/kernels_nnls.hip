@@ -300,6 +300,103 @@ __global__ __launch_bounds__(64) void nnls_quad_kernel(const double* __restrict_
     }
 }
 
+// The same four-columns-per-wave solve for ranks whose triangles do not fit LDS (50 < k <= 128): the column's Gram
+// stays in global memory and row i + 1 is fetched (each 16-lane row its own column's 128-byte pieces) while coordinate
+// i is worked on.  nnls_wave_kernel spends ~49 instructions per column and coordinate step, 45 of them uniform over the
+// wave (eight v_readlane, the step's chain); here one issue of the chain serves four columns and the broadcasts are
+// DPP moves: ~13 instructions per column and step.  Every row is read in every sweep (the wave kernel skips the rows
+// of coordinates that do not move; with four columns per wave that test is rarely uniform).  Same arithmetic, same
+// order: bit-identical results.
+template <int NR>
+__global__ __launch_bounds__(64) void nnls_quad_global_kernel(const double* __restrict__ G, int64_t gstride,
+                                                              const double* __restrict__ B, double* __restrict__ X,
+                                                              const int64_t* __restrict__ col_nnz, int k, int64_t ncols,
+                                                              double L1, double L2, unsigned long long* __restrict__ sweep_counter) {
+    const int lane = threadIdx.x, grp = lane >> 4, l = lane & 15;
+    const double kd = (double)k;
+    long long total_sweeps = 0, ran_total = 0;
+    const int64_t nquads = (ncols + 3) >> 2;
+    for (int64_t quad = blockIdx.x; quad < nquads; quad += gridDim.x) {
+        const int64_t col = quad * 4 + grp;
+        const bool cvalid = col < ncols && (col_nnz == nullptr || col_nnz[col] != 0);
+        const double* __restrict__ Gc = G + (cvalid ? col : 0) * gstride;
+        double b[NR], x[NR], rg[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int j = l + 16 * r;
+            const bool v = cvalid && j < k;
+            b[r] = v ? B[col * k + j] : 0.0;
+            x[r] = v ? X[col * k + j] : 0.0;
+            rg[r] = v ? 1.0 / Gc[(int64_t)j * k + j] : 1.0;   // correctly rounded reciprocal of the diagonal
+        }
+        double tol = 1.0;
+        int it = 0, ran = 0, one = 1;
+        while (true) {
+            const bool go = cvalid && it < 100 && (tol / kd) > 1e-8;
+            if (__ballot(go) == 0ull) break;
+            ++ran;
+            if (go) tol = 0.0;
+            double gn[NR];   // row 0 of this sweep
+#pragma unroll
+            for (int r = 0; r < NR; ++r) gn[r] = (l + 16 * r < k) ? Gc[l + 16 * r] : 0.0;
+            static_for<16 * NR>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                constexpr int ir = i >> 4, il = i & 15;
+                bool run_i = i < k;
+                if (i <= 16 * (NR - 1)) { asm volatile("" : "+s"(one)); run_i = one != 0; }   // opaque, always true (see nnls_lane.h)
+                if (run_i) {
+                    double g[NR];
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) g[r] = gn[r];
+                    if (i + 1 < 16 * NR) {   // row i + 1, in flight during this coordinate
+                        const bool more = (i + 1 <= 16 * (NR - 1)) || (i + 1 < k);
+#pragma unroll
+                        for (int r = 0; r < NR; ++r) gn[r] = (more && l + 16 * r < k) ? Gc[(int64_t)(i + 1) * k + l + 16 * r] : 0.0;
+                    }
+                    const double bi = quad_bcast<il>(b[ir]);
+                    const double xi = quad_bcast<il>(x[ir]);
+                    const double rii = quad_bcast<il>(rg[ir]);
+                    const double gii = quad_bcast<il>(g[ir]);
+                    const double q0 = bi * rii;
+                    const double diff0 = fma(fma(-q0, gii, bi), rii, q0);   // b_i / g_ii (Markstein, see nnls_lane.h)
+                    double xn = xi;
+                    const double nd = sgl_nnls_step(diff0, xn, tol, go, L1, L2);
+                    x[ir] = (l == il) ? xn : x[ir];
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) b[r] = fma(g[r], nd, b[r]);
+                }
+            });
+            it += go ? 1 : 0;
+        }
+        if (cvalid) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int j = l + 16 * r;
+                if (j < k) X[col * k + j] = x[r];
+            }
+            if (l == 0) total_sweeps += it;
+        }
+        ran_total += ran;
+    }
+    if (sweep_counter != nullptr) {
+        for (int off = 32; off > 0; off >>= 1) total_sweeps += __shfl_down(total_sweeps, off, 64);
+        if (lane == 0 && (total_sweeps != 0 || ran_total != 0)) {
+            atomicAdd(sweep_counter, (unsigned long long)total_sweeps);
+            atomicAdd(sweep_counter + 2, (unsigned long long)ran_total);
+        }
+    }
+}
+
+template <int NR>
+static int launch_nnls_quad_global(hipStream_t s, const double* G, int64_t gstride, const double* B, double* X, const int64_t* col_nnz,
+                                   int k, int64_t ncols, double L1, double L2, unsigned long long* sweep_counter) {
+    const int64_t nquads = (ncols + 3) / 4;
+    const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>(nquads, 256 * 4 * 8));
+    nnls_quad_global_kernel<NR><<<dim3((unsigned)blocks), dim3(64), 0, s>>>(G, gstride, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
+    HIPCHK(hipGetLastError());
+    return SGL_OK;
+}
+
 template <int NR>
 static int launch_nnls_quad(hipStream_t s, const double* G, int64_t gstride, const double* B, double* X, const int64_t* col_nnz,
                             int k, int64_t ncols, double L1, double L2, unsigned long long* sweep_counter) {
@@ -333,6 +430,18 @@ int k_nnls_wave(hipStream_t s, const double* G, int64_t gstride, const double* B
             case 2: return launch_nnls_quad<2>(s, G, gstride, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
             case 3: return launch_nnls_quad<3>(s, G, gstride, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
             default: return launch_nnls_quad<4>(s, G, gstride, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
+        }
+    }
+    // per-column Grams above that, up to k = 112: four columns per wave on the Gram in global memory.  Measured per masked
+    // iteration at 30 000 x 200 000 (nnls_h, ms; wave kernel -> this one): k = 56: 102 -> 83, 64: 119 -> 84, 80: 234 -> 146,
+    // 100: 330 -> 298; at k = 128 (eight registers of row per lane, every row read in every sweep) it loses, 416 -> 572,
+    // and the wave kernel with its skipped rows stays.  (env: A/B tests)
+    if (gstride != 0 && k <= 112 && !getenv("SGL_NNLS_NO_QUAD_GLOBAL")) {
+        switch ((k + 15) / 16) {
+            case 1: case 2: case 3: case 4: return launch_nnls_quad_global<4>(s, G, gstride, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
+            case 5: return launch_nnls_quad_global<5>(s, G, gstride, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
+            case 6: return launch_nnls_quad_global<6>(s, G, gstride, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
+            default: return launch_nnls_quad_global<7>(s, G, gstride, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
         }
     }
     int64_t blocks = (ncols + 3) / 4;
