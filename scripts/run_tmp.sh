@@ -1,8 +1,5 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests -m gpu -q -k "ard or mask or config5" 2>&1 | grep -E "passed|failed|FAILED|Error" | tail -5
-for k in 10 30 50 64 80 100 128; do
-  for v in pf1 pf2; do
-    export SGL_LIB_PATH=/root/repo/build/lib_$v.so
-    echo "k=$k $v $(python scripts/ard_rate.py 200000 30000 $k 2 | python -c "import json,sys; j=json.loads(sys.stdin.read()); print(round(j['ms_per_iter'],1), {a:round(b,1) for a,b in j['phases_ms_per_iter'].items() if b>0.05}, j['test_mse'][-1])")"
-  done
-done
+for rep in 1 2; do for v in a0 a1 a2 a3 a4; do
+  export SGL_LIB_PATH=/root/repo/build/lib_$v.so
+  timeout 120 python bench.py --no-cpu-baseline --steps 6 --warmup 1 --cells 200000 2>/dev/null | python -c "import json,sys; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', {a:round(b,3) for a,b in j['phases_ms_per_step'].items() if a.startswith('nnls')}, j['nnls_mean_sweeps']['h_per_wave'])"
+done; done
