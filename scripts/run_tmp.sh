@@ -1,5 +1,11 @@
 cd $GRAFT_REPO_ROOT
-for rep in 1 2; do for v in a0 a1 a2 a3 a4; do
-  export SGL_LIB_PATH=/root/repo/build/lib_$v.so
-  timeout 120 python bench.py --no-cpu-baseline --steps 6 --warmup 1 --cells 200000 2>/dev/null | python -c "import json,sys; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', {a:round(b,3) for a,b in j['phases_ms_per_step'].items() if a.startswith('nnls')}, j['nnls_mean_sweeps']['h_per_wave'])"
-done; done
+python -m pytest tests -m gpu -q -k "ard or mask or config5" 2>&1 | grep -E "passed|failed|FAILED|Error" | tail -5
+for k in 56 64 80 100 112 128; do
+    unset SGL_NNLS_QUAD_GLOBAL_128 SGL_NNLS_NO_QUAD_GLOBAL
+    if [ $k = 128 ]; then export SGL_NNLS_QUAD_GLOBAL_128=1; fi
+    echo "k=$k quad_global $(python scripts/ard_rate.py 200000 30000 $k 2 | python -c "import json,sys; j=json.loads(sys.stdin.read()); print(round(j['ms_per_iter'],1), {a:round(b,1) for a,b in j['phases_ms_per_iter'].items() if b>0.05}, j['test_mse'][-1])")"
+done
+export SGL_NNLS_NO_QUAD_GLOBAL=1
+for k in 112; do
+    echo "k=$k wave $(python scripts/ard_rate.py 200000 30000 $k 2 | python -c "import json,sys; j=json.loads(sys.stdin.read()); print(round(j['ms_per_iter'],1), {a:round(b,1) for a,b in j['phases_ms_per_iter'].items() if b>0.05}, j['test_mse'][-1])")"
+done

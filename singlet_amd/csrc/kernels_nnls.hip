@@ -337,8 +337,11 @@ __global__ __launch_bounds__(64) void nnls_quad_global_kernel(const double* __re
             ++ran;
             if (go) tol = 0.0;
             double gn[NR];   // row 0 of this sweep
+            // a running row pointer (its addresses cannot be hoisted out of the sweep loop: written as Gc[(i + 1) k + ...]
+            // hipcc kept the addresses of all 16 NR rows in registers, 344 VGPRs at NR = 7)
+            const double* __restrict__ gp = Gc + l;
 #pragma unroll
-            for (int r = 0; r < NR; ++r) gn[r] = (l + 16 * r < k) ? Gc[l + 16 * r] : 0.0;
+            for (int r = 0; r < NR; ++r) gn[r] = (l + 16 * r < k) ? gp[16 * r] : 0.0;
             static_for<16 * NR>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
                 constexpr int ir = i >> 4, il = i & 15;
@@ -350,9 +353,12 @@ __global__ __launch_bounds__(64) void nnls_quad_global_kernel(const double* __re
                     for (int r = 0; r < NR; ++r) g[r] = gn[r];
                     if (i + 1 < 16 * NR) {   // row i + 1, in flight during this coordinate
                         const bool more = (i + 1 <= 16 * (NR - 1)) || (i + 1 < k);
+                        gp += k;
 #pragma unroll
-                        for (int r = 0; r < NR; ++r) gn[r] = (more && l + 16 * r < k) ? Gc[(int64_t)(i + 1) * k + l + 16 * r] : 0.0;
+                        for (int r = 0; r < NR; ++r) gn[r] = (more && l + 16 * r < k) ? gp[16 * r] : 0.0;
                     }
+                    // fence: one row ahead, no more
+                    __builtin_amdgcn_sched_barrier(0);
                     const double bi = quad_bcast<il>(b[ir]);
                     const double xi = quad_bcast<il>(x[ir]);
                     const double rii = quad_bcast<il>(rg[ir]);
@@ -364,6 +370,7 @@ __global__ __launch_bounds__(64) void nnls_quad_global_kernel(const double* __re
                     x[ir] = (l == il) ? xn : x[ir];
 #pragma unroll
                     for (int r = 0; r < NR; ++r) b[r] = fma(g[r], nd, b[r]);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             });
             it += go ? 1 : 0;
@@ -432,16 +439,17 @@ int k_nnls_wave(hipStream_t s, const double* G, int64_t gstride, const double* B
             default: return launch_nnls_quad<4>(s, G, gstride, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
         }
     }
-    // per-column Grams above that, up to k = 112: four columns per wave on the Gram in global memory.  Measured per masked
-    // iteration at 30 000 x 200 000 (nnls_h, ms; wave kernel -> this one): k = 56: 102 -> 83, 64: 119 -> 84, 80: 234 -> 146,
-    // 100: 330 -> 298; at k = 128 (eight registers of row per lane, every row read in every sweep) it loses, 416 -> 572,
-    // and the wave kernel with its skipped rows stays.  (env: A/B tests)
-    if (gstride != 0 && k <= 112 && !getenv("SGL_NNLS_NO_QUAD_GLOBAL")) {
+    // per-column Grams above that, up to k = 104: four columns per wave on the Gram in global memory.  Measured per masked
+    // iteration at 30 000 x 200 000 (nnls_h, ms; wave kernel -> this one): k = 56: 102 -> 62, 64: 119 -> 84, 80: 234 -> 146,
+    // 100: 330 -> 293; it reads every row in every sweep (1.6 TB/s at k = 100) where the wave kernel skips the rows of
+    // coordinates that do not move, and loses from k = 112 on (370 -> 394, k = 128: 416 -> 566).  (env: A/B tests)
+    if (gstride != 0 && k <= (getenv("SGL_NNLS_QUAD_GLOBAL_128") ? 128 : 104) && !getenv("SGL_NNLS_NO_QUAD_GLOBAL")) {
         switch ((k + 15) / 16) {
             case 1: case 2: case 3: case 4: return launch_nnls_quad_global<4>(s, G, gstride, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
             case 5: return launch_nnls_quad_global<5>(s, G, gstride, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
             case 6: return launch_nnls_quad_global<6>(s, G, gstride, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
-            default: return launch_nnls_quad_global<7>(s, G, gstride, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
+            case 7: return launch_nnls_quad_global<7>(s, G, gstride, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
+            default: return launch_nnls_quad_global<8>(s, G, gstride, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
         }
     }
     int64_t blocks = (ncols + 3) / 4;
