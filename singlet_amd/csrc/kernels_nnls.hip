@@ -305,8 +305,8 @@ __global__ __launch_bounds__(64) void nnls_quad_kernel(const double* __restrict_
 // i is worked on.  nnls_wave_kernel spends ~49 instructions per column and coordinate step, 45 of them uniform over the
 // wave (eight v_readlane, the step's chain); here one issue of the chain serves four columns and the broadcasts are
 // DPP moves: ~13 instructions per column and step.  Every row is read in every sweep (the wave kernel skips the rows
-// of coordinates that do not move; with four columns per wave that test is rarely uniform).  Same arithmetic, same
-// order: bit-identical results.
+// of coordinates that do not move; here a row is skipped when its coordinate moves in none of the four columns, and
+// fetched ahead only if it moved in the previous sweep).  Same arithmetic, same order: bit-identical results.
 template <int NR>
 __global__ __launch_bounds__(64) void nnls_quad_global_kernel(const double* __restrict__ G, int64_t gstride,
                                                               const double* __restrict__ B, double* __restrict__ X,
@@ -320,28 +320,38 @@ __global__ __launch_bounds__(64) void nnls_quad_global_kernel(const double* __re
         const int64_t col = quad * 4 + grp;
         const bool cvalid = col < ncols && (col_nnz == nullptr || col_nnz[col] != 0);
         const double* __restrict__ Gc = G + (cvalid ? col : 0) * gstride;
-        double b[NR], x[NR], rg[NR];
+        double b[NR], x[NR], rg[NR], gd[NR];
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             const int j = l + 16 * r;
             const bool v = cvalid && j < k;
             b[r] = v ? B[col * k + j] : 0.0;
             x[r] = v ? X[col * k + j] : 0.0;
-            rg[r] = v ? 1.0 / Gc[(int64_t)j * k + j] : 1.0;   // correctly rounded reciprocal of the diagonal
+            gd[r] = v ? Gc[(int64_t)j * k + j] : 1.0;
+            rg[r] = 1.0 / gd[r];   // correctly rounded reciprocal of the diagonal
         }
         double tol = 1.0;
         int it = 0, ran = 0, one = 1;
+        // Row i is only needed when coordinate i MOVES in one of the four columns (otherwise b += 0 * row).  Which
+        // coordinates move is nearly the same from sweep to sweep, so a row is fetched ahead only if its coordinate moved in
+        // the previous sweep (all of them in the first); a coordinate that moves without its row at hand fetches it then
+        // (rare).  The kernel is bound by these reads (random 128-byte lines over the chunk's Grams: ~2 TB/s).
+        unsigned long long act_lo = ~0ull, act_hi = ~0ull;
         while (true) {
             const bool go = cvalid && it < 100 && (tol / kd) > 1e-8;
             if (__ballot(go) == 0ull) break;
             ++ran;
             if (go) tol = 0.0;
-            double gn[NR];   // row 0 of this sweep
+            unsigned long long cur_lo = 0ull, cur_hi = 0ull;
+            double gn[NR];
             // a running row pointer (its addresses cannot be hoisted out of the sweep loop: written as Gc[(i + 1) k + ...]
             // hipcc kept the addresses of all 16 NR rows in registers, 344 VGPRs at NR = 7)
-            const double* __restrict__ gp = Gc + l;
+            const double* __restrict__ gp = Gc + l;   // row i of the running coordinate
+            bool have = (act_lo & 1ull) != 0ull;      // row 0 fetched ahead? (wave-uniform)
+            if (have) {
 #pragma unroll
-            for (int r = 0; r < NR; ++r) gn[r] = (l + 16 * r < k) ? gp[16 * r] : 0.0;
+                for (int r = 0; r < NR; ++r) gn[r] = (l + 16 * r < k) ? gp[16 * r] : 0.0;
+            }
             static_for<16 * NR>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
                 constexpr int ir = i >> 4, il = i & 15;
@@ -351,28 +361,43 @@ __global__ __launch_bounds__(64) void nnls_quad_global_kernel(const double* __re
                     double g[NR];
 #pragma unroll
                     for (int r = 0; r < NR; ++r) g[r] = gn[r];
-                    if (i + 1 < 16 * NR) {   // row i + 1, in flight during this coordinate
+                    const bool have_i = have;
+                    have = false;
+                    if (i + 1 < 16 * NR) {   // row i + 1, in flight during this coordinate -- if its coordinate moved last sweep
                         const bool more = (i + 1 <= 16 * (NR - 1)) || (i + 1 < k);
-                        gp += k;
+                        constexpr int i1 = i + 1;
+                        have = more && (((i1 < 64 ? (act_lo >> (i1 & 63)) : (act_hi >> (i1 & 63))) & 1ull) != 0ull);
+                        if (have) {
 #pragma unroll
-                        for (int r = 0; r < NR; ++r) gn[r] = (more && l + 16 * r < k) ? gp[16 * r] : 0.0;
+                            for (int r = 0; r < NR; ++r) gn[r] = (l + 16 * r < k) ? gp[k + 16 * r] : 0.0;
+                        }
                     }
                     // fence: one row ahead, no more
                     __builtin_amdgcn_sched_barrier(0);
                     const double bi = quad_bcast<il>(b[ir]);
                     const double xi = quad_bcast<il>(x[ir]);
                     const double rii = quad_bcast<il>(rg[ir]);
-                    const double gii = quad_bcast<il>(g[ir]);
+                    const double gii = quad_bcast<il>(gd[ir]);
                     const double q0 = bi * rii;
                     const double diff0 = fma(fma(-q0, gii, bi), rii, q0);   // b_i / g_ii (Markstein, see nnls_lane.h)
                     double xn = xi;
                     const double nd = sgl_nnls_step(diff0, xn, tol, go, L1, L2);
                     x[ir] = (l == il) ? xn : x[ir];
+                    if (__ballot(nd != 0.0 || xn != xi) != 0ull) {   // the coordinate moves in one of the four columns
+                        if (!have_i) {
 #pragma unroll
-                    for (int r = 0; r < NR; ++r) b[r] = fma(g[r], nd, b[r]);
+                            for (int r = 0; r < NR; ++r) g[r] = (l + 16 * r < k) ? gp[16 * r] : 0.0;
+                        }
+#pragma unroll
+                        for (int r = 0; r < NR; ++r) b[r] = fma(g[r], nd, b[r]);
+                        if (i < 64) cur_lo |= 1ull << (i & 63); else cur_hi |= 1ull << (i & 63);
+                    }
+                    gp += k;
                     __builtin_amdgcn_sched_barrier(0);
                 }
             });
+            act_lo = cur_lo;
+            act_hi = cur_hi;
             it += go ? 1 : 0;
         }
         if (cvalid) {
@@ -439,11 +464,11 @@ int k_nnls_wave(hipStream_t s, const double* G, int64_t gstride, const double* B
             default: return launch_nnls_quad<4>(s, G, gstride, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
         }
     }
-    // per-column Grams above that, up to k = 104: four columns per wave on the Gram in global memory.  Measured per masked
-    // iteration at 30 000 x 200 000 (nnls_h, ms; wave kernel -> this one): k = 56: 102 -> 62, 64: 119 -> 84, 80: 234 -> 146,
-    // 100: 330 -> 293; it reads every row in every sweep (1.6 TB/s at k = 100) where the wave kernel skips the rows of
-    // coordinates that do not move, and loses from k = 112 on (370 -> 394, k = 128: 416 -> 566).  (env: A/B tests)
-    if (gstride != 0 && k <= (getenv("SGL_NNLS_QUAD_GLOBAL_128") ? 128 : 104) && !getenv("SGL_NNLS_NO_QUAD_GLOBAL")) {
+    // per-column Grams above that, up to k = 112: four columns per wave on the Gram in global memory.  Measured per masked
+    // iteration at 30 000 x 200 000 (nnls_h, ms; wave kernel -> this one): k = 56: 102 -> 50, 64: 119 -> 68, 80: 234 -> 122,
+    // 100: 330 -> 245, 112: 370 -> 311; at k = 128 (eight row registers per lane) 416 -> 428: the wave kernel stays there.
+    // (env: A/B tests)
+    if (gstride != 0 && k <= (getenv("SGL_NNLS_QUAD_GLOBAL_128") ? 128 : 112) && !getenv("SGL_NNLS_NO_QUAD_GLOBAL")) {
         switch ((k + 15) / 16) {
             case 1: case 2: case 3: case 4: return launch_nnls_quad_global<4>(s, G, gstride, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
             case 5: return launch_nnls_quad_global<5>(s, G, gstride, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
