@@ -186,6 +186,8 @@ def main():
     import torch
     import singlet_amd as sa
 
+    if "SGL_BENCH_FORCE_DEVICE" in os.environ:   # plumbing tests on a 1-GPU box: every rank on one device (RCCL then refuses the team)
+        local_rank = int(os.environ["SGL_BENCH_FORCE_DEVICE"])
     torch.cuda.set_device(local_rank)
     mode = args.comm
     if args.native_comm:

@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests -m gpu -q -k "ard or mask or config5 or team" 2>&1 | grep -E "passed|failed|FAILED|Error" | tail -5
-for k in 10 30 50 64 80 100 128; do
-    echo "k=$k $(python scripts/ard_rate.py 200000 30000 $k 2 | python -c "import json,sys; j=json.loads(sys.stdin.read()); print(round(j['ms_per_iter'],1), {a:round(b,1) for a,b in j['phases_ms_per_iter'].items() if b>0.05}, j['test_mse'][-1])")"
-done
+export SGL_BENCH_FORCE_DEVICE=0
+timeout 240 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 2 --warmup 1 --cells 60000 --no-cpu-baseline > gpurun_out/two_ranks_one_gpu.log 2>&1
+echo "exit code $?"
+grep -v "^$" gpurun_out/two_ranks_one_gpu.log | tail -25 | cut -c1-400
