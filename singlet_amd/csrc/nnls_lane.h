@@ -16,6 +16,9 @@
 #ifndef SGL_NNLS_WPE
 #define SGL_NNLS_WPE 2   // minimum waves per SIMD the register allocation must allow
 #endif
+#ifndef SGL_NNLS_GRAM_LDS
+#define SGL_NNLS_GRAM_LDS 1
+#endif
 #ifndef SGL_NNLS_REPACK_NUM
 #define SGL_NNLS_REPACK_NUM 3
 #define SGL_NNLS_REPACK_DEN 8
@@ -52,6 +55,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SGL_NNLS_WP
     // columns of this pass: all of them (first pass) or the list written by the previous pass
     const int64_t n_in = ps.list ? (int64_t)*ps.count : ncols;
     if ((int64_t)blockIdx.x * blockDim.x >= n_in) return;
+    // GV, k <= 64: the padded Gram (rows 0 .. KP: the Gram and the reciprocals of its diagonal, (KP + 1) x GS doubles, 33 KB
+    // at KP = 64) is staged ONCE per workgroup in LDS and the sweeps read their rows from there: immediate offsets off one
+    // per-lane base (no per-coordinate address arithmetic), LDS latency instead of the vector cache's.
+    constexpr bool GLDS = GV && !XM && SGL_NNLS_GRAM_LDS;
+    constexpr int GS_ = ((KP + 15) / 16) * 16;
+    __shared__ double Gl[GLDS ? (KP + 1) * GS_ : 1];
+    if (GLDS) {
+        for (int e = threadIdx.x; e < (KP + 1) * GS_; e += blockDim.x) Gl[e] = Gpad[e];
+        __syncthreads();
+    }
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool in_range = gid < n_in;
     const int64_t col = in_range ? (ps.list ? (int64_t)ps.list[gid] : gid) : 0;
@@ -105,7 +118,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SGL_NNLS_WP
         asm volatile("" : "+s"(gofs));
         const double* __restrict__ Gs = Gpad + gofs;
         constexpr int NG = (KP + 15) / 16, GS = NG * 16;
-        const double* __restrict__ Gv = Gpad + gofs + (threadIdx.x & 15);
+        const double* __restrict__ Gvg = Gpad + gofs + (threadIdx.x & 15);
+        const int gl0 = gofs + (int)(threadIdx.x & 15);
+        // entry X of this lane's column of the padded Gram (LDS keeps its address space: no generic pointer)
+        auto Gv = [&](int X) -> double { if constexpr (GLDS) return Gl[gl0 + X]; else return Gvg[X]; };
         // GV: explicit one-row-ahead software pipeline of the Gram rows (g2[parity]), fenced with
         // scheduling barriers: left alone, hipcc hoists the loads of dozens of rows of this straight-line
         // code and spills (kilobytes of scratch per lane at k > 64).
@@ -117,12 +133,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SGL_NNLS_WP
         double rrow[(GV && RCP) ? NG : 1];
         if (GV && RCP) {
 #pragma unroll
-            for (int m = 0; m < NG; ++m) rrow[m] = Gv[KP * GS + 16 * m];
+            for (int m = 0; m < NG; ++m) rrow[m] = Gv(KP * GS + 16 * m);
         }
         double g2[G2 ? 2 : 1][NG];
         if (GV && G2) {
 #pragma unroll
-            for (int m = 0; m < NG; ++m) g2[0][m] = Gv[16 * m];
+            for (int m = 0; m < NG; ++m) g2[0][m] = Gv(16 * m);
         }
         if (XM) {  // the first PF coordinates of this sweep (slot = coordinate % PF)
 #pragma unroll
@@ -141,11 +157,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SGL_NNLS_WP
                     if (G2) {
                         if (i + 1 < KLOW || i + 1 < k) {
 #pragma unroll
-                            for (int m = 0; m < NG; ++m) g2[(i + 1) & 1][m] = Gv[(i + 1) * GS + 16 * m];
+                            for (int m = 0; m < NG; ++m) g2[(i + 1) & 1][m] = Gv((i + 1) * GS + 16 * m);
                         }
                     } else {
 #pragma unroll
-                        for (int m = 0; m < NG; ++m) g2[0][m] = Gv[i * GS + 16 * m];
+                        for (int m = 0; m < NG; ++m) g2[0][m] = Gv(i * GS + 16 * m);
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
