@@ -61,8 +61,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SGL_NNLS_WP
     constexpr bool GLDS = GV && !XM && SGL_NNLS_GRAM_LDS;
     constexpr int GS_ = ((KP + 15) / 16) * 16;
     __shared__ double Gl[GLDS ? (KP + 1) * GS_ : 1];
+    __shared__ __attribute__((aligned(16))) double Dl[GLDS ? 2 * KP : 2];   // (G_jj, 1 / G_jj) pairs: one uniform 16-byte read per coordinate
     if (GLDS) {
         for (int e = threadIdx.x; e < (KP + 1) * GS_; e += blockDim.x) Gl[e] = Gpad[e];
+        for (int j = threadIdx.x; j < KP; j += blockDim.x) {
+            Dl[2 * j] = Gpad[j * GS_ + j];
+            Dl[2 * j + 1] = Gpad[KP * GS_ + j];
+        }
         __syncthreads();
     }
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -130,11 +135,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SGL_NNLS_WP
         // (not in the k > 64 instances: they have no registers to spare -- measured 11 % slower at k = 100 -- and
         // keep the division)
         constexpr bool RCP = !XM;
-        double rrow[(GV && RCP) ? NG : 1];
-        if (GV && RCP) {
+        double rrow[(GV && RCP && !GLDS) ? NG : 1];
+        if (GV && RCP && !GLDS) {
 #pragma unroll
             for (int m = 0; m < NG; ++m) rrow[m] = Gv(KP * GS + 16 * m);
         }
+        // GLDS: the diagonal pair of the coming coordinate, read (uniform address: a broadcast) one coordinate ahead
+        double dnext0 = 0.0, dnext1 = 1.0;
+        if (GLDS) { dnext0 = Dl[gofs]; dnext1 = Dl[gofs + 1]; }
         double g2[G2 ? 2 : 1][NG];
         if (GV && G2) {
 #pragma unroll
@@ -166,8 +174,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SGL_NNLS_WP
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int m = 0; m < NG; ++m) grow[m] = g2[G2 ? (i & 1) : 0][m];
-                    gii = nnls_dpp_bcast<(i & 15)>(grow[i >> 4]);
-                    rii = RCP ? nnls_dpp_bcast<(i & 15)>(rrow[RCP ? (i >> 4) : 0]) : 0.0;
+                    if (GLDS) {
+                        gii = dnext0; rii = dnext1;
+                        if (i + 1 < KP) { dnext0 = Dl[gofs + 2 * (i + 1)]; dnext1 = Dl[gofs + 2 * (i + 1) + 1]; }
+                    } else {
+                        gii = nnls_dpp_bcast<(i & 15)>(grow[i >> 4]);
+                        rii = RCP ? nnls_dpp_bcast<(i & 15)>(rrow[(RCP && !GLDS) ? (i >> 4) : 0]) : 0.0;
+                    }
                 } else {
                     gii = Gs[i + KP * i];
                     rii = Gs[KP * KP + i];
