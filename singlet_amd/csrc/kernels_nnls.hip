@@ -17,6 +17,7 @@
 // arithmetic difference to an SSE2 build of the reference is FMA contraction of
 // b - G*delta.
 #include "sgl_internal.h"
+#include <atomic>
 #include "nnls_static_for.h"
 #include <algorithm>
 #include <cstdlib>
@@ -434,7 +435,7 @@ static int launch_nnls_quad(hipStream_t s, const double* G, int64_t gstride, con
                             int k, int64_t ncols, double L1, double L2, unsigned long long* sweep_counter) {
     const int TRI = k * (k + 1) / 2, TS = (TRI + 1) & ~1;
     const size_t lds = sizeof(double) * 4 * (size_t)TS;
-    static bool attr_set[64] = {false};   // per (function, device)
+    static std::atomic<bool> attr_set[64];   // per (function, device); several host threads may drive devices at once
     int dev = 0;
     HIPCHK(hipGetDevice(&dev));
     if (lds > 48 * 1024 && (dev < 0 || dev >= 64 || !attr_set[dev])) {

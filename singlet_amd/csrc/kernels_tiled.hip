@@ -35,6 +35,7 @@
 // the tile range is split over blockIdx.y; each split writes a partial k x ncol
 // slab and acc_tiled_reduce sums the slabs in a fixed order.
 #include "sgl_internal.h"
+#include <atomic>
 #include <hipcub/hipcub.hpp>
 #include <stdlib.h>
 #include <utility>
@@ -566,7 +567,7 @@ int k_acc_tiled(hipStream_t s, const DevTiled& S, const double* F, int ldf, doub
     const int KS = (S.k + 1) & ~1;
     const size_t lds = (size_t)S.TR * KS * 8 + 512;
     // the attribute belongs to the (function, device) pair: one process may drive several devices
-    static bool attr_set[64] = {false};
+    static std::atomic<bool> attr_set[64];   // several host threads may drive devices at once (replica sweep)
     int dev = 0;
     HIPCHK(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
