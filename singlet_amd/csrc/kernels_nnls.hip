@@ -39,6 +39,9 @@ int k_nnls_lane_launch4(hipStream_t s, const double* Gpad, int KP, double* B, do
                         int64_t ncols, double L1, double L2, unsigned long long* sweep_counter, const NnlsPass& ps, dim3 g,
                         dim3 b);
 
+int k_nnls_half_launch(hipStream_t s, const double* Gpad, int KP, double* B, double* X, const int64_t* col_nnz, int k,
+                       int64_t ncols, double L1, double L2, unsigned long long* sweep_counter, const NnlsPass& ps);
+
 int64_t nnls_repack_min_cols() {
     // read on every call (cheap): tests lower it to drive small problems through the multi-pass path
     const char* e = getenv("SGL_NNLS_REPACK_MIN_COLS");
@@ -52,12 +55,16 @@ int nnls_gram_stride(int KP) { return KP > 40 ? (KP + 15) / 16 * 16 : KP; }
 // padded rank of the lane kernel instance serving rank k (0: no instance, use the wave kernel)
 int nnls_lane_kp(int k) { return k <= 64 ? (k + 1) / 2 * 2 : (k <= SGL_LANE_NNLS_MAX_K ? (k + 7) / 8 * 8 : 0); }
 
+// 64 < k <= 104: two lanes per column, everything in registers (nnls_half.h); SGL_NNLS_NO_HALF=1 keeps the x-scratch instances
+static bool nnls_use_half(int KP) { return KP > 64 && KP <= 104 && !getenv("SGL_NNLS_NO_HALF"); }
+static bool nnls_needs_xt(int KP) { return KP > 64 && !nnls_use_half(KP); }
+
 int nnls_scratch_alloc(NnlsScratch& sc, int64_t cap, int k_for_xt) {
     nnls_scratch_free(sc);
     if (cap <= 0) return SGL_OK;
     bool ok = true;
     // x scratch of the k > 64 instances; lists / per-column state only where re-packing is used
-    if (k_for_xt > 64) ok = hipMalloc(&sc.xt, sizeof(double) * (size_t)cap * k_for_xt) == hipSuccess;
+    if (nnls_needs_xt(nnls_lane_kp(k_for_xt))) ok = hipMalloc(&sc.xt, sizeof(double) * (size_t)cap * k_for_xt) == hipSuccess;
     if (ok && cap >= nnls_repack_min_cols())
         ok = hipMalloc(&sc.list[0], sizeof(int32_t) * cap) == hipSuccess && hipMalloc(&sc.list[1], sizeof(int32_t) * cap) == hipSuccess &&
              hipMalloc(&sc.counts, sizeof(uint32_t) * (SGL_NNLS_MAX_PASSES + 1)) == hipSuccess &&
@@ -85,12 +92,18 @@ void nnls_scratch_free(NnlsScratch& sc) {
 int k_nnls_lane(hipStream_t s, const double* Gpad, int KP, double* B, double* X, const int64_t* col_nnz, int k,
                 int64_t ncols, double L1, double L2, unsigned long long* sweep_counter, const NnlsScratch* scr) {
     if (ncols <= 0) return SGL_OK;
-    auto launch = (KP <= 40) ? k_nnls_lane_launch1 : (KP <= 64 ? k_nnls_lane_launch2 : (KP <= 104 ? k_nnls_lane_launch3 : k_nnls_lane_launch4));
-    if (KP > 64 && (scr == nullptr || scr->xt == nullptr || scr->cap < ncols)) {
+    auto launch_lane = (KP <= 40) ? k_nnls_lane_launch1 : (KP <= 64 ? k_nnls_lane_launch2 : (KP <= 104 ? k_nnls_lane_launch3 : k_nnls_lane_launch4));
+    const bool half = nnls_use_half(KP);
+    auto launch = [&](hipStream_t s_, const double* Gp_, int KP_, double* B_, double* X_, const int64_t* nz_, int k_, int64_t nc_, double L1_,
+                      double L2_, unsigned long long* sw_, const NnlsPass& ps_, dim3 g_, dim3 b_) {
+        return half ? k_nnls_half_launch(s_, Gp_, KP_, B_, X_, nz_, k_, nc_, L1_, L2_, sw_, ps_)
+                    : launch_lane(s_, Gp_, KP_, B_, X_, nz_, k_, nc_, L1_, L2_, sw_, ps_, g_, b_);
+    };
+    if (nnls_needs_xt(KP) && (scr == nullptr || scr->xt == nullptr || scr->cap < ncols)) {
         sgl_set_error("k_nnls_lane: k > 64 needs the x scratch");
         return SGL_ESTATE;
     }
-    double* xt = (KP > 64) ? scr->xt : nullptr;
+    double* xt = nnls_needs_xt(KP) ? scr->xt : nullptr;
     const dim3 g((unsigned)((ncols + 255) / 256)), b(256);
     const bool repack = scr != nullptr && scr->list[0] != nullptr && scr->cap >= ncols && ncols >= nnls_repack_min_cols();
     if (!repack) {

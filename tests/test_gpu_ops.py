@@ -273,7 +273,7 @@ def test_nnls(ctx, ora, k, L1, L2):
     assert sweeps == esw
 
 
-@pytest.mark.parametrize("k", [7, 12, 50])
+@pytest.mark.parametrize("k", [7, 12, 50, 66, 72, 97, 104, 120])
 def test_nnls_repack_passes_are_bit_identical(ctx, k, monkeypatch):
     """The multi-pass lane kernel (stragglers re-packed between passes, nnls_lane.h) must give
     bit-identical solutions and the same sweep total as the one-pass kernel.  Columns with very
@@ -290,6 +290,35 @@ def test_nnls_repack_passes_are_bit_identical(ctx, k, monkeypatch):
     monkeypatch.setenv("SGL_NNLS_REPACK_MIN_COLS", "512")
     X2, s2 = ctx.op_nnls(G, B, X0, 0.01, 0.0)
     assert np.array_equal(X1, X2) and s1 == s2
+
+
+@pytest.mark.parametrize("k", [65, 71, 72, 73, 88, 96, 97, 100, 104])
+def test_nnls_two_lanes_per_column_matches_the_x_scratch_instances(ctx, k, monkeypatch):
+    """64 < k <= 104 runs with two lanes per column (nnls_half.h); SGL_NNLS_NO_HALF=1 selects the lane-per-column
+    instances with x in a global scratch.  Same operations in the same order: bit-identical solutions, equal sweep totals,
+    one pass or re-packed passes, with a ragged column count (partial waves and workgroups)."""
+    rng = np.random.default_rng(300 + k)
+    ncols = 5000 + 37
+    F = rng.random((3 * k + 5, k))
+    G = F.T @ F + 1e-15 * np.eye(k)
+    B = rng.normal(size=(ncols, k)) * 3 + 1.0
+    B *= np.exp(rng.normal(size=(ncols, 1)) * 2)
+    X0 = np.abs(rng.normal(size=(ncols, k))) * (rng.random((ncols, k)) < 0.5) * 1e-3
+    out = {}
+    for half in (True, False):
+        for repack in (False, True):
+            if half:
+                monkeypatch.delenv("SGL_NNLS_NO_HALF", raising=False)
+            else:
+                monkeypatch.setenv("SGL_NNLS_NO_HALF", "1")
+            if repack:
+                monkeypatch.setenv("SGL_NNLS_REPACK_MIN_COLS", "512")
+            else:
+                monkeypatch.delenv("SGL_NNLS_REPACK_MIN_COLS", raising=False)
+            out[(half, repack)] = ctx.op_nnls(G, B, X0, 0.02, 0.01)
+    X, s = out[(False, False)]
+    for key, (Xo, so) in out.items():
+        assert np.array_equal(X, Xo) and s == so, key
 
 
 def test_scale_and_cor(ctx, ora):
