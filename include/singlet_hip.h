@@ -416,6 +416,13 @@ SGL_API int sgl_op_mask(sgl_ctx* ctx, uint64_t state, uint64_t inv_density, int6
                 uint8_t* out);
 /* AAt (src/singlet.cpp:200-206): G = F F^T (+1e-15 on the diagonal), F k x cols. */
 SGL_API int sgl_op_gram(sgl_ctx* ctx, const double* F, int32_t k, int64_t cols, double* G);
+/* The per-column Gram downdate of predict_mask (src/singlet.cpp:458-463): for the columns c in [0, ncols)
+ * out[c] (k x k) = G - (AAt(F[:, idx_c]) + 1e-15 I), idx_c = the rows r in [0, nrow) with draw(...) true
+ * (mask_t = 0: draw(cell = c + col_offset, gene = r + row_offset); 1: draw(cell = r + row_offset, gene = c + col_offset));
+ * G = NULL: the plain sum AAt(F[:, idx_c]) without ridge (the partial a shard contributes).  F is nrow x k row-major
+ * (k x nrow column-major).  use_lists = 0: the rows are hashed inside the kernel; 1: from the mask lists built first. */
+SGL_API int sgl_op_mask_gram(sgl_ctx* ctx, const double* F, const double* G, int32_t k, int32_t nrow, int64_t ncols, uint64_t seed,
+                uint64_t inv_density, int mask_t, int64_t col_offset, int64_t row_offset, int use_lists, double* out);
 /* Right-hand sides of predict (src/singlet.cpp:341-343) for the resident
  * shard: which = 0: B = F * A (F k x nrow, B k x ncol); which = 1: B = F * At;
  * which = 2 / 3: the same two products through the LDS-tiled kernel (k <= 128) that the

@@ -122,6 +122,8 @@ SIGNATURES = {
     "sgl_op_gram": (C.c_int, [C.c_void_p, f64p, C.c_int32, C.c_int64, f64p]),
     "sgl_op_rhs": (C.c_int, [C.c_void_p, C.c_int, f64p, C.c_int32, f64p]),
     "sgl_op_nnls": (C.c_int, [C.c_void_p, f64p, f64p, f64p, C.c_int32, C.c_int64, C.c_double, C.c_double, i32p]),
+    "sgl_op_mask_gram": (C.c_int, [C.c_void_p, f64p, f64p, C.c_int32, C.c_int32, C.c_int64, C.c_uint64, C.c_uint64, C.c_int, C.c_int64,
+                                   C.c_int64, C.c_int, f64p]),
     "sgl_op_scale": (C.c_int, [C.c_void_p, f64p, C.c_int32, C.c_int64, f64p]),
     "sgl_op_cor": (C.c_int, [C.c_void_p, f64p, f64p, C.c_int64, f64p]),
     "sgl_op_mse_test": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, f64p]),

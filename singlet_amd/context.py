@@ -311,6 +311,16 @@ class Context:
         check(self._L.sgl_op_nnls(self._h, ptr(G, f64p), ptr(B, f64p), ptr(X, f64p), k, ncols, L1, L2, C.byref(sw)))
         return X, sw.value
 
+    def op_mask_gram(self, F, G, ncols, seed, inv_density, mask_t=0, col_offset=0, row_offset=0, use_lists=False):
+        """Per-column Gram downdates of predict_mask for columns 0 .. ncols-1: F is nrow x k, G k x k or None (raw sums)."""
+        F = _f(F)
+        nrow, k = F.shape
+        out = np.empty((ncols, k, k))
+        Gp = ptr(_f(G), f64p) if G is not None else None
+        check(self._L.sgl_op_mask_gram(self._h, ptr(F, f64p), Gp, k, nrow, ncols, int(seed), int(inv_density), int(mask_t),
+                                       int(col_offset), int(row_offset), 1 if use_lists else 0, ptr(out, f64p)))
+        return out
+
     def op_scale(self, F):
         F = np.array(F, dtype=np.float64, order="C")
         cols, k = F.shape

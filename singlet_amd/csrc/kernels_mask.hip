@@ -5,6 +5,9 @@
 //  * mse_test (src/singlet.cpp:536-568).
 // The hash is the bit-exact uint64 rng of kernels_hash.hip.
 #include "sgl_internal.h"
+#include "nnls_static_for.h"
+#include <atomic>
+#include <hipcub/hipcub.hpp>
 #include <cstdlib>
 #include <utility>
 #include <type_traits>
@@ -112,6 +115,13 @@ __device__ __forceinline__ void static_for_rem_impl(F_&& f, std::integer_sequenc
 template <int N, typename F_>
 __device__ __forceinline__ void static_for_rem(F_&& f) { static_for_rem_impl(f, std::make_integer_sequence<int, (N > 0 ? N : 1)>{}); }
 #define MG_QW 1024  // ring queue of drawn rows per wave (power of two)
+// tiles per epilogue batch (8 KB of LDS each); at least what the remainder partials need (REM * NB * 2 KB)
+constexpr int mg_tb(int ntiles, int rem, int nb) {
+    // small tile sets run several workgroups per CU: keep their LDS small (17 KB of row queues + 8 KB per tile of the batch)
+    const int want = ntiles <= 6 ? 2 : (ntiles <= 15 ? 4 : 8), need = (rem * nb + 3) / 4;
+    return want > need ? want : need;
+}
+#define MG_TB(NTILES_, REM_, NB_) mg_tb(NTILES_, REM_, NB_)
 
 // NPARTS > 1 (k > 96): the tile set no longer fits a wave's registers; launch PART = 0 .. NPARTS-1, each
 // computing the tiles t with t % NPARTS == PART (the rows are hashed again in every part).
@@ -127,6 +137,81 @@ __device__ __forceinline__ double mg_bcast(double v) {
     return __hiloint2double(hi, lo);
 }
 
+
+// ---- epilogue of the MFMA downdate kernels: sum the 4 waves' partial tiles, Gout = G - (Gsub + 1e-15 I) ----------
+// Tiles go through LDS in batches of TB: ONE barrier pair per batch, then wave w finishes the batch's tiles
+// u = w, w + 4, ... (sum of the four partials in wave order, as ever; the Gram value; the two mirrored stores), so
+// that the loads and stores of all tiles are in flight together.  The first form took the tiles one by one -- two
+// barriers, wave 0 alone reading G and storing -- ~1 us per tile with the matrix pipe idle: 55 us per column at
+// k = 100, 30 % of the H-side launches (profiles/r3_mask_gram_ablation.md).  Same sums in the same order.
+constexpr int mg_tile_bi(int t) { int bi = 0; while ((bi + 1) * (bi + 2) / 2 <= t) ++bi; return bi; }
+constexpr int mg_tile_bj(int t) { return t - mg_tile_bi(t) * (mg_tile_bi(t) + 1) / 2; }
+
+template <int NT, int NPARTS, int PART, int REM, int TB, int NTILES, int NB, int NR>
+__device__ __forceinline__ void mg_epilogue(const mg_d4 (&acc)[NTILES], const double (&accr)[NR][NB], double* __restrict__ epi, int wave,
+                                            int lane, const double* __restrict__ G, double* __restrict__ out, int k, int raw) {
+    const int r16 = lane & 15, kk = lane >> 4;
+    constexpr int NBATCH = (NTILES + TB - 1) / TB;
+    static_for<NBATCH>([&](auto bc) {
+        constexpr int q0 = decltype(bc)::value * TB;
+        __syncthreads();   // the main loop (first batch) / the reads of the previous batch are done
+        static_for<TB>([&](auto uc) {
+            constexpr int u = decltype(uc)::value, qa = q0 + u;
+            if constexpr (qa < NTILES) {
+                double* dst = epi + (u * 4 + wave) * 256 + lane * 4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dst[r] = acc[qa][r];
+            }
+        });
+        __syncthreads();
+        static_for<TB>([&](auto uc) {
+            constexpr int u = decltype(uc)::value, qa = q0 + u;
+            if constexpr (qa < NTILES) {
+                if ((u & 3) == wave) {
+                    constexpr int t = PART + qa * NPARTS, bi = mg_tile_bi(t), bj = mg_tile_bj(t);
+                    const double* src = epi + u * 4 * 256 + lane * 4;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        double sub = ((src[r] + src[256 + r]) + src[512 + r]) + src[768 + r];
+                        const int row = bi * 16 + kk + 4 * r;  // D row (lane >> 4) + 4 r
+                        const int cc = bj * 16 + r16;          // D col lane & 15
+                        if (row < k && cc < k) {
+                            if (row == cc && !raw) sub += 1e-15;
+                            const double v = raw ? sub : G[(size_t)cc * k + row] - sub;
+                            out[(size_t)cc * k + row] = v;
+                            if (row != cc) out[(size_t)row * k + cc] = v;
+                        }
+                    }
+                }
+            }
+        });
+    });
+    if constexpr (REM > 0) {   // remainder rows: the 4 row groups of the 4 waves, fixed order (w, then g)
+        static_assert(REM * NB * 4 * 64 <= TB * 4 * 256, "the remainder partials must fit the tile buffer");
+        __syncthreads();
+        static_for<REM>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) epi[((i * NB + b) * 4 + wave) * 64 + lane] = accr[i][b];
+        });
+        __syncthreads();
+        for (int o = wave * 64 + lane; o < REM * NB * 16; o += 256) {
+            const int ib = o >> 4, c16 = o & 15, i = ib / NB, b = ib - i * NB;
+            const double* src = epi + (size_t)ib * 4 * 64 + c16;
+            double sub = 0.0;
+            for (int w = 0; w < 4; ++w)
+                for (int g = 0; g < 4; ++g) sub += src[w * 64 + g * 16];
+            const int row = 16 * NT + i, cc = 16 * b + c16;
+            if (row < k && cc < k && cc <= row) {
+                if (row == cc && !raw) sub += 1e-15;
+                const double v = raw ? sub : G[(size_t)cc * k + row] - sub;
+                out[(size_t)cc * k + row] = v;
+                if (row != cc) out[(size_t)row * k + cc] = v;
+            }
+        }
+    }
+}
+
 template <int NT, int NPARTS = 1, int PART = 0, int REM = 0>
 __global__ __launch_bounds__(256) void mask_gram_mfma_kernel(int64_t col0, int64_t ncols, int32_t nrow,
                                                              const int64_t* __restrict__ col_nnz,
@@ -136,7 +221,7 @@ __global__ __launch_bounds__(256) void mask_gram_mfma_kernel(int64_t col0, int64
     constexpr int NTILES_ALL = NT * (NT + 1) / 2;
     constexpr int NTILES = (NTILES_ALL - PART + NPARTS - 1) / NPARTS;  // tiles of this part
     __shared__ int list[4 * (MG_QW + 64)];   // per wave: the ring + a dump slot for the lanes that drew nothing
-    __shared__ double sm[4][64 * 4];
+    extern __shared__ __attribute__((aligned(16))) double mg_epi_raw[];   // epilogue buffer: MG_TB tiles x 4 waves x 256
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, kk = lane >> 4;
     const int64_t lc = blockIdx.x;
@@ -167,6 +252,13 @@ __global__ __launch_bounds__(256) void mask_gram_mfma_kernel(int64_t col0, int64
             const int fr = b * 16 + r16;
             f[b] = (valid && fr < k) ? F[(int64_t)row * k + fr] : 0.0;
         }
+    };
+    // the same for a complete group, branch-free: only the last block can reach past the rank
+    auto load_group_full = [&](double (&f)[NB], unsigned first) {
+        const double* src = F + (int64_t)q[(first + kk) & (MG_QW - 1)] * k + r16;
+#pragma unroll
+        for (int b = 0; b + 1 < NB; ++b) f[b] = src[16 * b];
+        f[NB - 1] = ((NB - 1) * 16 + r16 < k) ? src[16 * (NB - 1)] : 0.0;
     };
     auto mfma_group = [&](const double (&f)[NB]) {
         if (REM > 0) {   // the remainder rows on the VALU
@@ -207,11 +299,21 @@ __global__ __launch_bounds__(256) void mask_gram_mfma_kernel(int64_t col0, int64
     double f[NB];
     bool have = false;
     for (int64_t r0 = (int64_t)wave * 64; r0 < nrow; r0 += 256) {
-        if (have) {
-            // one basic block: the MFMAs of the loaded group, the hash of the next 64 rows in their shadow
-            double fc[NB];
+        // f holds the group gathered during the previous step (if any).  Copy it, start the gather of the NEXT group
+        // at once -- it has this step's hash and MFMAs to arrive in -- then hash 64 rows and feed the copy to the
+        // matrix cores.  (A group queued by this step's hash is gathered at the top of the next step.)
+        double fc[NB];
+        const bool have_c = have;
+        if (have_c) {
 #pragma unroll
             for (int b = 0; b < NB; ++b) fc[b] = f[b];
+        }
+        have = head - tail >= 4;
+        if (have) {
+            load_group_full(f, tail);
+            tail += 4;
+        }
+        if (have_c) {
             hash_step(r0);
             mfma_group(fc);
 #pragma unroll
@@ -223,17 +325,16 @@ __global__ __launch_bounds__(256) void mask_gram_mfma_kernel(int64_t col0, int64
             hash_step(r0);
         }
         __builtin_amdgcn_wave_barrier();
-        // the queue must never wrap onto unread rows: drain without hashing while it is nearly full
+        // the queue must never wrap onto unread rows: drain without hashing while it is nearly full (dense masks)
         while (head - tail > MG_QW - 128) {
+            if (have) {   // the gathered group first: rows enter the sums in queue order
+                mfma_group(f);
+                have = false;
+            }
             double fz[NB];
-            load_group(fz, tail, 4);
+            load_group_full(fz, tail);
             tail += 4;
             mfma_group(fz);
-        }
-        have = head - tail >= 4;
-        if (have) {   // gather the next group: in flight during the next step
-            load_group(f, tail, 4);
-            tail += 4;
         }
     }
     if (have) mfma_group(f);
@@ -245,69 +346,45 @@ __global__ __launch_bounds__(256) void mask_gram_mfma_kernel(int64_t col0, int64
         mfma_group(fz);
     }
 
-    // sum the 4 waves' tiles in a fixed order; Gout = G - (Gsub + 1e-15 I)  (quirk 8: the two 1e-15 cancel)
-    int t = 0, qa = 0;
-#pragma unroll
-    for (int bi = 0; bi < NT; ++bi)
-#pragma unroll
-        for (int bj = 0; bj <= bi; ++bj) {
-            if (t % NPARTS != PART) { ++t; continue; }
-            __syncthreads();
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sm[wave][lane * 4 + r] = acc[qa][r];
-            ++qa;
-            __syncthreads();
-            if (wave == 0) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    double sub = ((sm[0][lane * 4 + r] + sm[1][lane * 4 + r]) + sm[2][lane * 4 + r]) + sm[3][lane * 4 + r];
-                    const int row = bi * 16 + kk + 4 * r;  // D row (lane >> 4) + 4 r
-                    const int cc = bj * 16 + r16;          // D col lane & 15
-                    if (row < k && cc < k) {
-                        if (row == cc && !raw) sub += 1e-15;
-                        const double v = raw ? sub : G[(size_t)cc * k + row] - sub;
-                        out[(size_t)cc * k + row] = v;
-                        if (row != cc) out[(size_t)row * k + cc] = v;
-                    }
-                }
-            }
-            ++t;
-        }
-    if (REM > 0) {   // remainder rows: sum the 4 row groups of the 4 waves (fixed order)
-        static_for_rem<REM>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-#pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                __syncthreads();
-                sm[wave][lane] = accr[i][b];
-                __syncthreads();
-                if (wave == 0 && kk == 0) {
-                    double sub = 0.0;
-                    for (int w = 0; w < 4; ++w)
-                        for (int g = 0; g < 4; ++g) sub += sm[w][g * 16 + r16];
-                    const int row = 16 * NT + i, cc = 16 * b + r16;
-                    if (row < k && cc < k && cc <= row) {
-                        if (row == cc && !raw) sub += 1e-15;
-                        const double v = raw ? sub : G[(size_t)cc * k + row] - sub;
-                        out[(size_t)cc * k + row] = v;
-                        if (row != cc) out[(size_t)row * k + cc] = v;
-                    }
-                }
-            }
-        });
-    }
+    mg_epilogue<NT, NPARTS, PART, REM, MG_TB(NTILES, REM, NB)>(acc, accr, mg_epi_raw, wave, lane, G, out, k, raw);
 }
+
+template <int NT, int NPARTS = 1, int PART = 0, int REM = 0>
+static int launch_mask_gram_mfma(dim3 g, dim3 b, hipStream_t s, int64_t col0, int64_t ncols, int32_t nrow, const int64_t* col_nnz,
+                                 const double* F, const double* G, int k, uint64_t seed, SglDiv dv, int mask_t, int64_t col_offset,
+                                 int64_t row_offset, double* Gcols, int raw) {
+    constexpr int NTILES = (NT * (NT + 1) / 2 - PART + NPARTS - 1) / NPARTS, NB = NT + (REM > 0 ? 1 : 0);
+    constexpr size_t lds = (size_t)MG_TB(NTILES, REM, NB) * 4 * 256 * sizeof(double);
+    static std::atomic<bool> attr_set[64];
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mask_gram_mfma_kernel<NT, NPARTS, PART, REM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
+    }
+    mask_gram_mfma_kernel<NT, NPARTS, PART, REM><<<g, b, lds, s>>>(col0, ncols, nrow, col_nnz, F, G, k, seed, dv, mask_t, col_offset, row_offset, Gcols, raw);
+    return SGL_OK;
+}
+
+#include "mask_gram_list.inc"
 
 // G == nullptr: "raw" mode -- Gcols[c] = the plain sum of f f^T over the masked rows of column c (no Gram,
 // no ridge): the partial a cell shard contributes to a gene's downdate (multi.hip sums them over the ranks)
 int k_mask_gram_cols(hipStream_t s, int64_t col0, int64_t ncols, int32_t nrow, const int64_t* col_nnz,
                      const double* F, const double* G, int k, uint64_t seed, uint64_t inv_density, int mask_t,
-                     int64_t col_offset, int64_t row_offset, double* Gcols) {
+                     int64_t col_offset, int64_t row_offset, double* Gcols, const DevMaskList* L) {
     if (ncols <= 0) return SGL_OK;
     const int raw = G == nullptr ? 1 : 0;
     dim3 g((unsigned)ncols), b(256);
+    const bool lists = L != nullptr && L->mask_t == mask_t && L->ptr != nullptr && L->idx != nullptr && L->seed == seed &&
+                       L->inv == inv_density && L->nrow == nrow && L->col_off == col_offset && L->row_off == row_offset &&
+                       col0 + ncols <= L->ncol;
     if (k <= 128 && !getenv("SGL_MASK_GRAM_VALU")) {  // env: keep the VALU kernel reachable for A/B tests
-#define SGL_MGM(...) mask_gram_mfma_kernel<__VA_ARGS__><<<g, b, 0, s>>>(col0, ncols, nrow, col_nnz, F, G, k, seed, sgl_div_make(inv_density), mask_t, col_offset, row_offset, Gcols, raw)
+#define SGL_MGM(...)                                                                                                               \
+    do {                                                                                                                            \
+        if (lists) SGLCHK((launch_mask_gram_list<__VA_ARGS__>(g, b, s, col0, ncols, col_nnz, L, F, G, k, Gcols, raw)));            \
+        else SGLCHK((launch_mask_gram_mfma<__VA_ARGS__>(g, b, s, col0, ncols, nrow, col_nnz, F, G, k, seed, sgl_div_make(inv_density), mask_t, col_offset, row_offset, Gcols, raw))); \
+    } while (0)
         // k = 16 NT + r with r <= 4: the remainder rows on the VALU (REM = 2 / 4) instead of NT + 1 more tiles
         const int nt_full = k / 16, rem = k % 16;
         if (rem >= 1 && rem <= 4 && nt_full >= 1 && nt_full <= 6 && !getenv("SGL_MASK_GRAM_NO_REM")) {

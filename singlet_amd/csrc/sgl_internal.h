@@ -99,6 +99,21 @@ struct NnlsScratch {
     int64_t cap = 0;
 };
 
+// The cross-validation mask of one orientation as lists: idx[ptr[c] .. ptr[c + 1]) = the rows r (ascending) with
+// draw(cell, gene) true for column c -- built once per (seed, inv_density, shape, offsets) by two hashing passes and
+// read by mask_gram_list_kernel every iteration instead of hashing all rows x columns again (kernels_mask.hip).
+struct DevMaskList {
+    int64_t* ptr = nullptr;    // ncol + 1
+    int32_t* idx = nullptr;
+    size_t cap_ptr = 0, cap_idx = 0;
+    int64_t ncol = 0, total = 0;
+    int32_t nrow = 0;
+    uint64_t seed = 0, inv = 0;
+    int mask_t = -1;           // -1: nothing built
+    int64_t col_off = 0, row_off = 0;
+    bool refused = false;      // too large for the memory budget under this key: the hashing kernel runs
+};
+
 struct sgl_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -129,6 +144,7 @@ struct sgl_ctx {
     double* link_h = nullptr;  // c_linked_nmf: link_rows x ncol / x nrow multipliers of the right-hand sides
     double* link_w = nullptr;
     int link_h_rows = 0, link_w_rows = 0;
+    DevMaskList ML[2];         // masked path: the drawn rows of every column, per orientation (kernels_mask.hip); live with the entry streams
     double* Gcols = nullptr;   // masked path: per-column Grams of one chunk of columns (gcols_chunk * k * k)
     int64_t gcols_chunk = 0;
     double* Wd = nullptr;      // mse_test: W' = W^T diag(d) as k x m
@@ -261,7 +277,10 @@ int k_nnls_wave(hipStream_t s, const double* G, int64_t gstride, const double* B
 // masked path
 int k_mask_gram_cols(hipStream_t s, int64_t col0, int64_t ncols, int32_t nrow, const int64_t* col_nnz,
                      const double* F, const double* G, int k, uint64_t seed, uint64_t inv_density, int mask_t,
-                     int64_t col_offset, int64_t row_offset, double* Gcols);
+                     int64_t col_offset, int64_t row_offset, double* Gcols, const DevMaskList* L = nullptr);
+int sgl_mask_list_build(sgl_ctx* c, DevMaskList& L, int64_t ncol, int32_t nrow, uint64_t seed, uint64_t inv_density, int mask_t,
+                        int64_t col_offset, int64_t row_offset);
+void sgl_mask_list_free(DevMaskList& L);
 int k_mask_gram_finalize(hipStream_t s, const double* G, const double* S, int k, int64_t ncols, double* out);
 int k_mse_test(sgl_ctx* c, const double* Wd, const double* H, int k, uint64_t seed, uint64_t inv_density,
                double* out_dev);

@@ -159,6 +159,8 @@ static void free_fit(sgl_ctx* c, bool keep_streams = false) {
     if (!keep_streams) {
         sgl_tiled_free(c->TA);
         sgl_tiled_free(c->TAt);
+        sgl_mask_list_free(c->ML[0]);
+        sgl_mask_list_free(c->ML[1]);
     }
     c->use_tiled = false;
     c->k = 0;
@@ -925,10 +927,19 @@ int sgl_predict_mask_dev(sgl_ctx* c, const DevCSC& M, const int64_t* col_nnz, co
     { Phase ph(c, rhs_phase);
       SGLCHK(sgl_masked_rhs(c, mask_t, F, Bbuf, seed, inv_density)); }
     const int64_t chunk = c->gcols_chunk;
+    // the mask of this orientation as lists, built on the first pass of a fit (no-op afterwards); SGL_MASK_NO_LIST=1
+    // or a mask too dense for the memory budget: every pass hashes
+    DevMaskList* L = nullptr;
+    if (k <= 128 && !getenv("SGL_MASK_NO_LIST")) {
+        Phase ph(c, SGL_PH_MASK);
+        DevMaskList& Lm = c->ML[mask_t ? 1 : 0];
+        SGLCHK(sgl_mask_list_build(c, Lm, M.ncol, M.nrow, seed, inv_density, mask_t, col_off, row_off));
+        if (Lm.mask_t == mask_t) L = &Lm;
+    }
     for (int64_t c0 = 0; c0 < M.ncol; c0 += chunk) {
         const int64_t nc = std::min<int64_t>(chunk, M.ncol - c0);
         { Phase ph(c, SGL_PH_MASK);
-          SGLCHK(k_mask_gram_cols(c->stream, c0, nc, M.nrow, col_nnz, F, c->G, k, seed, inv_density, mask_t, col_off, row_off, c->Gcols)); }
+          SGLCHK(k_mask_gram_cols(c->stream, c0, nc, M.nrow, col_nnz, F, c->G, k, seed, inv_density, mask_t, col_off, row_off, c->Gcols, L)); }
         { Phase ph(c, nnls_phase);
           SGLCHK(k_nnls_wave(c->stream, c->Gcols, (int64_t)k * k, Bbuf + (size_t)c0 * k, X + (size_t)c0 * k,
                              col_nnz ? col_nnz + c0 : nullptr, k, nc, L1, L2, counter)); }
@@ -1414,6 +1425,31 @@ extern "C" int sgl_op_gram(sgl_ctx* c, const double* F, int32_t k, int64_t cols,
     int rc = k_gram(c, dF.p, k, cols, dG.p, 1e-15);
     if (rc == SGL_OK) HIPCHK(hipMemcpyAsync(G, dG.p, sizeof(double) * (size_t)k * k, hipMemcpyDeviceToHost, c->stream));
     return op_finish(c, rc, "sgl_op_gram");
+}
+
+extern "C" int sgl_op_mask_gram(sgl_ctx* c, const double* F, const double* G, int32_t k, int32_t nrow, int64_t ncols, uint64_t seed,
+                                uint64_t inv_density, int mask_t, int64_t col_offset, int64_t row_offset, int use_lists, double* out) {
+    CTX_GUARD(c);
+    if (!F || !out || k <= 0 || k > SGL_MAX_K || nrow <= 0 || ncols <= 0 || inv_density == 0) { sgl_set_error("sgl_op_mask_gram: bad arguments"); return SGL_EINVAL; }
+    DevBuf<double> dF, dG, dO;
+    SGLCHK(dF.alloc((size_t)k * nrow + 2));
+    SGLCHK(dO.alloc((size_t)k * k * ncols));
+    if (G) SGLCHK(dG.alloc((size_t)k * k));
+    HIPCHK(hipMemcpyAsync(dF.p, F, sizeof(double) * (size_t)k * nrow, hipMemcpyHostToDevice, c->stream));
+    if (G) HIPCHK(hipMemcpyAsync(dG.p, G, sizeof(double) * (size_t)k * k, hipMemcpyHostToDevice, c->stream));
+    DevMaskList L;
+    int rc = SGL_OK;
+    if (use_lists) {
+        rc = sgl_mask_list_build(c, L, ncols, nrow, seed, inv_density, mask_t, col_offset, row_offset);
+        if (rc == SGL_OK && L.mask_t != mask_t) { sgl_set_error("sgl_op_mask_gram: the lists were refused"); rc = SGL_ENOMEM; }
+    }
+    if (rc == SGL_OK)
+        rc = k_mask_gram_cols(c->stream, 0, ncols, nrow, nullptr, dF.p, G ? dG.p : nullptr, k, seed, inv_density, mask_t, col_offset, row_offset,
+                              dO.p, use_lists ? &L : nullptr);
+    if (rc == SGL_OK && hipMemcpyAsync(out, dO.p, sizeof(double) * (size_t)k * k * ncols, hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = SGL_EHIP;
+    rc = op_finish(c, rc, "sgl_op_mask_gram");
+    sgl_mask_list_free(L);
+    return rc;
 }
 
 extern "C" int sgl_op_rhs(sgl_ctx* c, int which, const double* F, int32_t k, double* B) {

@@ -41,6 +41,53 @@ def test_mask_bit_exact(ctx, ora, inv_density):
     assert np.array_equal(got, exp)
 
 
+def _mask_gram_oracle(ora, F, G, ncols, seed, inv_density, mask_t, col_off, row_off):
+    """G - (AAt(F[idx_c]) + 1e-15 I) per column (src/singlet.cpp:458-463), idx_c from the oracle's mask; G None: the raw sum."""
+    nrow, k = F.shape
+    if mask_t == 0:   # columns are cells, rows genes
+        M = ora.rng_mask(seed, col_off, ncols, nrow + row_off, inv_density)[:, row_off:]
+    else:             # columns are genes, rows cells
+        M = ora.rng_mask(seed, row_off, nrow, ncols + col_off, inv_density)[:, col_off:].T
+    out = np.empty((ncols, k, k))
+    for c in range(ncols):
+        Fs = F[M[c].astype(bool)]
+        S = Fs.T @ Fs
+        out[c] = S if G is None else G - (S + 1e-15 * np.eye(k))
+    return out
+
+
+@pytest.mark.parametrize("k", [1, 2, 5, 10, 16, 17, 18, 20, 30, 33, 36, 48, 50, 52, 64, 66, 70, 80, 84, 96, 98, 100, 104, 112, 128, 130])
+@pytest.mark.parametrize("use_lists", [False, True])
+def test_mask_gram_downdate(ctx, ora, k, use_lists):
+    """Per-column Gram downdates of predict_mask, by the hashing kernel and from the mask lists (every tile-set
+    instance: full blocks, VALU remainder rows, a partial last block, two-part tile sets; k = 130: the VALU kernel,
+    which ignores the lists), both orientations with offsets, raw sums; several hundred drawn rows per column
+    (the pipelined loop of the list kernel) down to none."""
+    rng = np.random.default_rng(500 + k)
+    nrow, ncols = 1500, 7
+    F = rng.random((nrow, k)) + 0.1
+    G = ora.aat(rng.random((3 * k + 2, k)))
+    for mask_t, inv, co, ro, raw in ((0, 5, 11, 0, False), (1, 4, 0, 23, False), (0, 3, 5, 0, True), (1, 1, 0, 0, False), (0, 700, 3, 0, False)):
+        got = ctx.op_mask_gram(F, None if raw else G, ncols, 77, inv, mask_t, co, ro, use_lists)
+        exp = _mask_gram_oracle(ora, F, None if raw else G, ncols, 77, inv, mask_t, co, ro)
+        scale = np.abs(exp).max() + 1.0
+        assert np.abs(got - exp).max() / scale < 1e-12, (mask_t, inv, raw)
+        assert np.array_equal(got, got.transpose(0, 2, 1))
+
+
+@pytest.mark.parametrize("nrow", [1, 3, 4, 5, 17, 64, 65, 250])
+def test_mask_gram_lists_short_columns(ctx, ora, nrow):
+    """Few rows: empty lists, one partial group, fewer groups than waves, the unpipelined tail only."""
+    rng = np.random.default_rng(900 + nrow)
+    for k in (7, 50, 100):
+        F = rng.random((nrow, k)) + 0.1
+        G = ora.aat(rng.random((2 * k, k)))
+        for inv in (1, 2, 9):
+            got = ctx.op_mask_gram(F, G, 9, 5, inv, 0, 2, 0, True)
+            exp = _mask_gram_oracle(ora, F, G, 9, 5, inv, 0, 2, 0)
+            assert np.abs(got - exp).max() / (np.abs(exp).max() + 1.0) < 1e-12, (k, inv)
+
+
 @pytest.mark.parametrize("k,cols", [(1, 5), (8, 400), (16, 33), (30, 2000), (50, 777), (64, 300), (70, 129), (100, 50), (128, 300),
                                     (129, 200), (300, 700), (520, 90)])
 def test_gram(ctx, ora, k, cols):
