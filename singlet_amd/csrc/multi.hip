@@ -509,8 +509,13 @@ static int team_ard_iterate(sgl_team* T, double L1, double L2, uint64_t seed, ui
         SGLCHK(sgl_phase_begin(c, SGL_PH_MASK, &pe));
         HIPCHK(hipMemsetAsync(c->Sbuf, 0, sizeof(double) * (size_t)mpad * k * k, c->stream));
         if (!c->gene_nnz_global) { sgl_set_error("team: global gene counts missing"); return SGL_ESTATE; }
+        const DevMaskList* ML = nullptr;   // this shard's part of every gene's mask as lists (built on the fit's first pass)
+        if (k <= 128 && !getenv("SGL_MASK_NO_LIST")) {
+            SGLCHK(sgl_mask_list_build(c, c->ML[1], m, c->At.nrow, seed, inv_density, 1, 0, c->cell_offset));
+            if (c->ML[1].mask_t == 1) ML = &c->ML[1];
+        }
         SGLCHK(k_mask_gram_cols(c->stream, 0, m, c->At.nrow, c->col_nnz_At_global, c->H, nullptr, k, seed, inv_density, 1, 0,
-                                c->cell_offset, c->Sbuf));
+                                c->cell_offset, c->Sbuf, ML));
         SGLCHK(sgl_phase_end(c, &pe));
         red[i] = Bw;
         sb[i] = c->Sbuf;
