@@ -20,9 +20,12 @@ ctx.ard_run(0.0, 1, 0.01, 0.0, 123, 20, 1e9, 1)   # warm-up
 ctx.fit_init(k, None)
 ctx.timing_enable(True)
 ctx.timing_get(reset=True)
+ctx.sweeps_get(reset=True)
 t0 = time.perf_counter()
 r = ctx.ard_run(0.0, iters, 0.01, 0.0, 123, 20, 1e9, iters)
 dt = time.perf_counter() - t0
 ph = ctx.timing_get(reset=True)
+sw = ctx.sweeps_get(reset=True)
 print(json.dumps({"cells": cells, "genes": genes, "k": k, "iters": iters, "ms_per_iter": 1e3 * dt / iters,
-                  "phases_ms_per_iter": {p: v[0] / iters for p, v in ph.items()}, "test_mse": r["test_mse"].tolist()}))
+                  "phases_ms_per_iter": {p: v[0] / iters for p, v in ph.items()}, "test_mse": r["test_mse"].tolist(),
+                  "sweeps_per_column_per_iter": {"h": sw["h_sweeps"] / iters / cells, "w": sw["w_sweeps"] / iters / genes}}))

@@ -888,7 +888,15 @@ int sgl_mask_workspace(sgl_ctx* c) {
     const int k = c->k;
     if (!c->Gcols) {
         const int64_t widest = std::max<int64_t>(c->A.ncol, c->At.ncol);
-        const int64_t chunk = std::max<int64_t>(256, std::min<int64_t>(widest, ((int64_t)256 << 20) / ((int64_t)k * k * 8)));
+        // Columns per chunk: the per-column solve (four columns per wave) needs ~12 000 columns in flight to fill the
+        // chip, and a chunk is one launch -- round 1 - 2's fixed 256 MB held 3 355 columns at k = 100 and left three
+        // quarters of the wave slots empty (nnls_h 196 -> 102 ms per 200 000 cells at 4 GB, 99 ms unchunked).  An eighth
+        // of the free memory, at least 256 MB, at most 16 GB; SGL_GCOLS_MB overrides (A/B tests).
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(hipMemGetInfo(&free_b, &total_b));
+        const char* e = getenv("SGL_GCOLS_MB");
+        const int64_t mb = (e && atoll(e) > 0) ? atoll(e) : std::min<int64_t>(16384, std::max<int64_t>(256, (int64_t)(free_b >> 23)));
+        const int64_t chunk = std::max<int64_t>(256, std::min<int64_t>(widest, (mb << 20) / ((int64_t)k * k * 8)));
         SGLCHK(dev_alloc(&c->Gcols, (size_t)chunk * k * k));
         c->gcols_chunk = chunk;
     }
