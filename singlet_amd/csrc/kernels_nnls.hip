@@ -482,7 +482,14 @@ int k_nnls_wave(hipStream_t s, const double* G, int64_t gstride, const double* B
     // iteration at 30 000 x 200 000 (nnls_h, ms; wave kernel -> this one): k = 56: 102 -> 50, 64: 119 -> 68, 80: 234 -> 122,
     // 100: 330 -> 245, 112: 370 -> 311; at k = 128 (eight row registers per lane) 416 -> 428: the wave kernel stays there.
     // (env: A/B tests)
-    if (gstride != 0 && k <= (getenv("SGL_NNLS_QUAD_GLOBAL_128") ? 128 : 112) && !getenv("SGL_NNLS_NO_QUAD_GLOBAL")) {
+    // Late round 3: those numbers were taken with 256 MB chunks of Grams (3 355 columns per launch at k = 100: a quarter of
+    // the wave slots).  With chunks that fill the chip (sgl_mask_workspace) k = 113 ... 128 gains too when the launch has
+    // columns enough (nnls_h k = 120: 198 -> 134 ms, 128: 216 -> 146; the 30 000 genes of the W side: 19.5 -> 24.0, so
+    // short launches keep the wave kernel there).  SGL_NNLS_QUAD_GLOBAL_112=1: the old limit for every launch.
+    const char* qmin = getenv("SGL_NNLS_QUAD_GLOBAL_MIN_COLS");   // (tests lower it to reach the k > 112 instance with small problems)
+    const int64_t long_launch = (qmin && atoll(qmin) > 0) ? atoll(qmin) : 65536;
+    const int quad_global_max_k = (ncols >= long_launch && !getenv("SGL_NNLS_QUAD_GLOBAL_112")) ? 128 : 112;
+    if (gstride != 0 && k <= quad_global_max_k && !getenv("SGL_NNLS_NO_QUAD_GLOBAL")) {
         switch ((k + 15) / 16) {
             case 1: case 2: case 3: case 4: return launch_nnls_quad_global<4>(s, G, gstride, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
             case 5: return launch_nnls_quad_global<5>(s, G, gstride, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);

@@ -109,6 +109,21 @@ def test_c_ard_nmf_parity(sa, ora, k, trace, maxit):
     assert np.allclose(got["score_overfit"], ref["score_overfit"], rtol=1e-6, atol=1e-12)
 
 
+@pytest.mark.parametrize("k", [113, 116, 128])
+def test_c_ard_nmf_parity_quad_solve_above_112(sa, ora, k, monkeypatch):
+    """Ranks 113 - 128 take the four-columns-per-wave solve on global Grams only for launches of 65 536 columns or
+    more (shorter ones keep the wave kernel): force it for a small problem and hold the fit against the oracle."""
+    monkeypatch.setenv("SGL_NNLS_QUAD_GLOBAL_MIN_COLS", "1")
+    m, n = 900, 1000
+    A = ora.synth_csc(m, n, 20)
+    At = A.t()
+    w0 = ora.synth_winit(k, m)
+    ref = ora.c_ard_nmf(A, At, 0.0, 2, 0.01, 0.0, 0, w0, 77, 20, 1e-3, 2)
+    got = sa.c_ard_nmf(to_dgc(sa, A), to_dgc(sa, At), 0.0, 2, False, 0.01, 0.0, 0, w0.T, 77, 20, 1e-3, 2)
+    _check(got, ref)
+    assert np.allclose(got["test_mse"], ref["test_mse"], rtol=1e-9, atol=0)
+
+
 def test_c_ard_nmf_overfit_break(sa, ora):
     """A tiny overfit threshold makes the reference break out of the loop early; same here."""
     A = ora.synth_csc(200, 240, 20)
