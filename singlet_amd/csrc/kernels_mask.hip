@@ -147,8 +147,10 @@ __device__ __forceinline__ double mg_bcast(double v) {
 constexpr int mg_tile_bi(int t) { int bi = 0; while ((bi + 1) * (bi + 2) / 2 <= t) ++bi; return bi; }
 constexpr int mg_tile_bj(int t) { return t - mg_tile_bi(t) * (mg_tile_bi(t) + 1) / 2; }
 
-template <int NT, int NPARTS, int PART, int REM, int TB, int NTILES, int NB, int NR>
-__device__ __forceinline__ void mg_epilogue(const mg_d4 (&acc)[NTILES], const double (&accr)[NR][NB], double* __restrict__ epi, int wave,
+// tile(integral_constant<int, q>) returns the wave's partial of tile q of this part (a register array in the hashing
+// kernel; read from the AGPR file batch by batch in the list kernel, which keeps its VGPR count low)
+template <int NT, int NPARTS, int PART, int REM, int TB, int NTILES, typename TileFn, int NB, int NR>
+__device__ __forceinline__ void mg_epilogue(TileFn&& tile, const double (&accr)[NR][NB], double* __restrict__ epi, int wave,
                                             int lane, const double* __restrict__ G, double* __restrict__ out, int k, int raw) {
     const int r16 = lane & 15, kk = lane >> 4;
     constexpr int NBATCH = (NTILES + TB - 1) / TB;
@@ -159,8 +161,9 @@ __device__ __forceinline__ void mg_epilogue(const mg_d4 (&acc)[NTILES], const do
             constexpr int u = decltype(uc)::value, qa = q0 + u;
             if constexpr (qa < NTILES) {
                 double* dst = epi + (u * 4 + wave) * 256 + lane * 4;
+                const mg_d4 a = tile(std::integral_constant<int, qa>{});
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dst[r] = acc[qa][r];
+                for (int r = 0; r < 4; ++r) dst[r] = a[r];
             }
         });
         __syncthreads();
@@ -346,7 +349,8 @@ __global__ __launch_bounds__(256) void mask_gram_mfma_kernel(int64_t col0, int64
         mfma_group(fz);
     }
 
-    mg_epilogue<NT, NPARTS, PART, REM, MG_TB(NTILES, REM, NB)>(acc, accr, mg_epi_raw, wave, lane, G, out, k, raw);
+    mg_epilogue<NT, NPARTS, PART, REM, MG_TB(NTILES, REM, NB), NTILES>([&](auto qc) { return acc[decltype(qc)::value]; }, accr, mg_epi_raw, wave, lane, G,
+                                                                       out, k, raw);
 }
 
 template <int NT, int NPARTS = 1, int PART = 0, int REM = 0>
