@@ -127,3 +127,56 @@ def test_nnls_dpp_operands_have_no_valu_write_hazard(tmp_path):
     d = text.index(".amdhsa_kernel _Z16nnls_lane_kernelILi50ELb1ELb0EE")
     ms = re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", text[d:d + 1500])
     assert ms and int(ms.group(1)) <= 64, "NNLS lane kernel <50> spills %s bytes per lane" % (ms.group(1) if ms else "?")
+
+
+# ---- mask_gram_list_kernel: accumulator tiles in named AGPRs outside hipcc's allocation ------------------------------
+MASK_SRC = os.path.join(ROOT, "singlet_amd", "csrc", "kernels_mask.hip")
+
+
+@pytest.fixture(scope="module")
+def mask_asm(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not installed")
+    out = str(tmp_path_factory.mktemp("asm") / "kernels_mask.s")
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-S",
+                    "--cuda-device-only", "-o", out, MASK_SRC], check=True, capture_output=True, timeout=900)
+    return open(out).read()
+
+
+def test_list_downdate_kernels_own_their_agprs(mask_asm):
+    """mask_gram_list_kernel names its accumulators a[0 : NREG - 1] in inline asm.  That is only sound while hipcc
+    itself never touches the AGPR file in these kernels (no spills to AGPRs, no MFMA of its own), does not spill to
+    scratch, and the kernel descriptor covers the named registers: every AGPR reference must sit inside an asm
+    statement, and the steady-state loop must not wait for vmcnt(0) before every group (branch-free loop)."""
+    kernels = re.findall(r"^(_Z21mask_gram_list_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E\w*):[^\n]*\n(.*?)s_endpgm", mask_asm, re.S | re.M)
+    assert len(kernels) >= 20, "list kernel instances not found"
+    for name, nt, nparts, part, rem, body in kernels:
+        nt, nparts, part, rem = int(nt), int(nparts), int(part), int(rem)
+        ntiles = (nt * (nt + 1) // 2 - part + nparts - 1) // nparts
+        nreg = 8 * ntiles + (2 * (nt + 1) if rem else 0)
+        in_asm = False
+        for line in body.splitlines():
+            if "#ASMSTART" in line:
+                in_asm = True
+                continue
+            if "#ASMEND" in line:
+                in_asm = False
+                continue
+            code = line.split(";")[0]
+            if not in_asm and re.search(r"\ba(\d+|\[)", code):
+                raise AssertionError("%s: hipcc uses an AGPR itself: %s" % (name, code.strip()))
+        assert "scratch_" not in body, "%s spills to scratch" % name
+        asm_text = "\n".join(re.findall(r"#ASMSTART(.*?)#ASMEND", body, re.S))
+        assert asm_text.count("v_accvgpr_write_b32") == nreg, name
+        used = [int(x) for x in re.findall(r"\ba\[(\d+)", asm_text)]
+        assert max(used) < nreg, name
+        meta = mask_asm[mask_asm.index(".amdhsa_kernel " + name):]
+        meta = meta[:meta.index(".end_amdhsa_kernel")]
+        acc_off = int(re.search(r"\.amdhsa_accum_offset (\d+)", meta).group(1))
+        nxt = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", meta).group(1))
+        assert nxt - acc_off >= nreg, "%s: the descriptor allocates %d AGPRs, the asm names %d" % (name, nxt - acc_off, nreg)
+        # the pipelined loop: the block holding 3 groups of MFMAs must contain counted waits, not only vmcnt(0)
+        blocks = re.split(r"^\.LBB\d+_\d+:", body, flags=re.M)
+        best = max(blocks, key=lambda b: b.count("v_mfma_f64_16x16x4"))
+        waits = re.findall(r"vmcnt\((\d+)\)", best)
+        assert any(int(w) > 1 for w in waits), "%s: no counted vmcnt in the steady-state loop (%s)" % (name, waits)
