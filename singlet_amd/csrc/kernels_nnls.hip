@@ -346,22 +346,32 @@ __global__ __launch_bounds__(64) void nnls_quad_global_kernel(const double* __re
         }
         double tol = 1.0;
         int it = 0, ran = 0, one = 1;
-        // Row i is only needed when coordinate i MOVES in one of the four columns (otherwise b += 0 * row).  Which
-        // coordinates move is nearly the same from sweep to sweep, so a row is fetched ahead only if its coordinate moved in
-        // the previous sweep (all of them in the first); a coordinate that moves without its row at hand fetches it then
-        // (rare).  The kernel is bound by these reads (random 128-byte lines over the chunk's Grams: ~2 TB/s).
-        unsigned long long act_lo = ~0ull, act_hi = ~0ull;
+        // Row i of a column's Gram is only needed when coordinate i MOVES in that column (otherwise b += 0 * row), and the
+        // kernel is bound by these reads (FETCH_SIZE: 675 GB per pass over 200 000 columns at k = 100 = 6.2 TB/s, the
+        // copy rate of the part).  Which coordinates move is nearly the same from sweep to sweep, so a 16-lane row
+        // fetches row i ahead only if coordinate i moved in ITS column in the previous sweep (all of them in the
+        // first); a coordinate that moves without its row at hand fetches it then (rare).  The masks are per column
+        // (one bit per coordinate, the same value in the 16 lanes of a column): a column that has stopped, or whose
+        // coordinate rests at its bound, reads nothing while its three neighbours in the wave go on.  Rows not fetched
+        // leave stale -- finite -- values in g: they meet nd = 0.
+        constexpr int NW = (16 * NR + 31) / 32;
+        unsigned act[NW], cur[NW];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) act[w] = ~0u;
+        double gn[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) gn[r] = 0.0;
         while (true) {
             const bool go = cvalid && it < 100 && (tol / kd) > 1e-8;
             if (__ballot(go) == 0ull) break;
             ++ran;
             if (go) tol = 0.0;
-            unsigned long long cur_lo = 0ull, cur_hi = 0ull;
-            double gn[NR];
+#pragma unroll
+            for (int w = 0; w < NW; ++w) cur[w] = 0u;
             // a running row pointer (its addresses cannot be hoisted out of the sweep loop: written as Gc[(i + 1) k + ...]
             // hipcc kept the addresses of all 16 NR rows in registers, 344 VGPRs at NR = 7)
             const double* __restrict__ gp = Gc + l;   // row i of the running coordinate
-            bool have = (act_lo & 1ull) != 0ull;      // row 0 fetched ahead? (wave-uniform)
+            bool have = go && (act[0] & 1u) != 0u;    // row 0 fetched ahead? (per column)
             if (have) {
 #pragma unroll
                 for (int r = 0; r < NR; ++r) gn[r] = (l + 16 * r < k) ? gp[16 * r] : 0.0;
@@ -380,7 +390,7 @@ __global__ __launch_bounds__(64) void nnls_quad_global_kernel(const double* __re
                     if (i + 1 < 16 * NR) {   // row i + 1, in flight during this coordinate -- if its coordinate moved last sweep
                         const bool more = (i + 1 <= 16 * (NR - 1)) || (i + 1 < k);
                         constexpr int i1 = i + 1;
-                        have = more && (((i1 < 64 ? (act_lo >> (i1 & 63)) : (act_hi >> (i1 & 63))) & 1ull) != 0ull);
+                        have = more && go && (act[i1 >> 5] & (1u << (i1 & 31))) != 0u;
                         if (have) {
 #pragma unroll
                             for (int r = 0; r < NR; ++r) gn[r] = (l + 16 * r < k) ? gp[k + 16 * r] : 0.0;
@@ -397,21 +407,22 @@ __global__ __launch_bounds__(64) void nnls_quad_global_kernel(const double* __re
                     double xn = xi;
                     const double nd = sgl_nnls_step(diff0, xn, tol, go, L1, L2);
                     x[ir] = (l == il) ? xn : x[ir];
-                    if (__ballot(nd != 0.0 || xn != xi) != 0ull) {   // the coordinate moves in one of the four columns
-                        if (!have_i) {
+                    const bool moved = nd != 0.0;   // (x changes only with nd != 0; a stopped column has nd = 0)
+                    if (__ballot(moved) != 0ull) {   // the coordinate moves in one of the four columns
+                        if (moved && !have_i) {
 #pragma unroll
                             for (int r = 0; r < NR; ++r) g[r] = (l + 16 * r < k) ? gp[16 * r] : 0.0;
                         }
 #pragma unroll
                         for (int r = 0; r < NR; ++r) b[r] = fma(g[r], nd, b[r]);
-                        if (i < 64) cur_lo |= 1ull << (i & 63); else cur_hi |= 1ull << (i & 63);
+                        cur[i >> 5] |= moved ? (1u << (i & 31)) : 0u;
                     }
                     gp += k;
                     __builtin_amdgcn_sched_barrier(0);
                 }
             });
-            act_lo = cur_lo;
-            act_hi = cur_hi;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) act[w] = cur[w];
             it += go ? 1 : 0;
         }
         if (cvalid) {
