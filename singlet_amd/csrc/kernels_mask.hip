@@ -562,6 +562,75 @@ __global__ __launch_bounds__(256) void mse_test_kernel(const double* __restrict_
     }
 }
 
+// mse_test from the mask lists (the cell-side lists of the fit, mask_gram_list.inc): one wave per cell, FOUR drawn
+// genes per step -- one per 16-lane row, lane l of a row on the factors l, l + 16, ... -- so a step costs one index load,
+// NJ = ceil(k / 16) loads and FMAs per lane and one 4-step row reduction for four predictions, where the hashing kernel
+// above spends a whole wave (hash, 64-lane reduction) per drawn gene.  The matrix value at (gene, cell) comes from the
+// same sliding 64-entry window over the cell's ascending non-zeros (the listed genes ascend too).  The squared errors
+// of a cell are summed in four interleaved partial sums (rounding only).
+template <int NJ>
+__global__ __launch_bounds__(256) void mse_test_list_kernel(const double* __restrict__ Ax, const int32_t* __restrict__ Ai,
+                                                            const int64_t* __restrict__ Ap, int64_t n,
+                                                            const int64_t* __restrict__ lptr, const int32_t* __restrict__ lidx,
+                                                            const double* __restrict__ Wd, const double* __restrict__ H, int k,
+                                                            double* __restrict__ losses) {
+    const int lane = threadIdx.x & 63, rowid = lane >> 4, l16 = lane & 15;
+    const int64_t gw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t cell = gw; cell < n; cell += nwaves) {
+        const int64_t qend = Ap[cell + 1];
+        int64_t qbase = Ap[cell];
+        const int64_t p0 = lptr[cell];
+        const int nl = (int)(lptr[cell + 1] - p0);
+        double h[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) h[j] = (l16 + 16 * j < k) ? H[cell * k + l16 + 16 * j] : 0.0;
+        int wrow = (qbase + lane < qend) ? Ai[qbase + lane] : INT32_MAX;
+        double wval = (qbase + lane < qend) ? Ax[qbase + lane] : 0.0;
+        double s = 0.0;
+        for (int t = 0; t < nl; t += 4) {
+            const bool valid = t + rowid < nl;
+            const int g = valid ? lidx[p0 + t + rowid] : 0;
+            const double* wd = Wd + (int64_t)g * k + l16;
+            double prod = 0.0;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                if (l16 + 16 * j < k) prod = fma(wd[16 * j], h[j], prod);
+            prod += dpp_mov_f64(prod, 0, 0xf);
+            prod += dpp_mov_f64(prod, 1, 0xf);
+            prod += dpp_mov_f64(prod, 2, 0xf);
+            prod += dpp_mov_f64(prod, 3, 0xf);   // every lane of a 16-lane row holds its gene's prediction
+            double val = 0.0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (t + r < nl) {   // (wave-uniform)
+                    const int gr = __builtin_amdgcn_readlane(g, 16 * r);
+                    while (__builtin_amdgcn_readlane(wrow, 63) < gr && qbase + 64 < qend) {   // slide the window up to the gene
+                        qbase += 64;
+                        wrow = (qbase + lane < qend) ? Ai[qbase + lane] : INT32_MAX;
+                        wval = (qbase + lane < qend) ? Ax[qbase + lane] : 0.0;
+                    }
+                    const unsigned long long m = __ballot(wrow == gr);
+                    double vr = 0.0;
+                    if (m != 0ull) {
+                        const int src = __builtin_ctzll(m);
+                        vr = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(wval), src), __builtin_amdgcn_readlane(__double2loint(wval), src));
+                    }
+                    val = (rowid == r) ? vr : val;
+                }
+            }
+            const double e = prod - val;
+            s = valid ? fma(e, e, s) : s;
+        }
+        // the four rows' partial sums in row order
+        const double s0 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(s), 0), __builtin_amdgcn_readlane(__double2loint(s), 0));
+        const double s1 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(s), 16), __builtin_amdgcn_readlane(__double2loint(s), 16));
+        const double s2 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(s), 32), __builtin_amdgcn_readlane(__double2loint(s), 32));
+        const double s3 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(s), 48), __builtin_amdgcn_readlane(__double2loint(s), 48));
+        if (lane == 0) losses[cell] = (nl > 0) ? (((s0 + s1) + s2) + s3) / (double)nl : 0.0;
+    }
+}
+
 __global__ __launch_bounds__(256) void sum_partial_kernel(const double* __restrict__ v, int64_t n,
                                                           double* __restrict__ part) {
     double s = 0.0;
@@ -597,7 +666,24 @@ int k_mse_test(sgl_ctx* c, const double* Wd, const double* H, int k, uint64_t se
     double* part = c->ws + n;
     int64_t blocks = (n + 3) / 4;
     if (blocks > 256 * 16) blocks = 256 * 16;
-    if (k <= 64)
+    // the cell-side mask lists of this fit, when they are there (built by the H-update of the masked iteration)
+    const DevMaskList& L = c->ML[0];
+    const bool lists = k <= 128 && L.mask_t == 0 && L.ptr != nullptr && L.idx != nullptr && L.seed == seed && L.inv == inv_density &&
+                       L.ncol == n && L.nrow == c->A.nrow && L.col_off == c->cell_offset && L.row_off == 0 && !getenv("SGL_MSE_NO_LIST");
+    if (lists) {
+#define SGL_MSEL(NJ_) mse_test_list_kernel<NJ_><<<dim3((unsigned)blocks), dim3(256), 0, c->stream>>>(c->A.x, c->A.i, c->A.p, n, L.ptr, L.idx, Wd, H, k, losses)
+        switch ((k + 15) / 16) {
+            case 1: SGL_MSEL(1); break;
+            case 2: SGL_MSEL(2); break;
+            case 3: SGL_MSEL(3); break;
+            case 4: SGL_MSEL(4); break;
+            case 5: SGL_MSEL(5); break;
+            case 6: SGL_MSEL(6); break;
+            case 7: SGL_MSEL(7); break;
+            default: SGL_MSEL(8); break;
+        }
+#undef SGL_MSEL
+    } else if (k <= 64)
         mse_test_kernel<1><<<dim3((unsigned)blocks), dim3(256), 0, c->stream>>>(c->A.x, c->A.i, c->A.p, c->A.nrow, n, c->cell_offset,
                                                                                 Wd, H, k, seed, sgl_div_make(inv_density), losses);
     else if (k <= 128)
