@@ -55,8 +55,9 @@ int nnls_gram_stride(int KP) { return KP > 40 ? (KP + 15) / 16 * 16 : KP; }
 // padded rank of the lane kernel instance serving rank k (0: no instance, use the wave kernel)
 int nnls_lane_kp(int k) { return k <= 64 ? (k + 1) / 2 * 2 : (k <= SGL_LANE_NNLS_MAX_K ? (k + 7) / 8 * 8 : 0); }
 
-// 64 < k <= 104: two lanes per column, everything in registers (nnls_half.h); SGL_NNLS_NO_HALF=1 keeps the x-scratch instances
-static bool nnls_use_half(int KP) { return KP > 64 && KP <= 104 && !getenv("SGL_NNLS_NO_HALF"); }
+// 64 < k <= 128: two lanes per column, everything in registers (nnls_half.h; above 104 x sits in the AGPR half of the
+// register file); SGL_NNLS_NO_HALF=1 keeps the x-scratch instances
+static bool nnls_use_half(int KP) { return KP > 64 && KP <= 128 && !getenv("SGL_NNLS_NO_HALF"); }
 static bool nnls_needs_xt(int KP) { return KP > 64 && !nnls_use_half(KP); }
 
 int nnls_scratch_alloc(NnlsScratch& sc, int64_t cap, int k_for_xt) {

@@ -1,4 +1,4 @@
-// nnls_half_kernel<KH> instances for 64 < k <= 104 (two lanes per column, see nnls_half.h)
+// nnls_half_kernel<KH> instances for 64 < k <= 128 (two lanes per column, see nnls_half.h)
 #include "nnls_half.h"
 #include <atomic>
 
@@ -21,7 +21,7 @@ static int launch_half(dim3 g, dim3 b, hipStream_t s, const double* Gpad, double
 // workgroup per CU (KP = 104: 94 KB of LDS) and there are columns enough, 512 threads, so that a SIMD still has two waves.
 int k_nnls_half_launch(hipStream_t s, const double* Gpad, int KP, double* B, double* X, const int64_t* col_nnz, int k,
                        int64_t ncols, double L1, double L2, unsigned long long* sweep_counter, const NnlsPass& ps) {
-    const bool big = KP > 96 && ncols >= 256 * 256;
+    const bool big = KP > 96 && KP <= 104 && ncols >= 256 * 256;   // (above 104: x in AGPRs, one wave per SIMD, 256 threads)
     const int cpb = big ? 256 : 128;
     const dim3 g((unsigned)((ncols + cpb - 1) / cpb)), b(2 * cpb);
     switch (KP) {
@@ -30,6 +30,9 @@ int k_nnls_half_launch(hipStream_t s, const double* Gpad, int KP, double* B, dou
         case 88: return launch_half<44>(g, b, s, Gpad, B, X, col_nnz, k, ncols, L1, L2, sweep_counter, ps);
         case 96: return launch_half<48>(g, b, s, Gpad, B, X, col_nnz, k, ncols, L1, L2, sweep_counter, ps);
         case 104: return launch_half<52>(g, b, s, Gpad, B, X, col_nnz, k, ncols, L1, L2, sweep_counter, ps);
+        case 112: return launch_half<56>(g, b, s, Gpad, B, X, col_nnz, k, ncols, L1, L2, sweep_counter, ps);
+        case 120: return launch_half<60>(g, b, s, Gpad, B, X, col_nnz, k, ncols, L1, L2, sweep_counter, ps);
+        case 128: return launch_half<64>(g, b, s, Gpad, B, X, col_nnz, k, ncols, L1, L2, sweep_counter, ps);
         default: sgl_set_error("k_nnls_half: unsupported KP=%d", KP); return SGL_EINVAL;
     }
 }

@@ -35,6 +35,28 @@ __device__ __forceinline__ void half_bcast(double v, double& lo, double& hi) {
     hi = __hiloint2double(b1, b0);
 }
 
+// KH > 52 (k = 105 ... 128): b alone takes 2 KH <= 128 VGPRs of the wave's 256 at two waves per SIMD; x then lives in the
+// AGPR half of the register file -- named registers a[2 j : 2 j + 1], outside hipcc's allocation (it has no other use for
+// AGPRs in this kernel; tests/test_kernel_codegen.py holds it to that) -- at one wave per SIMD (512 registers).  A
+// coordinate reads and writes its x once: two v_accvgpr_read + two v_accvgpr_write per step.
+template <int J>
+__device__ __forceinline__ double half_xa_read() {
+    int lo, hi;
+    asm volatile("v_accvgpr_read_b32 %0, a[%2]\n\tv_accvgpr_read_b32 %1, a[%3]\n\ts_nop 1" : "=v"(lo), "=v"(hi) : "n"(2 * J), "n"(2 * J + 1));
+    return __hiloint2double(hi, lo);
+}
+template <int J>
+__device__ __forceinline__ void half_xa_write(double v) {
+    asm volatile("v_accvgpr_write_b32 a[%2], %0\n\tv_accvgpr_write_b32 a[%3], %1" ::"v"(__double2loint(v)), "v"(__double2hiint(v)), "n"(2 * J), "n"(2 * J + 1));
+}
+template <int KH>
+__device__ __forceinline__ void half_xa_reserve() {
+    if constexpr (KH <= 56) asm volatile("" ::: "a111");
+    else if constexpr (KH <= 60) asm volatile("" ::: "a119");
+    else asm volatile("" ::: "a127");
+    static_assert(KH <= 64, "x in AGPRs: at most 64 coordinates per lane");
+}
+
 template <int KH>
 constexpr size_t nnls_half_lds_bytes() {
     constexpr int KP = 2 * KH, GS = ((KP + 15) / 16) * 16;
@@ -42,11 +64,13 @@ constexpr size_t nnls_half_lds_bytes() {
 }
 
 template <int KH>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void nnls_half_kernel(
+__global__ __launch_bounds__(KH > 52 ? 256 : 512) __attribute__((amdgpu_waves_per_eu(KH > 52 ? 1 : 2))) void nnls_half_kernel(
     const double* __restrict__ Gpad, double* __restrict__ B, double* __restrict__ X, const int64_t* __restrict__ col_nnz, int k,
     int64_t ncols, double L1, double L2, unsigned long long* __restrict__ sweep_counter, NnlsPass ps) {
     constexpr int KP = 2 * KH, NG = (KP + 15) / 16, GS = NG * 16, NGH = (KH + 15) / 16;
     constexpr bool G2 = SGL_HALF_G2 != 0 && KH <= 48;   // Gram rows one coordinate ahead (registers permitting)
+    constexpr bool XA = KH > 52;                        // x in named AGPRs (one wave per SIMD)
+    if constexpr (XA) half_xa_reserve<KH>();
     const int64_t n_in = ps.list ? (int64_t)*ps.count : ncols;
     const int cpb = (int)(blockDim.x >> 1);   // columns per workgroup
     if ((int64_t)blockIdx.x * cpb >= n_in) return;
@@ -67,14 +91,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void n
     const bool to_end = (ps.next_list == nullptr) || n_in <= (int64_t)ps.final_below;
     constexpr int KLOW = KP - 7;   // coordinates below it always exist (an instance serves KP - 7 <= k <= KP)
     int one = 1;
-    double b[KH], x[KH];
+    double b[KH], x[XA ? 1 : KH];
     double* bp = B + col * k + half * KH;
     double* xp = X + col * k + half * KH;
     const int kh = half ? k - KH : KH;   // coordinates this lane holds (k >= KP - 7 > KH)
     static_for<KH>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
         b[j] = (valid && j < kh) ? bp[j] : 0.0;
-        x[j] = (valid && j < kh) ? xp[j] : 0.0;
+        const double x0 = (valid && j < kh) ? xp[j] : 0.0;
+        if constexpr (XA) half_xa_write<j>(x0); else x[j] = x0;
     });
     const double kd = (double)k;
     double tol = 1.0;
@@ -122,9 +147,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void n
                 const double gii = dnext0, rii = dnext1;
                 if (i + 1 < KP) { dnext0 = Dl[gofs + 2 * (i + 1)]; dnext1 = Dl[gofs + 2 * (i + 1) + 1]; }
                 __builtin_amdgcn_sched_barrier(0);
-                double blo, bhi, xlo, xhi;
+                double blo, bhi, xlo, xhi, xown;
+                if constexpr (XA) xown = half_xa_read<ii>(); else xown = x[ii];
                 half_bcast(b[ii], blo, bhi);
-                half_bcast(x[ii], xlo, xhi);
+                half_bcast(xown, xlo, xhi);
                 const double bi = owner ? bhi : blo, xi = owner ? xhi : xlo;
                 // b_i / G_ii, correctly rounded, from the correctly rounded reciprocal (Markstein; see nnls_lane.h)
                 const double q0 = bi * rii;
@@ -132,7 +158,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void n
                 const double diff0 = fma(rem, rii, q0);
                 double xv = xi;
                 const double nd = sgl_nnls_step(diff0, xv, tol, go, L1, L2);
-                x[ii] = (half == owner) ? xv : x[ii];
+                const double xnew = (half == owner) ? xv : xown;
+                if constexpr (XA) half_xa_write<ii>(xnew); else x[ii] = xnew;
                 static_for<KH>([&](auto jc) {
                     constexpr int j = decltype(jc)::value;
                     half_dpp_fmac<(j & 15)>(b[j], grow[j >> 4], nd);
@@ -146,8 +173,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void n
     if (valid) {
         static_for<KH>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
-            if (j < kh) xp[j] = x[j];
+            double xj;
+            if constexpr (XA) xj = half_xa_read<j>(); else xj = x[j];
+            if (j < kh) xp[j] = xj;
         });
+    } else if constexpr (XA) {
+        asm volatile("" ::: "memory");
     }
     if (unfinished) {
         static_for<KH>([&](auto jc) {

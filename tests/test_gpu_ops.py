@@ -339,9 +339,9 @@ def test_nnls_repack_passes_are_bit_identical(ctx, k, monkeypatch):
     assert np.array_equal(X1, X2) and s1 == s2
 
 
-@pytest.mark.parametrize("k", [65, 71, 72, 73, 88, 96, 97, 100, 104])
+@pytest.mark.parametrize("k", [65, 71, 72, 73, 88, 96, 97, 100, 104, 105, 111, 112, 113, 120, 121, 127, 128])
 def test_nnls_two_lanes_per_column_matches_the_x_scratch_instances(ctx, k, monkeypatch):
-    """64 < k <= 104 runs with two lanes per column (nnls_half.h); SGL_NNLS_NO_HALF=1 selects the lane-per-column
+    """64 < k <= 128 runs with two lanes per column (nnls_half.h; above 104 with x in AGPRs); SGL_NNLS_NO_HALF=1 selects the lane-per-column
     instances with x in a global scratch.  Same operations in the same order: bit-identical solutions, equal sweep totals,
     one pass or re-packed passes, with a ragged column count (partial waves and workgroups)."""
     rng = np.random.default_rng(300 + k)

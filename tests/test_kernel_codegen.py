@@ -180,3 +180,46 @@ def test_list_downdate_kernels_own_their_agprs(mask_asm):
         best = max(blocks, key=lambda b: b.count("v_mfma_f64_16x16x4"))
         waits = re.findall(r"vmcnt\((\d+)\)", best)
         assert any(int(w) > 1 for w in waits), "%s: no counted vmcnt in the steady-state loop (%s)" % (name, waits)
+
+
+# ---- nnls_half_kernel<KH > 52>: x in named AGPRs outside hipcc's allocation -------------------------------------------
+HALF_SRC = os.path.join(ROOT, "singlet_amd", "csrc", "kernels_nnls_half.hip")
+
+
+def test_half_lane_nnls_x_in_agprs(tmp_path_factory):
+    """The k = 105 ... 128 instances keep x in a[0 : 2 KH - 1] by name: hipcc itself must not touch the AGPR file there
+    (it would, to spill, if the kernel were held to 256 registers), must not spill to scratch, and the kernel
+    descriptor must cover the named registers."""
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not installed")
+    out = str(tmp_path_factory.mktemp("asm") / "kernels_nnls_half.s")
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-S",
+                    "--cuda-device-only", "-o", out, HALF_SRC], check=True, capture_output=True, timeout=900)
+    text = open(out).read()
+    kernels = re.findall(r"^(_Z16nnls_half_kernelILi(\d+)E\w*):[^\n]*\n(.*?)s_endpgm", text, re.S | re.M)
+    assert len(kernels) == 8
+    for name, kh, body in kernels:
+        kh = int(kh)
+        in_asm = False
+        for line in body.splitlines():
+            if "#ASMSTART" in line:
+                in_asm = True
+                continue
+            if "#ASMEND" in line:
+                in_asm = False
+                continue
+            code = line.split(";")[0]
+            if not in_asm and re.search(r"\ba(\d+|\[)", code):
+                raise AssertionError("%s: hipcc uses an AGPR itself: %s" % (name, code.strip()))
+        meta = text[text.index(".amdhsa_kernel " + name):]
+        meta = meta[:meta.index(".end_amdhsa_kernel")]
+        scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", meta).group(1))
+        if kh > 52:
+            assert scratch == 0, "%s spills %d bytes" % (name, scratch)
+            acc_off = int(re.search(r"\.amdhsa_accum_offset (\d+)", meta).group(1))
+            nxt = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", meta).group(1))
+            assert nxt - acc_off >= 2 * kh, "%s: %d AGPRs allocated, %d named" % (name, nxt - acc_off, 2 * kh)
+            asm_text = "\n".join(re.findall(r"#ASMSTART(.*?)#ASMEND", body, re.S))
+            assert max(int(x) for x in re.findall(r"\ba\[(\d+)\]", asm_text)) == 2 * kh - 1
+        else:
+            assert scratch <= 64, "%s spills %d bytes" % (name, scratch)
