@@ -148,7 +148,7 @@ def test_list_downdate_kernels_own_their_agprs(mask_asm):
     itself never touches the AGPR file in these kernels (no spills to AGPRs, no MFMA of its own), does not spill to
     scratch, and the kernel descriptor covers the named registers: every AGPR reference must sit inside an asm
     statement, and the steady-state loop must not wait for vmcnt(0) before every group (branch-free loop)."""
-    kernels = re.findall(r"^(_Z21mask_gram_list_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E\w*):[^\n]*\n(.*?)s_endpgm", mask_asm, re.S | re.M)
+    kernels = re.findall(r"^(_Z21mask_gram_list_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E\w*):[^\n]*\n(.*?)^\.Lfunc_end", mask_asm, re.S | re.M)
     assert len(kernels) >= 20, "list kernel instances not found"
     for name, nt, nparts, part, rem, body in kernels:
         nt, nparts, part, rem = int(nt), int(nparts), int(part), int(rem)
@@ -168,7 +168,7 @@ def test_list_downdate_kernels_own_their_agprs(mask_asm):
         assert "scratch_" not in body, "%s spills to scratch" % name
         asm_text = "\n".join(re.findall(r"#ASMSTART(.*?)#ASMEND", body, re.S))
         assert asm_text.count("v_accvgpr_write_b32") == nreg, name
-        used = [int(x) for x in re.findall(r"\ba\[(\d+)", asm_text)]
+        used = [int(x, 0) for x in re.findall(r"\ba\[(0x[0-9a-fA-F]+|\d+)", asm_text)] + [int(x, 0) for x in re.findall(r"\ba\[[0-9a-fx]+:(0x[0-9a-fA-F]+|\d+)\]", asm_text)]
         assert max(used) < nreg, name
         meta = mask_asm[mask_asm.index(".amdhsa_kernel " + name):]
         meta = meta[:meta.index(".end_amdhsa_kernel")]
@@ -196,7 +196,7 @@ def test_half_lane_nnls_x_in_agprs(tmp_path_factory):
     subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-S",
                     "--cuda-device-only", "-o", out, HALF_SRC], check=True, capture_output=True, timeout=900)
     text = open(out).read()
-    kernels = re.findall(r"^(_Z16nnls_half_kernelILi(\d+)E\w*):[^\n]*\n(.*?)s_endpgm", text, re.S | re.M)
+    kernels = re.findall(r"^(_Z16nnls_half_kernelILi(\d+)E\w*):[^\n]*\n(.*?)^\.Lfunc_end", text, re.S | re.M)
     assert len(kernels) == 8
     for name, kh, body in kernels:
         kh = int(kh)
@@ -220,6 +220,6 @@ def test_half_lane_nnls_x_in_agprs(tmp_path_factory):
             nxt = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", meta).group(1))
             assert nxt - acc_off >= 2 * kh, "%s: %d AGPRs allocated, %d named" % (name, nxt - acc_off, 2 * kh)
             asm_text = "\n".join(re.findall(r"#ASMSTART(.*?)#ASMEND", body, re.S))
-            assert max(int(x) for x in re.findall(r"\ba\[(\d+)\]", asm_text)) == 2 * kh - 1
+            assert max(int(x, 0) for x in re.findall(r"\ba\[(0x[0-9a-fA-F]+|\d+)\]", asm_text)) == 2 * kh - 1
         else:
             assert scratch <= 64, "%s spills %d bytes" % (name, scratch)
