@@ -322,8 +322,14 @@ __global__ __launch_bounds__(64) void nnls_quad_kernel(const double* __restrict_
 // DPP moves: ~13 instructions per column and step.  Every row is read in every sweep (the wave kernel skips the rows
 // of coordinates that do not move; here a row is skipped when its coordinate moves in none of the four columns, and
 // fetched ahead only if it moved in the previous sweep).  Same arithmetic, same order: bit-identical results.
+// Four waves per SIMD (128 registers: 20 - 104 B of scratch per lane at NR >= 5).  While the solve was bound by HBM (rows
+// skipped per wave: 6.2 TB/s) the occupancy made no difference; with the rows skipped per column it fetches 3.7 TB/s and
+// more waves in flight pay: nnls_h k = 72: 40.4 -> 36.1 ms, 100: 67.5 -> 62.3, 128: 92.0 -> 89.7 (30 000 x 200 000).
+#ifndef SGL_QG_WPE
+#define SGL_QG_WPE 4
+#endif
 template <int NR>
-__global__ __launch_bounds__(64) void nnls_quad_global_kernel(const double* __restrict__ G, int64_t gstride,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGL_QG_WPE))) void nnls_quad_global_kernel(const double* __restrict__ G, int64_t gstride,
                                                               const double* __restrict__ B, double* __restrict__ X,
                                                               const int64_t* __restrict__ col_nnz, int k, int64_t ncols,
                                                               double L1, double L2, unsigned long long* __restrict__ sweep_counter) {
