@@ -337,20 +337,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGL_QG_WPE))
     const double kd = (double)k;
     long long total_sweeps = 0, ran_total = 0;
     const int64_t nquads = (ncols + 3) >> 2;
+    __shared__ __attribute__((aligned(16))) double dgl[4 * 16 * NR * 2];
     for (int64_t quad = blockIdx.x; quad < nquads; quad += gridDim.x) {
         const int64_t col = quad * 4 + grp;
         const bool cvalid = col < ncols && (col_nnz == nullptr || col_nnz[col] != 0);
         const double* __restrict__ Gc = G + (cvalid ? col : 0) * gstride;
-        double b[NR], x[NR], rg[NR], gd[NR];
+        // (G_jj, 1 / G_jj) of the four columns: in LDS, not in 4 NR registers per lane -- a coordinate needs its pair once,
+        // as one 16-byte read at a constant offset a coordinate ahead, where four DPP broadcasts served it before
+        double b[NR], x[NR];
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             const int j = l + 16 * r;
             const bool v = cvalid && j < k;
             b[r] = v ? B[col * k + j] : 0.0;
             x[r] = v ? X[col * k + j] : 0.0;
-            gd[r] = v ? Gc[(int64_t)j * k + j] : 1.0;
-            rg[r] = 1.0 / gd[r];   // correctly rounded reciprocal of the diagonal
+            const double gdj = v ? Gc[(int64_t)j * k + j] : 1.0;
+            dgl[(grp * 16 * NR + j) * 2] = gdj;
+            dgl[(grp * 16 * NR + j) * 2 + 1] = 1.0 / gdj;   // correctly rounded reciprocal of the diagonal
         }
+        __builtin_amdgcn_wave_barrier();
+        const double* const dgc = dgl + (size_t)grp * 16 * NR * 2;   // this column's pairs
         double tol = 1.0;
         int it = 0, ran = 0, one = 1;
         // Row i of a column's Gram is only needed when coordinate i MOVES in that column (otherwise b += 0 * row), and the
@@ -378,6 +384,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGL_QG_WPE))
             // a running row pointer (its addresses cannot be hoisted out of the sweep loop: written as Gc[(i + 1) k + ...]
             // hipcc kept the addresses of all 16 NR rows in registers, 344 VGPRs at NR = 7)
             const double* __restrict__ gp = Gc + l;   // row i of the running coordinate
+            double dn0 = dgc[0], dn1 = dgc[1];        // (G_ii, 1 / G_ii) of the coordinate to come
             bool have = go && (act[0] & 1u) != 0u;    // row 0 fetched ahead? (per column)
             if (have) {
 #pragma unroll
@@ -407,8 +414,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGL_QG_WPE))
                     __builtin_amdgcn_sched_barrier(0);
                     const double bi = quad_bcast<il>(b[ir]);
                     const double xi = quad_bcast<il>(x[ir]);
-                    const double rii = quad_bcast<il>(rg[ir]);
-                    const double gii = quad_bcast<il>(gd[ir]);
+                    const double gii = dn0, rii = dn1;
+                    if (i + 1 < 16 * NR) { dn0 = dgc[2 * (i + 1)]; dn1 = dgc[2 * (i + 1) + 1]; }
                     const double q0 = bi * rii;
                     const double diff0 = fma(fma(-q0, gii, bi), rii, q0);   // b_i / g_ii (Markstein, see nnls_lane.h)
                     double xn = xi;
