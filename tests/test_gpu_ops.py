@@ -31,6 +31,33 @@ def test_rand_bulk_bit_exact(ctx, ora):
         assert np.array_equal(got, exp)
 
 
+def _rng_ref():
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rng_ref.npz"))
+    return g, np.unpackbits(g["draw"], axis=-1)[..., :int(g["draw_shape"][-1])]
+
+
+def test_rand_equals_the_reference_rng_class(ctx):
+    """The device hash against 101 152 outputs of the reference's own `rng` class (src/singlet.cpp:6-114 compiled from
+    the reference tree by oracle/make_ref.sh; fixture tests/golden/rng_ref.npz): bit-exact."""
+    g, _ = _rng_ref()
+    state, i, j, exp = g["state"], g["i"], g["j"], g["rand2"]
+    for s in np.unique(state):
+        sel = state == s
+        assert np.array_equal(ctx.op_rand(int(s), i[sel], j[sel]), exp[sel])
+
+
+def test_mask_equals_the_reference_rng_class(ctx):
+    """The device mask (multiply-compare divisibility test) against draw(cell, gene, inv_density) grids of the
+    reference's class: seven densities, cell offsets 0 and 999 000."""
+    g, grids = _rng_ref()
+    seed = int(g["draw_state"])
+    nc, ng = grids.shape[2], grids.shape[3]
+    for a, inv in enumerate(g["draw_inv_density"].tolist()):
+        for b, c0 in enumerate(g["draw_cell0"].tolist()):
+            assert np.array_equal(ctx.op_mask(seed, inv, c0, nc, ng), grids[a, b]), (inv, c0)
+
+
 @pytest.mark.parametrize("inv_density", [20, 5, 1, 2, 3, 7, 64, 1000, 2 ** 20 + 7])
 def test_mask_bit_exact(ctx, ora, inv_density):
     """draw = (rand % inv_density == 0): the device replaces the u64 modulo by a multiply-high test

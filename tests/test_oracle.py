@@ -234,3 +234,66 @@ def test_list_and_dense_ard_restatements_agree_with_the_plain_ones(ora):
     s1 = ora.c_ard_nmf(As, As.t(), 0.0, 3, 0.01, 0.0, 0, w0, 7, 10, 1e9, 1)
     s3 = ora.c_ard_nmf_dense(D, 0.0, 3, 0.01, 0.0, 0, w0, 7, 10, 1e9, 1)
     assert not np.array_equal(s1["w"][3], s3["w"][3])
+
+
+# ---- the integer part pinned to the REFERENCE's own code (oracle/make_ref.sh, tests/golden/make_rng_ref.py) ----
+def _rng_ref():
+    g = np.load(os.path.join(GOLD, "rng_ref.npz"))
+    grids = np.unpackbits(g["draw"], axis=-1)[..., :int(g["draw_shape"][-1])]
+    return g, grids
+
+
+def test_hash_equals_the_reference_rng_class(ora):
+    """101 152 (state, i, j) -> rand(i, j) triples computed by the reference's `rng` class itself
+    (src/singlet.cpp:6-114 compiled as it lies in the reference tree): C oracle and numpy transcription bit-exact."""
+    g, _ = _rng_ref()
+    state, i, j, exp = g["state"], g["i"], g["j"], g["rand2"]
+    assert i.size >= 100000
+    for s in np.unique(state):
+        sel = state == s
+        assert np.array_equal(npt.rand_np(int(s), i[sel], j[sel]), exp[sel])
+    step = 7   # the C oracle one call per triple: every 7th, plus all edge values (the first 144 of every state block)
+    idx = np.unique(np.concatenate([np.arange(0, i.size, step)] + [b + np.arange(144) for b in np.nonzero(np.diff(state, prepend=state[0] + 1))[0]]))
+    got = np.array([ora.rng_rand(int(state[q]), int(i[q]), int(j[q])) for q in idx], dtype=np.uint64)
+    assert np.array_equal(got, exp[idx])
+    for (s, a, b), v in KATS:   # the hand-derived known answers are the reference's too
+        hit = np.nonzero((state == s) & (i == a) & (j == b))[0]
+        assert hit.size == 0 or int(exp[hit[0]]) == v
+
+
+def test_mask_draws_equal_the_reference_rng_class(ora):
+    """draw(cell, gene, inv_density) grids (24 cells x 1500 genes at cell offsets 0 and 999 000, seven densities)
+    from the reference's class: the oracle's mask (what every masked parity test compares with) is identical."""
+    g, grids = _rng_ref()
+    seed = int(g["draw_state"])
+    nc, ng = grids.shape[2], grids.shape[3]
+    for a, inv in enumerate(g["draw_inv_density"].tolist()):
+        for b, c0 in enumerate(g["draw_cell0"].tolist()):
+            assert np.array_equal(ora.rng_mask(seed, c0, nc, ng, inv), grids[a, b]), (inv, c0)
+            cells = (np.uint64(c0) + np.arange(nc, dtype=np.uint64))[:, None]
+            assert np.array_equal(npt.draw_np(seed, cells, np.arange(ng, dtype=np.uint64)[None, :], inv), grids[a, b].astype(bool))
+
+
+def test_live_reference_build_when_present(ora):
+    """oracle/_ref/librng_ref.so (built by oracle/make_ref.sh from the reference tree; travels to the GPU box as a
+    build product) against the oracle on fresh random inputs -- skipped only where it was never built."""
+    import ctypes as C
+    path = os.path.join(os.path.dirname(GOLD), "..", "oracle", "_ref", "librng_ref.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref not built (needs /root/reference at build time)")
+    L = C.CDLL(os.path.abspath(path))
+    u64p = C.POINTER(C.c_uint64)
+    L.ref_rand2.argtypes = [C.c_uint64, u64p, u64p, C.c_int64, u64p]
+    L.ref_draw_grid.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int64, C.c_uint64, C.c_int64, C.POINTER(C.c_uint8)]
+    r = np.random.default_rng(11)
+    i = r.integers(0, 2 ** 64, 3000, dtype=np.uint64, endpoint=False)
+    j = r.integers(0, 2 ** 64, 3000, dtype=np.uint64, endpoint=False)
+    out = np.empty_like(i)
+    for s in (0, 77, 2 ** 64 - 1):
+        L.ref_rand2(s, i.ctypes.data_as(u64p), j.ctypes.data_as(u64p), i.size, out.ctypes.data_as(u64p))
+        assert np.array_equal(out, npt.rand_np(s, i, j))
+        assert all(ora.rng_rand(s, int(i[q]), int(j[q])) == int(out[q]) for q in range(0, 3000, 10))
+    buf = np.empty((50, 700), dtype=np.uint8)
+    for inv in (4, 20, 999):
+        L.ref_draw_grid(9, inv, 123456, 50, 0, 700, buf.ctypes.data_as(C.POINTER(C.c_uint8)))
+        assert np.array_equal(buf, ora.rng_mask(9, 123456, 50, 700, inv))
