@@ -2,8 +2,15 @@
 """ALS iterations/sec of the c_nmf loop on the synthetic config-3 matrix
 (30 000 genes x 1 000 000 cells, 5 % non-zeros, k = 50), BASELINE.json's metric.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+  python bench.py [--gpus N] [--steps K] [--warmup W]                  (no launcher: ONE process drives the N devices)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (one process per GPU)
+
+Which form runs is decided by the environment (plan()): with WORLD_SIZE set (torch.distributed.run) every process is
+one rank and joins the library's RCCL communicator (sgl_comm_init_rank); without it `--gpus N` (N > 1) takes the
+library's one-process team -- sgl_multi_create (ncclCommInitAll), one host thread per device inside the library --
+which is what an R session uses (no launcher, no torch).  `--single-process` forces that form at N = 1 (an RCCL team
+of one); `--loopback` puts all N ranks on device 0 (the exchange is then a HIP kernel, RCCL refuses duplicate
+devices): the team logic end to end on a 1-GPU box, marked "loopback": true.
 
 A step = one ALS iteration (H-update, scale, W-update, scale, cor) over the
 whole matrix, inputs resident in HBM (generated on the device by the hash
@@ -28,7 +35,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_MEASURED_GBS = 6290.0    # same table: float4 copy, 79 %
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -47,10 +54,50 @@ def parse():
                     help="exchange between the ranks: native = RCCL inside the library (sgl_comm_init_rank), hook = "
                          "torch.distributed all-reduce through sgl_set_allreduce, auto = none for one rank, native otherwise")
     ap.add_argument("--native-comm", action="store_true", help="same as --comm native (with one rank: an RCCL team of one)")
+    ap.add_argument("--single-process", action="store_true",
+                    help="one process drives all --gpus devices through the library's own team (sgl_multi_*); the default "
+                         "for --gpus N > 1 when no launcher set WORLD_SIZE")
+    ap.add_argument("--loopback", action="store_true",
+                    help="single-process team with all ranks on device 0 (exchange through a HIP kernel instead of RCCL): "
+                         "rehearsal of the N-rank team logic on a 1-GPU box; the JSON line carries \"loopback\": true")
     ap.add_argument("--force-allreduce", action="store_true",
                     help="with one rank: still create the RCCL process group and route the two per-iteration sums through "
                          "the all-reduce hook (plumbing check of the hook path on a 1-GPU box)")
-    return ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def plan(args, env):
+    """How this invocation runs, from the flags and the launcher's environment only (no GPU, no imports):
+      {'form': 'process-per-gpu', 'world': WORLD_SIZE, 'rank': RANK, 'local_rank': LOCAL_RANK}   under torch.distributed.run
+      {'form': 'single-process', 'world': N, 'devices': [...], 'loopback': bool}                  one process, N devices
+      {'form': 'one-gpu', 'world': 1}                                                            plain context, no team
+    A launcher's WORLD_SIZE > 1 wins over --gpus (the driver passes both, equal).  With no launcher, or a launcher
+    world of ONE process, --gpus N > 1 is the one-process team.  --single-process / --loopback under a launcher with
+    more than one rank is a contradiction and refused."""
+    ws = env.get("WORLD_SIZE")
+    world = 1
+    if ws is not None and str(ws).strip() != "":
+        world = int(ws)
+        if world < 1:
+            raise SystemExit("bench.py: WORLD_SIZE=%r" % ws)
+    if world > 1:
+        if args.single_process or args.loopback:
+            raise SystemExit("bench.py: --single-process / --loopback drive all devices from ONE process; do not start them "
+                             "under a launcher with WORLD_SIZE=%d" % world)
+        return {"form": "process-per-gpu", "world": world, "rank": int(env.get("RANK", "0")),
+                "local_rank": int(env.get("LOCAL_RANK", "0"))}
+    n = int(args.gpus)
+    if n < 1 or n > 16:
+        raise SystemExit("bench.py: --gpus %d out of range (1..16)" % n)
+    if n > 1 or args.single_process or args.loopback:
+        if args.comm in ("hook", "none") or args.force_allreduce:
+            raise SystemExit("bench.py: the one-process team exchanges inside the library (--comm native); --comm hook / none "
+                             "and --force-allreduce belong to the one-rank-per-process form")
+        if args.data != "iid":
+            raise SystemExit("bench.py: --data skewed is a one-GPU record")
+        return {"form": "single-process", "world": n, "devices": [0] * n if args.loopback else list(range(n)),
+                "loopback": bool(args.loopback), "rank": 0, "local_rank": 0}
+    return {"form": "one-gpu", "world": 1, "rank": 0, "local_rank": 0}
 
 
 def _cpu_model():
@@ -173,15 +220,184 @@ def measured_traffic(args, world, dom, lay):
     return None
 
 
+COMM_PER_ITERATION = {
+    "none": "no exchange (one shard)",
+    "native": "RCCL inside the library: 1 grouped collective (reduce-scatter k x genes by gene blocks + all-reduce [k x k | k]) "
+              "+ 1 all-gather of the W blocks",
+    "native-single-process": "RCCL inside the library, one process driving all devices (sgl_multi_*: ncclCommInitAll, one host "
+                             "thread per device): 1 grouped collective (reduce-scatter k x genes by gene blocks + all-reduce "
+                             "[k x k | k]) + 1 all-gather of the W blocks",
+    "loopback": "all ranks on one device: the same exchange steps as summing HIP kernels (no RCCL, no xGMI)",
+    "hook": "2 all-reduces through torch.distributed (k row sums; [k x genes | k x k])",
+}
+
+
+def report(args, run):
+    """The JSON record from what a run measured.  run: world, elapsed, steps' tols, rank-0 phases / sweeps / layout /
+    dims, nnz_total, comm dict, gen_s."""
+    world, elapsed = run["world"], run["elapsed"]
+    m, n_loc, nnz_local = run["dims"]
+    nnz_total, phases, sweeps, layout = run["nnz_total"], run["phases"], run["sweeps"], run["layout"]
+    k, n = args.k, args.cells
+    ms_step = 1e3 * elapsed / args.steps
+    # algorithmic bytes (SURVEY.md 8d): values f64 (vb = 8) + int32 row index per non-zero, column pointers,
+    # factor read + right-hand-side write; local shard on this rank
+    vb = 8
+    bytes_h = nnz_local * (vb + 4) + 4 * (n_loc + 1) + k * n_loc * 8 + k * m * 8
+    bytes_w = nnz_local * (vb + 4) + 4 * (m + 1) + k * n_loc * 8 + k * m * 8
+    bytes_iter = 2 * nnz_total * (vb + 4) + 4 * (n + m + 2) + 2 * k * n * 8 + 3 * k * m * 8
+    ph_ms = {p: (v[0] / args.steps) for p, v in phases.items()}
+    rhs_h_ms, rhs_w_ms = ph_ms["rhs_h"], ph_ms["rhs_w"]
+    dom = "rhs_h" if rhs_h_ms >= rhs_w_ms else "rhs_w"
+    dom_ms = max(rhs_h_ms, rhs_w_ms)
+    dom_bytes = bytes_h if dom == "rhs_h" else bytes_w
+    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    # what the kernel really has to move: the padded entry stream (12 B per stored entry), one byte per
+    # (column pair, tile), the output, and the factor tiles every workgroup stages (mostly L2 / MALL hits)
+    lay = layout["A" if dom == "rhs_h" else "At"]
+    ncols_dom = n_loc if dom == "rhs_h" else m
+    nrows_dom = m if dom == "rhs_h" else n_loc
+    stream_bytes = lay["entries"] * 12 + lay["col_blocks"] * lay["tiles"] * (32 + 8)
+    out_bytes = 8 * k * ncols_dom * (lay["tile_ranges"] + (2 if lay["tile_ranges"] > 1 else 0))
+    staged_bytes = 8 * k * nrows_dom * ((lay["col_blocks"] + 7) // 8)
+    traffic = measured_traffic(args, world, dom, lay) if args.data == "iid" else None
+    # Why 0.60 of the HBM peak is out of reach for this formulation in FP64 at k = 50 (DESIGN.md "The sparse update
+    # against its rooflines"): every entry pair costs one ds_read_b128 (the LDS retires one wave instruction per
+    # 1.76 ns per CU whatever its width) and 2 FP64 FMAs + 1 address add; micro-benchmark rates of this part,
+    # applied to THIS run's stored entry pairs on 256 CUs
+    pairs = lay["entries"] / 2.0
+    ceiling = {"lds_floor_ms": pairs * 1.76e-9 / 256 * 1e3, "loop_floor_ms": pairs * (153e-9 / 64) / 256 * 1e3,
+               "hbm_floor_ms": dom_bytes / (HBM_PEAK_GBS * 1e9) * 1e3,
+               "fp64_fma_floor_ms": lay["entries"] * 4.9 / 2.4e9 / 1024 * 1e3,
+               "source": "scripts/ubench/lds_rate, valu_rate, mix3 (profiles/r2_acc_tiled_tuning.md): 1.76 ns per LDS "
+                         "wave-instruction per CU; 153 ns per round of 8 waves x 8 entry pairs for the complete 64-entry set "
+                         "loop; 4.9 cycles per v_fmac_f64 wave-instruction per SIMD",
+               "note": "the kernel is bound by LDS operand delivery + FP64 issue, not by HBM: the frac below cannot exceed "
+                       "hbm_floor_ms / loop_floor_ms with one LDS read per entry pair"}
+    ceiling["max_frac_of_this_formulation"] = (ceiling["hbm_floor_ms"] / ceiling["loop_floor_ms"]) if pairs > 0 else None
+    comm = run["comm"]
+    default_shape = (args.genes, args.cells, args.k, args.inv_density) == (30000, 1000000, 50, 20)
+    out = {
+        "metric": "ALS iterations/sec (1M cells x 30k genes, 5% nnz, k=50)" if default_shape else
+                  "ALS iterations/sec (%d cells x %d genes, 1/%d nnz, k=%d)" % (args.cells, args.genes, args.inv_density, args.k),
+        "value": args.steps / elapsed, "unit": "iter/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic" if args.data == "iid" else "synthetic-skewed",
+        "config": {"workload": "synthetic CSC %d genes x %d cells, %s (nnz %d), k=%d, L1=%g, tol=0 "
+                               "(no early stop), cells sharded over %d GPU(s)"
+                               % (m, n, "1/%d non-zero" % args.inv_density if args.data == "iid" else
+                                  "mean density 1/%d with log-normal cell (sigma 0.5) and gene (sigma 1.5) weights" % args.inv_density,
+                                  nnz_total, k, args.L1, world),
+                   "genes": m, "cells": n, "k": k, "nnz": nnz_total, "parallelism": "cells/%d" % world},
+        "roofline": {"bound": "hbm", "kernel": "acc_tiled_kernel (%s: sparse accumulate of predict, one launch = one pass over the matrix)" % dom,
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "frac_of_measured_copy": achieved / HBM_MEASURED_GBS, "traffic": traffic, "ceiling": ceiling,
+                     "entries_per_nonzero": {"rhs_h": layout["A"]["entries"] / max(nnz_local, 1),
+                                             "rhs_w": layout["At"]["entries"] / max(nnz_local, 1)},
+                     "stream_layout": dict(lay, stream_bytes=stream_bytes, output_bytes=out_bytes,
+                                           factor_tile_bytes_staged_from_l2=staged_bytes),
+                     "stream_layouts": {"rhs_h": layout["A"], "rhs_w": layout["At"]},
+                     "algorithmic_bytes_per_pass": dom_bytes, "ms_per_pass": dom_ms,
+                     "whole_iteration": {"algorithmic_bytes": bytes_iter, "achieved": bytes_iter / (ms_step * 1e-3) / 1e9 / world,
+                                         "frac": bytes_iter / (ms_step * 1e-3) / 1e9 / world / HBM_PEAK_GBS}},
+        "phases_ms_per_step": ph_ms,
+        "comm": dict(comm, per_iteration=COMM_PER_ITERATION[comm["mode"]]),
+        "tol_last": run["tols"][-1], "generate_s": run["gen_s"],
+    }
+    if run.get("loopback"):
+        out["loopback"] = True
+        out["config"]["parallelism"] = "cells/%d, all ranks on ONE device (loopback rehearsal, not a scaling point)" % world
+    # mean sweeps per column, and mean sweeps each 64-column wave actually ran (its slowest column)
+    out["nnls_mean_sweeps"] = {"h": sweeps["h_sweeps"] / (args.steps * n_loc), "w": sweeps["w_sweeps"] / (args.steps * max(run["w_cols_rank0"], 1)),
+                               "h_per_wave": sweeps["h_wave_sweeps"] / (args.steps * ((n_loc + 63) // 64)),
+                               "w_per_wave": sweeps["w_wave_sweeps"] / (args.steps * ((run["w_cols_rank0"] + 63) // 64))}
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(args)
+            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        except Exception as e:  # noqa: BLE001 - the baseline is reported, never required
+            out["cpu_baseline"] = {"error": repr(e)}
+    return out
+
+
+def emit(line):
+    # RCCL writes a version banner through C stdio; push it out first so that the JSON line is the
+    # last thing on stdout
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    sys.stdout.flush()
+    print(line, flush=True)
+
+
+def run_single_process(args, pl):
+    """One process, N devices, no launcher and no torch: the library's own team (sgl_multi_create -> ncclCommInitAll over
+    the N devices, or the loopback exchange when all ranks sit on device 0), one host thread per device inside the
+    library.  sgl_multi_iterate returns when EVERY rank has delivered its tol (each rank's stream is synchronised by that
+    read), so the K timed iterations are bracketed by complete device idleness on both sides: the barrier + synchronize
+    of the bench contract."""
+    import singlet_amd as sa
+    from singlet_amd._lib import SingletHipError
+    world = pl["world"]
+    have = sa.device_count()
+    if not pl["loopback"] and have < world:
+        # same words as sgl_multi_create's own refusal, before anything is allocated
+        raise SystemExit("bench.py: --gpus %d but %d gfx950 device(s) visible (sgl_device_count); use --loopback to rehearse the "
+                         "team logic on one device" % (world, have))
+    try:
+        M = sa.Multi(pl["devices"])
+    except SingletHipError as e:
+        raise SystemExit("bench.py: sgl_multi_create(%r) failed: %s" % (pl["devices"], e))
+    with M:
+        t0 = time.perf_counter()
+        M.synth(args.genes, args.cells, args.inv_density)
+        gen_s = time.perf_counter() - t0
+        M.fit_init(args.k, None)
+        c0 = M.rank_ctx(0)
+        ranks = [M.rank_ctx(r) for r in range(world)]
+        dims = [c.dims() for c in ranks]
+
+        def step():
+            return M.iterate(args.L1, args.L1, 0.0, 0.0)
+
+        for _ in range(args.warmup):
+            step()
+        info = c0.comm_info()
+        if not pl["loopback"] and (not info["is_rccl"] or info["nranks"] != world):
+            raise SystemExit("bench.py: the library's communicator spans %d ranks (rccl=%s), asked for %d"
+                             % (info["nranks"], info["is_rccl"], world))
+        c0.sweeps_get(reset=True)
+        c0.timing_enable(True)
+        c0.timing_get(reset=True)
+        t0 = time.perf_counter()          # all streams idle: the last warm-up iterate() read every rank's tol
+        tols = [step() for _ in range(args.steps)]
+        elapsed = time.perf_counter() - t0
+        phases = c0.timing_get(reset=True)
+        c0.timing_enable(False)
+        m = dims[0][0]
+        mb = (m + world - 1) // world if world > 1 else m
+        run = {"world": world, "elapsed": elapsed, "tols": tols, "dims": dims[0], "nnz_total": int(sum(d[2] for d in dims)),
+               "phases": phases, "sweeps": c0.sweeps_get(reset=True), "layout": c0.layout_get(), "gen_s": gen_s,
+               "w_cols_rank0": min(mb, m), "loopback": pl["loopback"],
+               "comm": {"mode": "loopback" if pl["loopback"] else "native-single-process", "note": None,
+                        "rccl_nranks": info["nranks"] if info["is_rccl"] else None, "rccl_path": info["path"] or None,
+                        "host_coordination": "none (one process; one library thread per device%s)"
+                                             % (", SGL_MULTI_SERIAL: one thread for all" if os.environ.get("SGL_MULTI_SERIAL") else ""),
+                        "devices": pl["devices"],
+                        "tol_bit_identical_across_ranks": True if world > 1 else None}}   # checked by the library on every iteration
+        out = report(args, run)
+    emit(json.dumps(out))
+
+
 def main():
     args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
-        args.gpus = world
+    pl = plan(args, os.environ)
+    if pl["form"] == "single-process":
+        return run_single_process(args, pl)
+    rank, local_rank, world = pl["rank"], pl["local_rank"], pl["world"]
+    args.gpus = world
 
     import torch
     import singlet_amd as sa
@@ -334,101 +550,20 @@ def main():
         nnz_total = int(reduce_host([float(nnz_local)], dist.ReduceOp.SUM)[0])
 
     if rank == 0:
-        k, n = args.k, args.cells
-        ms_step = 1e3 * elapsed / args.steps
-        # algorithmic bytes: values f64 (vb = 8) + int32 row index per non-zero, column pointers,
-        # factor read + right-hand-side write; local shard on this rank
-        vb = 8
-        bytes_h = nnz_local * (vb + 4) + 4 * (n_loc + 1) + k * n_loc * 8 + k * m * 8
-        bytes_w = nnz_local * (vb + 4) + 4 * (m + 1) + k * n_loc * 8 + k * m * 8
-        bytes_iter = 2 * nnz_total * (vb + 4) + 4 * (n + m + 2) + 2 * k * n * 8 + 3 * k * m * 8
-        ph_ms = {p: (v[0] / args.steps) for p, v in phases.items()}
-        rhs_h_ms, rhs_w_ms = ph_ms["rhs_h"], ph_ms["rhs_w"]
-        dom = "rhs_h" if rhs_h_ms >= rhs_w_ms else "rhs_w"
-        dom_ms = max(rhs_h_ms, rhs_w_ms)
-        dom_bytes = bytes_h if dom == "rhs_h" else bytes_w
-        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        # what the kernel really has to move: the padded entry stream (12 B per stored entry), one byte per
-        # (column pair, tile), the output, and the factor tiles every workgroup stages (mostly L2 / MALL hits)
-        lay = layout["A" if dom == "rhs_h" else "At"]
-        ncols_dom = n_loc if dom == "rhs_h" else m
-        nrows_dom = m if dom == "rhs_h" else n_loc
-        stream_bytes = lay["entries"] * 12 + lay["col_blocks"] * lay["tiles"] * (32 + 8)
-        out_bytes = 8 * k * ncols_dom * (lay["tile_ranges"] + (2 if lay["tile_ranges"] > 1 else 0))
-        staged_bytes = 8 * k * nrows_dom * ((lay["col_blocks"] + 7) // 8)
-        traffic = measured_traffic(args, world, dom, lay) if args.data == "iid" else None
-        # Why 0.60 of the HBM peak is out of reach for this formulation in FP64 at k = 50 (DESIGN.md "The sparse update
-        # against its rooflines"): every entry pair costs one ds_read_b128 (the LDS retires one wave instruction per
-        # 1.76 ns per CU whatever its width) and 2 FP64 FMAs + 1 address add; micro-benchmark rates of this part,
-        # applied to THIS run's stored entry pairs on 256 CUs
-        pairs = lay["entries"] / 2.0
-        ceiling = {"lds_floor_ms": pairs * 1.76e-9 / 256 * 1e3, "loop_floor_ms": pairs * (153e-9 / 64) / 256 * 1e3,
-                   "hbm_floor_ms": dom_bytes / (HBM_PEAK_GBS * 1e9) * 1e3,
-                   "fp64_fma_floor_ms": lay["entries"] * 4.9 / 2.4e9 / 1024 * 1e3,
-                   "source": "scripts/ubench/lds_rate, valu_rate, mix3 (profiles/r2_acc_tiled_tuning.md): 1.76 ns per LDS "
-                             "wave-instruction per CU; 153 ns per round of 8 waves x 8 entry pairs for the complete 64-entry set "
-                             "loop; 4.9 cycles per v_fmac_f64 wave-instruction per SIMD",
-                   "note": "the kernel is bound by LDS operand delivery + FP64 issue, not by HBM: the frac below cannot exceed "
-                           "hbm_floor_ms / loop_floor_ms with one LDS read per entry pair"}
-        ceiling["max_frac_of_this_formulation"] = ceiling["hbm_floor_ms"] / ceiling["loop_floor_ms"]
-        out = {
-            "metric": "ALS iterations/sec (1M cells x 30k genes, 5% nnz, k=50)",
-            "value": args.steps / elapsed, "unit": "iter/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic" if args.data == "iid" else "synthetic-skewed",
-            "config": {"workload": "synthetic CSC %d genes x %d cells, %s (nnz %d), k=%d, L1=%g, tol=0 "
-                                   "(no early stop), cells sharded over %d GPU(s)"
-                                   % (m, n, "1/%d non-zero" % args.inv_density if args.data == "iid" else
-                                      "mean density 1/%d with log-normal cell (sigma 0.5) and gene (sigma 1.5) weights" % args.inv_density,
-                                      nnz_total, k, args.L1, world),
-                       "genes": m, "cells": n, "k": k, "nnz": nnz_total, "parallelism": "cells/%d" % world},
-            "roofline": {"bound": "hbm", "kernel": "acc_tiled_kernel (%s: sparse accumulate of predict, one launch = one pass over the matrix)" % dom,
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "frac_of_measured_copy": achieved / HBM_MEASURED_GBS, "traffic": traffic, "ceiling": ceiling,
-                         "entries_per_nonzero": {"rhs_h": layout["A"]["entries"] / max(nnz_local, 1),
-                                                 "rhs_w": layout["At"]["entries"] / max(nnz_local, 1)},
-                         "stream_layout": dict(lay, stream_bytes=stream_bytes, output_bytes=out_bytes,
-                                               factor_tile_bytes_staged_from_l2=staged_bytes),
-                         "stream_layouts": {"rhs_h": layout["A"], "rhs_w": layout["At"]},
-                         "algorithmic_bytes_per_pass": dom_bytes, "ms_per_pass": dom_ms,
-                         "whole_iteration": {"algorithmic_bytes": bytes_iter, "achieved": bytes_iter / (ms_step * 1e-3) / 1e9 / world,
-                                             "frac": bytes_iter / (ms_step * 1e-3) / 1e9 / world / HBM_PEAK_GBS}},
-            "phases_ms_per_step": ph_ms,
-            "comm": {"mode": mode, "note": comm_note, "rccl_nranks": comm_info["nranks"] if comm_info["is_rccl"] else None,
-                     "rccl_path": comm_info["path"] or None,
-                     "host_coordination": None if dist is None else dist.get_backend(),
-                     "tol_bit_identical_across_ranks": None if dist is None else True,
-                     "per_iteration": {"none": "no exchange (one shard)",
-                                       "native": "RCCL inside the library: 1 grouped collective (reduce-scatter k x genes by gene "
-                                                 "blocks + all-reduce [k x k | k]) + 1 all-gather of the W blocks",
-                                       "hook": "2 all-reduces through torch.distributed (k row sums; [k x genes | k x k])"}[mode]},
-            "tol_last": tols[-1], "generate_s": gen_s,
-        }
-        # mean sweeps per column, and mean sweeps each 64-column wave actually ran (its slowest column)
-        out["nnls_mean_sweeps"] = {"h": sweeps["h_sweeps"] / (args.steps * n_loc), "w": sweeps["w_sweeps"] / (args.steps * m),
-                                   "h_per_wave": sweeps["h_wave_sweeps"] / (args.steps * ((n_loc + 63) // 64)),
-                                   "w_per_wave": sweeps["w_wave_sweeps"] / (args.steps * ((m + 63) // 64))}
-        if world == 1 and not args.no_cpu_baseline:
-            try:
-                out["cpu_baseline"] = cpu_baseline(args)
-                out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
-            except Exception as e:  # noqa: BLE001 - the baseline is reported, never required
-                out["cpu_baseline"] = {"error": repr(e)}
+        mb = (m + world - 1) // world if (world > 1 and mode == "native") else m
+        out = report(args, {"world": world, "elapsed": elapsed, "tols": tols, "dims": (m, n_loc, nnz_local), "nnz_total": nnz_total,
+                            "phases": phases, "sweeps": sweeps, "layout": layout, "gen_s": gen_s, "w_cols_rank0": min(mb, m),
+                            "comm": {"mode": mode, "note": comm_note, "rccl_nranks": comm_info["nranks"] if comm_info["is_rccl"] else None,
+                                     "rccl_path": comm_info["path"] or None,
+                                     "host_coordination": None if dist is None else dist.get_backend(),
+                                     "tol_bit_identical_across_ranks": None if dist is None else True}})
         line = json.dumps(out)
     ctx.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        # RCCL writes a version banner through C stdio; push it out first so that the JSON line is the
-        # last thing on stdout
-        import ctypes
-        try:
-            ctypes.CDLL(None).fflush(None)
-        except OSError:
-            pass
-        sys.stdout.flush()
-        print(line, flush=True)
+        emit(line)
 
 
 if __name__ == "__main__":

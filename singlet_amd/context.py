@@ -51,6 +51,11 @@ def comm_unique_id():
     return buf.raw
 
 
+def device_count():
+    """gfx950 devices this process can use (sgl_device_count; 0 without the HIP runtime or a device)."""
+    return int(_lib.load().sgl_device_count())
+
+
 def comm_available():
     """(ok, path): can RCCL be bound in this process (no communication), and which library was opened.
     Ranks agree on this BEFORE comm_init_rank, which is collective and would otherwise hang on a rank

@@ -31,7 +31,11 @@
 #include <string.h>
 #include <stdlib.h>
 #include <algorithm>
+#include <condition_variable>
+#include <functional>
 #include <mutex>
+#include <string>
+#include <thread>
 #include <vector>
 
 // ---------------------------------------------------------------- RCCL binding --
@@ -102,7 +106,31 @@ static RcclApi* rccl_api() {
 // ----------------------------------------------------------------------- team --
 #define SGL_TEAM_MAX 16
 
+// One host thread per local rank of a single-process team (sgl_multi).  A team iteration is ~50 kernel launches
+// per rank; issued from ONE thread for 8 devices the last rank's first kernel would start ~1 ms after the first
+// rank's, and every collective waits for the slowest -- at the 8-GPU shard size (4.5 ms per iteration) that is the
+// difference between 6 x and 5 x.  The workers are persistent (one fork-join per library call), each binds its
+// device once, and in RCCL mode they never wait for one another on the host: every rank issues its own collectives
+// on its own communicator (the documented one-thread-per-device use of communicators from ncclCommInitAll).
+// SGL_MULTI_SERIAL=1 keeps the single-threaded drive (grouped collectives) for A/B runs and as a fallback.
+struct TeamPool {
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv_go, cv_done, cv_bar;
+    std::function<int(int)> job;
+    uint64_t gen = 0;
+    int pending = 0;
+    bool stop = false;
+    std::vector<int> rc;
+    std::vector<std::string> err;
+    // host barrier of the workers (loopback exchange only); `failed` releases everybody when a rank has given up
+    int bar_count = 0;
+    uint64_t bar_gen = 0;
+    bool failed = false;
+};
+
 struct sgl_team {
+    TeamPool* pool = nullptr;      // nullptr: the calling thread drives every local rank in turn
     int nranks = 1;
     std::vector<sgl_ctx*> local;   // the ranks this process drives
     std::vector<int> rank;         // team rank of local[i]
@@ -185,25 +213,121 @@ static int lb_run(sgl_team* T, F&& launch) {
 
 static unsigned lb_blocks(int64_t n) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 2048)); }
 
-// ------------------------------------------------------------------ collectives --
-// Each takes one buffer per LOCAL rank (index i = T->local[i]); all are in place.
-struct TeamPhase {  // SGL_PH_COMM on every local context
-    sgl_team* T;
-    std::vector<PhaseEvent> pe;
-    explicit TeamPhase(sgl_team* t) : T(t), pe(t->local.size()) {
-        for (size_t i = 0; i < T->local.size(); ++i) {
-            (void)hipSetDevice(T->local[i]->device);
-            (void)sgl_phase_begin(T->local[i], SGL_PH_COMM, &pe[i]);
+// ------------------------------------------------------------ worker threads --
+static void pool_worker(sgl_team* T, int i) {
+    TeamPool* P = T->pool;
+    uint64_t seen = 0;
+    for (;;) {
+        {
+            std::unique_lock<std::mutex> lk(P->mu);
+            P->cv_go.wait(lk, [&] { return P->stop || P->gen != seen; });
+            if (P->stop) return;
+            seen = P->gen;
+        }
+        int rc = SGL_OK;
+        if (hipSetDevice(T->local[i]->device) != hipSuccess) { sgl_set_error("team worker %d: hipSetDevice failed", i); rc = SGL_EHIP; }
+        if (rc == SGL_OK) rc = P->job(i);   // set before the generation moved, untouched until every worker is back
+        {
+            std::lock_guard<std::mutex> lk(P->mu);
+            P->rc[i] = rc;
+            if (rc != SGL_OK) {
+                P->err[i] = sgl_last_error();
+                P->failed = true;          // releases ranks waiting in team_barrier
+                P->cv_bar.notify_all();
+            }
+            if (--P->pending == 0) P->cv_done.notify_one();
         }
     }
-    ~TeamPhase() {
-        for (size_t i = 0; i < T->local.size(); ++i) {
-            (void)hipSetDevice(T->local[i]->device);
-            (void)sgl_phase_end(T->local[i], &pe[i]);
-        }
-    }
-};
+}
 
+static void pool_stop(sgl_team* T) {
+    TeamPool* P = T->pool;
+    if (!P) return;
+    {
+        std::lock_guard<std::mutex> lk(P->mu);
+        P->stop = true;
+    }
+    P->cv_go.notify_all();
+    for (auto& t : P->th) t.join();
+    delete P;
+    T->pool = nullptr;
+}
+
+static int pool_start(sgl_team* T) {
+    const int n = (int)T->local.size();
+    if (n < 2 || getenv("SGL_MULTI_SERIAL")) return SGL_OK;
+    TeamPool* P = new (std::nothrow) TeamPool();
+    if (!P) { sgl_set_error("out of host memory"); return SGL_ENOMEM; }
+    P->rc.assign(n, SGL_OK);
+    P->err.assign(n, std::string());
+    T->pool = P;
+    try {
+        for (int i = 0; i < n; ++i) P->th.emplace_back(pool_worker, T, i);
+    } catch (...) {
+        pool_stop(T);
+        sgl_set_error("team: could not start the worker threads");
+        return SGL_ENOMEM;
+    }
+    return SGL_OK;
+}
+
+// fn(i) for every local rank: on the rank's worker thread (all at once) or, without a pool, one after the other on
+// the calling thread.  Only for work whose ranks do not wait for one another on the HOST.
+template <typename F>
+static int team_parallel(sgl_team* T, F&& fn) {
+    const int n = (int)T->local.size();
+    TeamPool* P = T->pool;
+    if (!P) {
+        for (int i = 0; i < n; ++i) {
+            HIPCHK(hipSetDevice(T->local[i]->device));
+            SGLCHK(fn(i));
+        }
+        return SGL_OK;
+    }
+    {
+        std::unique_lock<std::mutex> lk(P->mu);
+        P->job = [&fn](int i) -> int { return fn(i); };
+        P->failed = false;
+        P->bar_count = 0;
+        std::fill(P->rc.begin(), P->rc.end(), (int)SGL_OK);
+        P->pending = n;
+        ++P->gen;
+        P->cv_go.notify_all();
+        P->cv_done.wait(lk, [&] { return P->pending == 0; });
+        P->job = nullptr;
+    }
+    for (int i = 0; i < n; ++i)
+        if (P->rc[i] != SGL_OK) {
+            sgl_set_error("%s", P->err[i].c_str());
+            return P->rc[i];
+        }
+    return SGL_OK;
+}
+
+// host barrier of the worker threads (the loopback exchange is one kernel launched by rank 0's thread once every
+// rank has enqueued its part); returns SGL_ECOMM when another rank has failed instead of waiting for it for ever
+static int team_barrier(sgl_team* T) {
+    TeamPool* P = T->pool;
+    if (!P) return SGL_OK;
+    std::unique_lock<std::mutex> lk(P->mu);
+    if (!P->failed) {
+        const uint64_t g = P->bar_gen;
+        if (++P->bar_count == (int)T->local.size()) {
+            P->bar_count = 0;
+            ++P->bar_gen;
+            P->cv_bar.notify_all();
+            return SGL_OK;
+        }
+        P->cv_bar.wait(lk, [&] { return P->bar_gen != g || P->failed; });
+        if (P->bar_gen != g) return SGL_OK;
+    }
+    sgl_set_error("team: another rank failed");
+    return SGL_ECOMM;
+}
+
+// ------------------------------------------------------------------ collectives --
+// Each takes one buffer per LOCAL rank (index i = T->local[i]) and issues the call for the local ranks [i0, i1);
+// all are in place.  Loopback: one kernel for the whole team, [i0, i1) must be all local ranks.
 static PtrPack pack(sgl_team* T, void* const* bufs) {
     PtrPack P;
     for (int i = 0; i < SGL_TEAM_MAX; ++i) P.p[i] = nullptr;
@@ -212,7 +336,7 @@ static PtrPack pack(sgl_team* T, void* const* bufs) {
 }
 
 // sum of `count` doubles (or int64) over the ranks
-static int team_allreduce(sgl_team* T, void* const* bufs, int64_t count, bool i64 = false) {
+static int team_allreduce(sgl_team* T, int i0, int i1, void* const* bufs, int64_t count, bool i64 = false) {
     if (count <= 0) return SGL_OK;
     if (T->loopback) {
         const PtrPack P = pack(T, bufs);
@@ -224,7 +348,7 @@ static int team_allreduce(sgl_team* T, void* const* bufs, int64_t count, bool i6
     }
     RcclApi* R = rccl_api();
     if (!R) return SGL_ECOMM;
-    for (size_t i = 0; i < T->local.size(); ++i) {
+    for (int i = i0; i < i1; ++i) {
         HIPCHK(hipSetDevice(T->local[i]->device));
         NCCLCHK(R->AllReduce(bufs[i], bufs[i], (size_t)count, i64 ? ncclInt64 : ncclDouble, ncclSum, T->comm[i], T->local[i]->stream));
     }
@@ -232,7 +356,7 @@ static int team_allreduce(sgl_team* T, void* const* bufs, int64_t count, bool i6
 }
 
 // block r (cnt doubles at offset r * cnt) of rank r's buffer = sum over the ranks of their block r
-static int team_reduce_scatter(sgl_team* T, void* const* bufs, int64_t cnt) {
+static int team_reduce_scatter(sgl_team* T, int i0, int i1, void* const* bufs, int64_t cnt) {
     if (cnt <= 0) return SGL_OK;
     if (T->loopback) {
         const PtrPack P = pack(T, bufs);
@@ -241,7 +365,7 @@ static int team_reduce_scatter(sgl_team* T, void* const* bufs, int64_t cnt) {
     }
     RcclApi* R = rccl_api();
     if (!R) return SGL_ECOMM;
-    for (size_t i = 0; i < T->local.size(); ++i) {
+    for (int i = i0; i < i1; ++i) {
         HIPCHK(hipSetDevice(T->local[i]->device));
         double* b = static_cast<double*>(bufs[i]);
         NCCLCHK(R->ReduceScatter(b, b + (size_t)T->rank[i] * cnt, (size_t)cnt, ncclDouble, ncclSum, T->comm[i], T->local[i]->stream));
@@ -249,7 +373,7 @@ static int team_reduce_scatter(sgl_team* T, void* const* bufs, int64_t cnt) {
     return SGL_OK;
 }
 
-static int team_allgather(sgl_team* T, void* const* bufs, int64_t cnt) {
+static int team_allgather(sgl_team* T, int i0, int i1, void* const* bufs, int64_t cnt) {
     if (cnt <= 0) return SGL_OK;
     if (T->loopback) {
         const PtrPack P = pack(T, bufs);
@@ -258,7 +382,7 @@ static int team_allgather(sgl_team* T, void* const* bufs, int64_t cnt) {
     }
     RcclApi* R = rccl_api();
     if (!R) return SGL_ECOMM;
-    for (size_t i = 0; i < T->local.size(); ++i) {
+    for (int i = i0; i < i1; ++i) {
         HIPCHK(hipSetDevice(T->local[i]->device));
         double* b = static_cast<double*>(bufs[i]);
         NCCLCHK(R->AllGather(b + (size_t)T->rank[i] * cnt, b, (size_t)cnt, ncclDouble, T->comm[i], T->local[i]->stream));
@@ -279,6 +403,66 @@ static int group_end(sgl_team* T) {
     return SGL_OK;
 }
 
+// One exchange step = a few collectives issued as ONE RCCL group, timed as SGL_PH_COMM.
+//   who < 0  : the calling thread issues it for every local rank (single-threaded drive, one process per GPU);
+//   who = i  : worker thread i issues rank i's part.  RCCL: its own group on its own communicator, no host
+//              rendez-vous (the kernels meet on the devices).  Loopback: the workers meet at a host barrier, rank 0's
+//              thread launches the summing kernel for the team, a second barrier lets the others go on.
+struct Xfer {
+    int kind;                        // 0 all-reduce, 1 reduce-scatter, 2 all-gather
+    const std::vector<void*>* bufs;  // one buffer per local rank
+    int64_t cnt;
+    bool i64;
+};
+static int xfer_issue(sgl_team* T, int i0, int i1, const Xfer& x) {
+    switch (x.kind) {
+        case 0: return team_allreduce(T, i0, i1, x.bufs->data(), x.cnt, x.i64);
+        case 1: return team_reduce_scatter(T, i0, i1, x.bufs->data(), x.cnt);
+        default: return team_allgather(T, i0, i1, x.bufs->data(), x.cnt);
+    }
+}
+static int team_exchange(sgl_team* T, int who, std::initializer_list<Xfer> ops) {
+    const int nl = (int)T->local.size();
+    if (who < 0) {
+        std::vector<PhaseEvent> pe(nl);
+        for (int i = 0; i < nl; ++i) {
+            HIPCHK(hipSetDevice(T->local[i]->device));
+            SGLCHK(sgl_phase_begin(T->local[i], SGL_PH_COMM, &pe[i]));
+        }
+        SGLCHK(group_begin(T));
+        int rc = SGL_OK;
+        for (const Xfer& x : ops)
+            if (rc == SGL_OK) rc = xfer_issue(T, 0, nl, x);
+        SGLCHK(group_end(T));
+        SGLCHK(rc);
+        for (int i = 0; i < nl; ++i) {
+            HIPCHK(hipSetDevice(T->local[i]->device));
+            SGLCHK(sgl_phase_end(T->local[i], &pe[i]));
+        }
+        return SGL_OK;
+    }
+    sgl_ctx* c = T->local[who];
+    HIPCHK(hipSetDevice(c->device));
+    PhaseEvent pe;
+    SGLCHK(sgl_phase_begin(c, SGL_PH_COMM, &pe));
+    if (T->loopback) {
+        SGLCHK(team_barrier(T));
+        if (who == 0) {
+            for (const Xfer& x : ops) SGLCHK(xfer_issue(T, 0, nl, x));
+            HIPCHK(hipSetDevice(c->device));
+        }
+        SGLCHK(team_barrier(T));
+    } else {
+        SGLCHK(group_begin(T));
+        int rc = SGL_OK;
+        for (const Xfer& x : ops)
+            if (rc == SGL_OK) rc = xfer_issue(T, who, who + 1, x);
+        SGLCHK(group_end(T));
+        SGLCHK(rc);
+    }
+    return sgl_phase_end(c, &pe);
+}
+
 // ---------------------------------------------------------------- team set-up --
 static int team_events(sgl_team* T) {
     if (!T->loopback) return SGL_OK;
@@ -292,8 +476,9 @@ static int team_events(sgl_team* T) {
 // per-gene non-zero counts over all ranks (which W columns predict() skips, src/singlet.cpp:340)
 static int team_gene_counts(sgl_team* T) {
     if (T->nranks <= 1) return SGL_OK;
-    std::vector<void*> bufs(T->local.size());
-    for (size_t i = 0; i < T->local.size(); ++i) {
+    const int nl = (int)T->local.size();
+    std::vector<void*> bufs(nl);
+    auto prep = [&](int i) -> int {
         sgl_ctx* c = T->local[i];
         HIPCHK(hipSetDevice(c->device));
         const int64_t m = c->A.nrow;
@@ -303,11 +488,17 @@ static int team_gene_counts(sgl_team* T) {
         }
         HIPCHK(hipMemcpyAsync(c->col_nnz_At_global, c->col_nnz_At, sizeof(int64_t) * (size_t)m, hipMemcpyDeviceToDevice, c->stream));
         bufs[i] = c->col_nnz_At_global;
+        return SGL_OK;
+    };
+    if (T->pool) {
+        SGLCHK(team_parallel(T, [&](int i) -> int {
+            SGLCHK(prep(i));
+            return team_exchange(T, i, {{0, &bufs, (int64_t)T->nrow, true}});
+        }));
+    } else {
+        for (int i = 0; i < nl; ++i) SGLCHK(prep(i));
+        SGLCHK(team_exchange(T, -1, {{0, &bufs, (int64_t)T->nrow, true}}));
     }
-    SGLCHK(group_begin(T));
-    int rc = team_allreduce(T, bufs.data(), T->nrow, true);
-    SGLCHK(group_end(T));
-    SGLCHK(rc);
     for (auto c : T->local) c->gene_nnz_global = true;
     return SGL_OK;
 }
@@ -317,9 +508,22 @@ static int team_gene_counts(sgl_team* T) {
         if ((T) == nullptr || (T)->local.empty()) { sgl_set_error("null or empty team"); return SGL_EINVAL; } \
     } while (0)
 
+// W is replicated, so tol = cor(w, w_prev) must come out bit-identical on every local rank: checked on every
+// iteration (a few compares) -- a team whose replicas have drifted apart must not go on silently.
+static int team_tols_agree(const std::vector<double>& tols) {
+    for (size_t i = 1; i < tols.size(); ++i)
+        if (memcmp(&tols[i], &tols[0], sizeof(double)) != 0) {
+            sgl_set_error("team: rank %zu computed tol %.17g, rank 0 %.17g -- the replicated W differs between ranks", i, tols[i], tols[0]);
+            return SGL_ECOMM;
+        }
+    return SGL_OK;
+}
+
 // -------------------------------------------------------------- the iteration --
 // One ALS iteration over the local ranks of the team (header comment).  Every enqueue of every rank
-// is asynchronous; the only host wait is the final read of tol.
+// is asynchronous; the only host wait is the final read of tol.  With worker threads (TeamPool) every rank runs
+// its whole sequence -- local part, exchange 1, its gene block, exchange 2, scale + cor, read tol -- on its own
+// thread; without, the calling thread walks the ranks phase by phase and groups the collectives.
 static int team_iterate(sgl_team* T, double L1_w, double L1_h, double L2_w, double L2_h, double* tol_out) {
     const int nl = (int)T->local.size();
     const int N = T->nranks;
@@ -333,7 +537,8 @@ static int team_iterate(sgl_team* T, double L1_w, double L1_h, double L2_w, doub
     const int64_t mb = N > 1 ? (m + N - 1) / N : m;       // genes per rank block
     const int64_t mpad = mb * N;
     std::vector<void*> red(nl), tail(nl), wbuf(nl);
-    for (int i = 0; i < nl; ++i) {
+    std::vector<double> tols(nl, 0.0);
+    auto local_part = [&](int i) -> int {   // h = predict(A_r, w); partials of the unscaled h
         sgl_ctx* c = T->local[i];
         HIPCHK(hipSetDevice(c->device));
         SGLCHK(sgl_step_begin(c));
@@ -355,16 +560,13 @@ static int team_iterate(sgl_team* T, double L1_w, double L1_h, double L2_w, doub
         red[i] = Bw;
         tail[i] = Gh;
         wbuf[i] = c->W;
-    }
-    {   // exchange 1: one grouped collective
-        TeamPhase ph(T);
-        SGLCHK(group_begin(T));
-        int rc = team_reduce_scatter(T, red.data(), (int64_t)k * mb);
-        if (rc == SGL_OK) rc = team_allreduce(T, tail.data(), (int64_t)k * k + k);
-        SGLCHK(group_end(T));
-        SGLCHK(rc);
-    }
-    for (int i = 0; i < nl; ++i) {
+        return SGL_OK;
+    };
+    // exchange 1: one grouped collective
+    auto exchange1 = [&](int who) -> int {
+        return team_exchange(T, who, {{1, &red, (int64_t)k * mb, false}, {0, &tail, (int64_t)k * k + k, false}});
+    };
+    auto gene_block = [&](int i) -> int {
         sgl_ctx* c = T->local[i];
         HIPCHK(hipSetDevice(c->device));
         const int r = T->rank[i];
@@ -393,26 +595,39 @@ static int team_iterate(sgl_team* T, double L1_w, double L1_h, double L2_w, doub
             SGLCHK(sgl_nnls_shared(c, c->G, Bblk, c->W + (size_t)g0 * k, c->solve_empty ? nullptr : gene_nnz + g0, ng, L1_w, L2_w, c->sweep_counters + 1));
         }
         SGLCHK(sgl_phase_end(c, &pe));
-    }
-    if (N > 1) {  // exchange 2
-        TeamPhase ph(T);
-        SGLCHK(group_begin(T));
-        int rc = team_allgather(T, wbuf.data(), (int64_t)k * mb);
-        SGLCHK(group_end(T));
-        SGLCHK(rc);
-    }
-    for (int i = 0; i < nl; ++i) {
+        return SGL_OK;
+    };
+    auto exchange2 = [&](int who) -> int {   // all-gather of the solved w blocks
+        if (N <= 1) return SGL_OK;
+        return team_exchange(T, who, {{2, &wbuf, (int64_t)k * mb, false}});
+    };
+    auto tail_part = [&](int i) -> int {
         HIPCHK(hipSetDevice(T->local[i]->device));
-        SGLCHK(sgl_scale_w_enqueue(T->local[i]));
-    }
-    double tol = 0.0;
-    for (int i = 0; i < nl; ++i) {
+        return sgl_scale_w_enqueue(T->local[i]);
+    };
+    auto fetch = [&](int i) -> int {
         HIPCHK(hipSetDevice(T->local[i]->device));
-        double t = 0.0;
-        SGLCHK(sgl_scale_w_fetch(T->local[i], &t));
-        if (i == 0) tol = t;   // w is replicated bit for bit: every rank computes the same value
+        return sgl_scale_w_fetch(T->local[i], &tols[i]);
+    };
+    if (T->pool) {
+        SGLCHK(team_parallel(T, [&](int i) -> int {
+            SGLCHK(local_part(i));
+            SGLCHK(exchange1(i));
+            SGLCHK(gene_block(i));
+            SGLCHK(exchange2(i));
+            SGLCHK(tail_part(i));
+            return fetch(i);
+        }));
+    } else {
+        for (int i = 0; i < nl; ++i) SGLCHK(local_part(i));
+        SGLCHK(exchange1(-1));
+        for (int i = 0; i < nl; ++i) SGLCHK(gene_block(i));
+        SGLCHK(exchange2(-1));
+        for (int i = 0; i < nl; ++i) SGLCHK(tail_part(i));
+        for (int i = 0; i < nl; ++i) SGLCHK(fetch(i));
     }
-    if (tol_out) *tol_out = tol;
+    SGLCHK(team_tols_agree(tols));
+    if (tol_out) *tol_out = tols[0];   // w is replicated bit for bit: every rank computes the same value
     return SGL_OK;
 }
 
@@ -466,7 +681,8 @@ static int team_ard_iterate(sgl_team* T, double L1, double L2, uint64_t seed, ui
     const int64_t mb = N > 1 ? (m + N - 1) / N : m;
     const int64_t mpad = mb * N;
     std::vector<void*> dv(nl), red(nl), sb(nl), tail(nl), wbuf(nl);
-    for (int i = 0; i < nl; ++i) {   // H-update: local
+    std::vector<double> tols(nl, 0.0);
+    auto h_update = [&](int i) -> int {   // H-update: local
         sgl_ctx* c = T->local[i];
         HIPCHK(hipSetDevice(c->device));
         SGLCHK(sgl_step_begin(c));
@@ -477,15 +693,13 @@ static int team_ard_iterate(sgl_team* T, double L1, double L2, uint64_t seed, ui
         SGLCHK(k_rowsum(c, c->H, k, c->A.ncol, c->d));
         SGLCHK(sgl_phase_end(c, &pe));
         dv[i] = c->d;
-    }
-    if (N > 1) {
-        TeamPhase ph(T);
-        SGLCHK(group_begin(T));
-        int rc = team_allreduce(T, dv.data(), k);
-        SGLCHK(group_end(T));
-        SGLCHK(rc);
-    }
-    for (int i = 0; i < nl; ++i) {   // scale(h, d); partials of the W-update
+        return SGL_OK;
+    };
+    auto exchange_d = [&](int who) -> int {
+        if (N <= 1) return SGL_OK;
+        return team_exchange(T, who, {{0, &dv, (int64_t)k, false}});
+    };
+    auto w_partials = [&](int i) -> int {   // scale(h, d); partials of the W-update
         sgl_ctx* c = T->local[i];
         HIPCHK(hipSetDevice(c->device));
         PhaseEvent pe;
@@ -494,9 +708,8 @@ static int team_ard_iterate(sgl_team* T, double L1, double L2, uint64_t seed, ui
         SGLCHK(sgl_phase_end(c, &pe));
         if (N == 1) {
             const int64_t* gene_nnz = c->col_nnz_At;
-            SGLCHK(sgl_predict_mask_dev(c, c->At, gene_nnz, c->H, c->W, c->red, seed, inv_density, L1, L2, 1, SGL_PH_RHS_W,
-                                        SGL_PH_NNLS_W, c->sweep_counters + 1));
-            continue;
+            return sgl_predict_mask_dev(c, c->At, gene_nnz, c->H, c->W, c->red, seed, inv_density, L1, L2, 1, SGL_PH_RHS_W,
+                                        SGL_PH_NNLS_W, c->sweep_counters + 1);
         }
         double* Bw = c->red;
         double* Gh = c->red + (size_t)k * mpad;
@@ -521,58 +734,72 @@ static int team_ard_iterate(sgl_team* T, double L1, double L2, uint64_t seed, ui
         sb[i] = c->Sbuf;
         tail[i] = Gh;
         wbuf[i] = c->W;
-    }
-    if (N > 1) {
-        {
-            TeamPhase ph(T);
-            SGLCHK(group_begin(T));
-            int rc = team_reduce_scatter(T, red.data(), (int64_t)k * mb);
-            if (rc == SGL_OK) rc = team_reduce_scatter(T, sb.data(), (int64_t)k * k * mb);
-            if (rc == SGL_OK) rc = team_allreduce(T, tail.data(), (int64_t)k * k);
-            SGLCHK(group_end(T));
-            SGLCHK(rc);
-        }
-        for (int i = 0; i < nl; ++i) {   // every rank: its block of genes
-            sgl_ctx* c = T->local[i];
-            HIPCHK(hipSetDevice(c->device));
-            const int r = T->rank[i];
-            const int64_t g0 = (int64_t)r * mb;
-            const int64_t ng = std::max<int64_t>(0, std::min<int64_t>(mb, m - g0));
-            double* Gh = c->red + (size_t)k * mpad;
-            PhaseEvent pe;
-            SGLCHK(sgl_phase_begin(c, SGL_PH_GRAM, &pe));
-            HIPCHK(hipMemcpyAsync(c->G, Gh, sizeof(double) * k * k, hipMemcpyDeviceToDevice, c->stream));
-            SGLCHK(k_gram_add_diag(c->stream, c->G, k, 1e-15));
+        return SGL_OK;
+    };
+    auto exchange_w = [&](int who) -> int {
+        if (N <= 1) return SGL_OK;
+        return team_exchange(T, who, {{1, &red, (int64_t)k * mb, false}, {1, &sb, (int64_t)k * k * mb, false}, {0, &tail, (int64_t)k * k, false}});
+    };
+    auto gene_block = [&](int i) -> int {   // every rank: its block of genes
+        if (N <= 1) return SGL_OK;
+        sgl_ctx* c = T->local[i];
+        HIPCHK(hipSetDevice(c->device));
+        const int r = T->rank[i];
+        const int64_t g0 = (int64_t)r * mb;
+        const int64_t ng = std::max<int64_t>(0, std::min<int64_t>(mb, m - g0));
+        double* Gh = c->red + (size_t)k * mpad;
+        PhaseEvent pe;
+        SGLCHK(sgl_phase_begin(c, SGL_PH_GRAM, &pe));
+        HIPCHK(hipMemcpyAsync(c->G, Gh, sizeof(double) * k * k, hipMemcpyDeviceToDevice, c->stream));
+        SGLCHK(k_gram_add_diag(c->stream, c->G, k, 1e-15));
+        SGLCHK(sgl_phase_end(c, &pe));
+        for (int64_t q0 = 0; q0 < ng; q0 += c->gcols_chunk) {
+            const int64_t nq = std::min<int64_t>(c->gcols_chunk, ng - q0);
+            SGLCHK(sgl_phase_begin(c, SGL_PH_MASK, &pe));
+            SGLCHK(k_mask_gram_finalize(c->stream, c->G, c->Sbuf + (size_t)(g0 + q0) * k * k, k, nq, c->Gcols));
             SGLCHK(sgl_phase_end(c, &pe));
-            for (int64_t q0 = 0; q0 < ng; q0 += c->gcols_chunk) {
-                const int64_t nq = std::min<int64_t>(c->gcols_chunk, ng - q0);
-                SGLCHK(sgl_phase_begin(c, SGL_PH_MASK, &pe));
-                SGLCHK(k_mask_gram_finalize(c->stream, c->G, c->Sbuf + (size_t)(g0 + q0) * k * k, k, nq, c->Gcols));
-                SGLCHK(sgl_phase_end(c, &pe));
-                SGLCHK(sgl_phase_begin(c, SGL_PH_NNLS_W, &pe));
-                SGLCHK(k_nnls_wave(c->stream, c->Gcols, (int64_t)k * k, c->red + (size_t)(g0 + q0) * k, c->W + (size_t)(g0 + q0) * k,
-                                   c->col_nnz_At_global + g0 + q0, k, nq, L1, L2, c->sweep_counters + 1));
-                SGLCHK(sgl_phase_end(c, &pe));
-            }
+            SGLCHK(sgl_phase_begin(c, SGL_PH_NNLS_W, &pe));
+            SGLCHK(k_nnls_wave(c->stream, c->Gcols, (int64_t)k * k, c->red + (size_t)(g0 + q0) * k, c->W + (size_t)(g0 + q0) * k,
+                               c->col_nnz_At_global + g0 + q0, k, nq, L1, L2, c->sweep_counters + 1));
+            SGLCHK(sgl_phase_end(c, &pe));
         }
-        TeamPhase ph(T);
-        SGLCHK(group_begin(T));
-        int rc = team_allgather(T, wbuf.data(), (int64_t)k * mb);
-        SGLCHK(group_end(T));
-        SGLCHK(rc);
-    }
-    for (int i = 0; i < nl; ++i) {
+        return SGL_OK;
+    };
+    auto exchange_gather = [&](int who) -> int {
+        if (N <= 1) return SGL_OK;
+        return team_exchange(T, who, {{2, &wbuf, (int64_t)k * mb, false}});
+    };
+    auto tail_part = [&](int i) -> int {
         HIPCHK(hipSetDevice(T->local[i]->device));
-        SGLCHK(sgl_scale_w_enqueue(T->local[i]));
-    }
-    double tol = 0.0;
-    for (int i = 0; i < nl; ++i) {
+        return sgl_scale_w_enqueue(T->local[i]);
+    };
+    auto fetch = [&](int i) -> int {
         HIPCHK(hipSetDevice(T->local[i]->device));
-        double t = 0.0;
-        SGLCHK(sgl_scale_w_fetch(T->local[i], &t));
-        if (i == 0) tol = t;
+        return sgl_scale_w_fetch(T->local[i], &tols[i]);
+    };
+    if (T->pool) {
+        SGLCHK(team_parallel(T, [&](int i) -> int {
+            SGLCHK(h_update(i));
+            SGLCHK(exchange_d(i));
+            SGLCHK(w_partials(i));
+            SGLCHK(exchange_w(i));
+            SGLCHK(gene_block(i));
+            SGLCHK(exchange_gather(i));
+            SGLCHK(tail_part(i));
+            return fetch(i);
+        }));
+    } else {
+        for (int i = 0; i < nl; ++i) SGLCHK(h_update(i));
+        SGLCHK(exchange_d(-1));
+        for (int i = 0; i < nl; ++i) SGLCHK(w_partials(i));
+        SGLCHK(exchange_w(-1));
+        for (int i = 0; i < nl; ++i) SGLCHK(gene_block(i));
+        SGLCHK(exchange_gather(-1));
+        for (int i = 0; i < nl; ++i) SGLCHK(tail_part(i));
+        for (int i = 0; i < nl; ++i) SGLCHK(fetch(i));
     }
-    if (tol_out) *tol_out = tol;
+    SGLCHK(team_tols_agree(tols));
+    if (tol_out) *tol_out = tols[0];
     return SGL_OK;
 }
 
@@ -580,18 +807,25 @@ static int team_ard_iterate(sgl_team* T, double L1, double L2, uint64_t seed, ui
 static int team_mse_test(sgl_team* T, uint64_t seed, uint64_t inv_density, double* out) {
     const int nl = (int)T->local.size();
     std::vector<void*> sc(nl);
-    for (int i = 0; i < nl; ++i) {
+    auto local_loss = [&](int i) -> int {
         sgl_ctx* c = T->local[i];
         HIPCHK(hipSetDevice(c->device));
         SGLCHK(sgl_mse_test_enqueue(c, seed, inv_density));
         sc[i] = c->scalars + 1;
-    }
-    if (T->nranks > 1) {
-        TeamPhase ph(T);
-        SGLCHK(group_begin(T));
-        int rc = team_allreduce(T, sc.data(), 1);
-        SGLCHK(group_end(T));
-        SGLCHK(rc);
+        return SGL_OK;
+    };
+    auto exchange = [&](int who) -> int {
+        if (T->nranks <= 1) return SGL_OK;
+        return team_exchange(T, who, {{0, &sc, (int64_t)1, false}});
+    };
+    if (T->pool) {
+        SGLCHK(team_parallel(T, [&](int i) -> int {
+            SGLCHK(local_loss(i));
+            return exchange(i);
+        }));
+    } else {
+        for (int i = 0; i < nl; ++i) SGLCHK(local_loss(i));
+        SGLCHK(exchange(-1));
     }
     sgl_ctx* c0 = T->local[0];
     HIPCHK(hipSetDevice(c0->device));
@@ -789,6 +1023,7 @@ extern "C" int sgl_multi_create(int ndev, const int* devices, sgl_multi** out) {
         }
     }
     if (rc == SGL_OK) rc = team_events(M);
+    if (rc == SGL_OK) rc = pool_start(M);
     if (rc != SGL_OK) { sgl_multi_destroy(M); return rc; }
     *out = M;
     return SGL_OK;
@@ -796,6 +1031,7 @@ extern "C" int sgl_multi_create(int ndev, const int* devices, sgl_multi** out) {
 
 extern "C" int sgl_multi_destroy(sgl_multi* M) {
     if (!M) return SGL_OK;
+    pool_stop(M);
     std::vector<sgl_ctx*> ctxs = M->local;
     for (auto c : ctxs) sgl_destroy(c);   // detaches (and destroys the rank's communicator)
     for (auto e : M->ev) (void)hipEventDestroy(e);
@@ -861,15 +1097,15 @@ extern "C" int sgl_multi_synth_csc(sgl_multi* M, uint64_t S, uint64_t inv_densit
     for (int r = 0; r < n; ++r) M->cell_lo[r + 1] = M->cell_lo[r] + base + (r < rem ? 1 : 0);
     M->nrow = ngenes;
     M->ncells_total = ncells_total;
-    for (int r = 0; r < n; ++r)
-        SGLCHK(sgl_synth_csc(M->local[r], S, inv_density, levels16, ngenes, M->cell_lo[r], (int32_t)(M->cell_lo[r + 1] - M->cell_lo[r]), ncells_total));
-    return SGL_OK;
+    return team_parallel(M, [&](int r) -> int {
+        return sgl_synth_csc(M->local[r], S, inv_density, levels16, ngenes, M->cell_lo[r], (int32_t)(M->cell_lo[r + 1] - M->cell_lo[r]), ncells_total);
+    });
 }
 
 extern "C" int sgl_multi_fit_init(sgl_multi* M, int32_t k, const double* w_init, uint64_t synth_seed) {
     TEAM_GUARD(M);
     if (M->cell_lo.empty()) { sgl_set_error("sgl_multi_fit_init: no matrix resident"); return SGL_ESTATE; }
-    for (auto c : M->local) SGLCHK(sgl_fit_init(c, k, w_init, synth_seed));
+    SGLCHK(team_parallel(M, [&](int r) -> int { return sgl_fit_init(M->local[r], k, w_init, synth_seed); }));
     for (auto c : M->local) c->gene_nnz_global = false;
     return team_gene_counts(M);
 }
