@@ -317,6 +317,14 @@ SGL_API int sgl_step_h(sgl_ctx* ctx, double L1, double L2);
 SGL_API int sgl_step_scale_h(sgl_ctx* ctx);
 SGL_API int sgl_step_w(sgl_ctx* ctx, double L1, double L2);
 SGL_API int sgl_step_scale_w(sgl_ctx* ctx, double* tol_out);
+/* The masked half-iterations c_ard_nmf_base's loop body is made of (src/singlet.cpp:1104, :1106):
+ *   sgl_step_h_masked   predict_mask(A, seed, inv_density, w, h, L1, L2, threads, false)    :436-466
+ *   sgl_step_w_masked   predict_mask(At, seed, inv_density, h, w, L1, L2, threads, true)
+ * on the resident fit of a single shard (the sharded masked loop is sgl_ard_run / sgl_multi_ard_run); the hash sees
+ * the shard's global cell index (cell_offset), as in the reference's chunked form (:485).  sgl_ard_run runs
+ * sgl_step_begin, sgl_step_h_masked, sgl_step_scale_h, sgl_step_w_masked, sgl_step_scale_w per iteration. */
+SGL_API int sgl_step_h_masked(sgl_ctx* ctx, double L1, double L2, uint64_t seed, uint64_t inv_density);
+SGL_API int sgl_step_w_masked(sgl_ctx* ctx, double L1, double L2, uint64_t seed, uint64_t inv_density);
 
 /* Whole loops on the resident shard. */
 SGL_API int sgl_nmf_run(sgl_ctx* ctx, double tol, int32_t maxit,

@@ -59,6 +59,13 @@ def lib():
         L.ora_predict_mask.restype = None
         L.ora_predict_mask.argtypes = csc + [C.c_int32, C.c_int32, C.c_uint64, C.c_uint64, _f64p, _f64p, C.c_int,
                                              C.c_double, C.c_double, C.c_int, C.c_int]
+        L.ora_predict_mask_off.restype = None
+        L.ora_predict_mask_off.argtypes = csc + [C.c_int32, C.c_int32, C.c_uint64, C.c_uint64, _f64p, _f64p, C.c_int,
+                                                 C.c_double, C.c_double, C.c_int, C.c_int, C.c_uint64, C.c_uint64]
+        L.ora_synth_gene_count.restype = C.c_int64
+        L.ora_synth_gene_count.argtypes = [C.c_uint64, C.c_uint64, _i64p, C.c_int64, C.c_int64, _i32p]
+        L.ora_synth_gene_fill.restype = None
+        L.ora_synth_gene_fill.argtypes = [C.c_uint64, C.c_uint64, _i64p, C.c_int64, C.c_int64, _f64p, _i32p, _i32p, _f64p]
         L.ora_mse_test.restype = C.c_double
         L.ora_mse_test.argtypes = csc + [C.c_int32, C.c_int32, _f64p, _f64p, _f64p, C.c_int, C.c_uint64, C.c_uint64,
                                          C.c_int]
@@ -212,13 +219,19 @@ def predict(A, F, X, L1=0.0, L2=0.0, threads=0):
     return X
 
 
-def predict_mask(A, seed, inv_density, F, X, L1=0.0, L2=0.0, threads=0, mask_t=False):
+def predict_mask(A, seed, inv_density, F, X, L1=0.0, L2=0.0, threads=0, mask_t=False, col_offset=0, row_offset=0):
+    """col_offset / row_offset: global index of A's first column / row in the mask hash -- A is then a slice of a
+    larger matrix and is solved exactly as that matrix would solve these columns (the reference's `i + offset`, :485)."""
     keep, ptrs = _csc(A.x, A.i, A.p)
     F = np.ascontiguousarray(F, dtype=np.float64)
     X = np.array(X, dtype=np.float64, order="C")
     k = F.shape[1]
-    lib().ora_predict_mask(*ptrs, A.nrow, A.ncol, seed, inv_density, _p(F, _f64p), _p(X, _f64p), k, L1, L2, threads,
-                           int(mask_t))
+    if col_offset == 0 and row_offset == 0:
+        lib().ora_predict_mask(*ptrs, A.nrow, A.ncol, seed, inv_density, _p(F, _f64p), _p(X, _f64p), k, L1, L2, threads,
+                               int(mask_t))
+    else:
+        lib().ora_predict_mask_off(*ptrs, A.nrow, A.ncol, seed, inv_density, _p(F, _f64p), _p(X, _f64p), k, L1, L2, threads,
+                                   int(mask_t), int(col_offset), int(row_offset))
     return X
 
 
@@ -437,6 +450,20 @@ def synth_csc(ngenes, ncells, inv_density=20, seed=SYNTH_SEED, cell0=0):
     lib().ora_synth_fill(seed, inv_density, cell0, ncells, ngenes, _p(lv, _f64p), _p(p, _i32p), _p(i, _i32p),
                          _p(x, _f64p))
     return CSC(x, i, p, ngenes, ncells)
+
+
+def synth_gene_columns(genes, ncells, inv_density=20, seed=SYNTH_SEED):
+    """Columns `genes` of t(A) of the SURVEY 8(d) matrix over cells 0 .. ncells-1: CSC with ncells rows and one column
+    per listed gene, without generating the whole matrix."""
+    g = np.ascontiguousarray(genes, dtype=np.int64)
+    p = np.empty(g.size + 1, dtype=np.int32)
+    nnz = lib().ora_synth_gene_count(seed, inv_density, _p(g, _i64p), g.size, ncells, _p(p, _i32p))
+    i = np.empty(nnz, dtype=np.int32)
+    x = np.empty(nnz)
+    lv = np.ascontiguousarray(LEVELS16)
+    lib().ora_synth_gene_fill(seed, inv_density, _p(g, _i64p), g.size, ncells, _p(lv, _f64p), _p(p, _i32p), _p(i, _i32p),
+                              _p(x, _f64p))
+    return CSC(x, i, p, ncells, g.size)
 
 
 def synth_winit(k, ngenes, seed=SYNTH_SEED):

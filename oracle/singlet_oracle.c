@@ -299,6 +299,15 @@ ORA_API void ora_predict_mask(const double* Ax, const int32_t* Ai, const int32_t
     predict_mask(A, seed, inv_density, F, X, k, L1, L2, threads, mask_t, 0, 0);
 }
 
+/* the same with the global index of the matrix's first column / row in the hash (what the reference's chunked form
+ * passes as `i + offset`, :485): a SLICE of columns of a larger matrix solved as that matrix would solve them */
+ORA_API void ora_predict_mask_off(const double* Ax, const int32_t* Ai, const int32_t* Ap, int32_t nrow, int32_t ncol,
+                                  uint64_t seed, uint64_t inv_density, const double* F, double* X, int k, double L1,
+                                  double L2, int threads, int mask_t, uint64_t col_offset, uint64_t row_offset) {
+    csc_t A = {Ax, Ai, Ap, nrow, ncol};
+    predict_mask(A, seed, inv_density, F, X, k, L1, L2, threads, mask_t, col_offset, row_offset);
+}
+
 /* mse_test(A, w, d, h, seed, inv_density, threads) sparse -- src/singlet.cpp:536-568
  * w: k x m, h: k x n.  w_ = w^T with column j scaled by d(j); the k-long dot
  * w_.row(i) * h.col(j) is summed left-to-right. */
@@ -870,6 +879,38 @@ ORA_API void ora_synth_fill(uint64_t S, uint64_t inv_density, int64_t cell0, int
             if (ora_rng_draw(S, (uint64_t)(cell0 + c), (uint64_t)g, inv_density)) {
                 i[q] = (int32_t)g;
                 x[q] = levels16[(ora_rng_rand(S + 1, (uint64_t)(cell0 + c), (uint64_t)g) >> 11) % 16];
+                ++q;
+            }
+        }
+    }
+}
+
+/* the same matrix seen from the gene side: columns = the listed genes, rows = cells 0 .. ncells-1 (a few columns of
+ * t(A) without generating the whole matrix; the full-size slice tests form W-side right-hand sides from them) */
+ORA_API int64_t ora_synth_gene_count(uint64_t S, uint64_t inv_density, const int64_t* genes, int64_t ngenes_sel, int64_t ncells,
+                                     int32_t* p) {
+    p[0] = 0;
+    int64_t tot = 0;
+    for (int64_t t = 0; t < ngenes_sel; ++t) {
+        int64_t cnt = 0;
+#pragma omp parallel for reduction(+ : cnt)
+        for (int64_t c = 0; c < ncells; ++c) cnt += ora_rng_draw(S, (uint64_t)c, (uint64_t)genes[t], inv_density);
+        tot += cnt;
+        p[t + 1] = (int32_t)tot;
+    }
+    return tot;
+}
+
+ORA_API void ora_synth_gene_fill(uint64_t S, uint64_t inv_density, const int64_t* genes, int64_t ngenes_sel, int64_t ncells,
+                                 const double* levels16, const int32_t* p, int32_t* i, double* x) {
+#pragma omp parallel for
+    for (int64_t t = 0; t < ngenes_sel; ++t) {
+        int64_t q = p[t];
+        const uint64_t g = (uint64_t)genes[t];
+        for (int64_t c = 0; c < ncells; ++c) {
+            if (ora_rng_draw(S, (uint64_t)c, g, inv_density)) {
+                i[q] = (int32_t)c;
+                x[q] = levels16[(ora_rng_rand(S + 1, (uint64_t)c, g) >> 11) % 16];
                 ++q;
             }
         }

@@ -89,6 +89,8 @@ SIGNATURES = {
     "sgl_step_h": (C.c_int, [C.c_void_p, C.c_double, C.c_double]),
     "sgl_step_scale_h": (C.c_int, [C.c_void_p]),
     "sgl_step_w": (C.c_int, [C.c_void_p, C.c_double, C.c_double]),
+    "sgl_step_h_masked": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_uint64, C.c_uint64]),
+    "sgl_step_w_masked": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_uint64, C.c_uint64]),
     "sgl_step_scale_w": (C.c_int, [C.c_void_p, f64p]),
     "sgl_nmf_run": (C.c_int, [C.c_void_p, C.c_double, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, i32p,
                               f64p, _CB]),

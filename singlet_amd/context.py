@@ -174,6 +174,14 @@ class Context:
         check(self._L.sgl_download_csc(self._h, int(which), ptr(x, f64p), ptr(i, i32p), ptr(p, i64p)))
         return x, i, p
 
+    def col_counts(self, which=0):
+        """Non-zeros per column of the resident A (which = 0: per cell) or t(A) (which = 1: per gene): the column
+        pointers only (sgl_download_csc with NULL value / index buffers)."""
+        nr, nc, _ = self.dims()
+        p = np.empty((nr if which else nc) + 1, dtype=np.int64)
+        check(self._L.sgl_download_csc(self._h, int(which), None, None, ptr(p, i64p)))
+        return np.diff(p)
+
     # -- fit ----------------------------------------------------------------
     def log_normalize(self, scale_factor=10000.0):
         """Seurat::LogNormalize on the resident shard (R/PreprocessData.R:34-39)."""
@@ -231,6 +239,14 @@ class Context:
 
     def step_w(self, L1, L2):
         check(self._L.sgl_step_w(self._h, L1, L2))
+
+    def step_h_masked(self, L1, L2, seed, inv_density):
+        """predict_mask(A, ...) on the resident fit: the masked H-update (unscaled h)."""
+        check(self._L.sgl_step_h_masked(self._h, L1, L2, int(seed), int(inv_density)))
+
+    def step_w_masked(self, L1, L2, seed, inv_density):
+        """predict_mask(At, ..., mask_t = true) on the resident fit: the masked W-update (unscaled w)."""
+        check(self._L.sgl_step_w_masked(self._h, L1, L2, int(seed), int(inv_density)))
 
     def step_scale_w(self):
         t = C.c_double()

@@ -980,6 +980,29 @@ extern "C" int sgl_op_mse_test(sgl_ctx* c, uint64_t seed, uint64_t inv_density, 
     return mse_test_dev(c, seed, inv_density, out);
 }
 
+static int masked_step_guard(sgl_ctx* c, uint64_t inv_density, const char* who) {
+    if (c->allreduce || (c->team && sgl_team_size(c) > 1)) { sgl_set_error("%s: single shard only (the sharded masked loop is sgl_ard_run on a native team)", who); return SGL_ESTATE; }
+    if (c->k > SGL_MASK_MAX_K) { sgl_set_error("%s: rank %d above the masked path's limit of %d", who, c->k, SGL_MASK_MAX_K); return SGL_EINVAL; }
+    if (inv_density == 0) { sgl_set_error("%s: inv_density must be positive", who); return SGL_EINVAL; }
+    return SGL_OK;
+}
+
+// predict_mask(A, seed, inv_density, w, h, L1, L2, threads, false): src/singlet.cpp:1104
+extern "C" int sgl_step_h_masked(sgl_ctx* c, double L1, double L2, uint64_t seed, uint64_t inv_density) {
+    FIT_GUARD(c);
+    SGLCHK(masked_step_guard(c, inv_density, "sgl_step_h_masked"));
+    return sgl_predict_mask_dev(c, c->A, c->solve_empty ? nullptr : c->col_nnz_A, c->W, c->H, c->B, seed, inv_density, L1, L2, 0,
+                                SGL_PH_RHS_H, SGL_PH_NNLS_H, c->sweep_counters + 0);
+}
+
+// predict_mask(At, seed, inv_density, h, w, L1, L2, threads, true): src/singlet.cpp:1106
+extern "C" int sgl_step_w_masked(sgl_ctx* c, double L1, double L2, uint64_t seed, uint64_t inv_density) {
+    FIT_GUARD(c);
+    SGLCHK(masked_step_guard(c, inv_density, "sgl_step_w_masked"));
+    return sgl_predict_mask_dev(c, c->At, c->solve_empty ? nullptr : c->col_nnz_At, c->H, c->W, c->red, seed, inv_density, L1, L2, 1,
+                                SGL_PH_RHS_W, SGL_PH_NNLS_W, c->sweep_counters + 1);
+}
+
 // c_ard_nmf_base: src/singlet.cpp:1090-1152
 extern "C" int sgl_ard_run(sgl_ctx* c, double tol, int32_t maxit, double L1, double L2, uint64_t seed,
                            uint64_t inv_density, double overfit_threshold, int32_t trace_test_mse, double* test_mse,
@@ -1011,12 +1034,10 @@ extern "C" int sgl_ard_run(sgl_ctx* c, double tol, int32_t maxit, double L1, dou
     };
     for (; it < maxit && tol_ > tol; ++it) {
         SGLCHK(sgl_step_begin(c));
-        SGLCHK(sgl_predict_mask_dev(c, c->A, c->solve_empty ? nullptr : c->col_nnz_A, c->W, c->H, c->B, seed, inv_density, L1, L2,
-                                    0, SGL_PH_RHS_H, SGL_PH_NNLS_H, c->sweep_counters + 0));
+        SGLCHK(sgl_step_h_masked(c, L1, L2, seed, inv_density));
         SGLCHK(sgl_step_scale_h(c));
         if (cb && cb->poll && cb->poll(cb->user)) { sgl_set_error("interrupted"); return SGL_EINTR; }
-        SGLCHK(sgl_predict_mask_dev(c, c->At, c->solve_empty ? nullptr : c->col_nnz_At, c->H, c->W, c->red, seed, inv_density, L1, L2, 1,
-                                SGL_PH_RHS_W, SGL_PH_NNLS_W, c->sweep_counters + 1));
+        SGLCHK(sgl_step_w_masked(c, L1, L2, seed, inv_density));
         SGLCHK(sgl_step_scale_w(c, &tol_));
         if (it % trace_test_mse == 0) {
             SGLCHK(push_trace(it));

@@ -464,3 +464,39 @@ def test_log_normalize_and_weight_by_split(sa, ora):
     assert rel_fro(got2.x, ref_ws.x) < 1e-13
     with pytest.raises(sa.SingletHipError):
         sa.weight_by_split(got, sb + 7, 4)   # group ids out of range
+
+
+@pytest.mark.parametrize("k", [3, 16, 50, 70])
+@pytest.mark.parametrize("use_lists", [True, False])
+def test_mse_test_op(sa, ora, k, use_lists, monkeypatch):
+    """sgl_op_mse_test against ora.mse_test (src/singlet.cpp:536-568) at op level: both kernels (from the cell-side mask
+    lists / hashing inside the kernel), one shard and two shards with a cell offset (the hash must see the GLOBAL cell
+    index, :590; every shard divides by the total cell count, so the shards' values add up to the whole)."""
+    if not use_lists:
+        monkeypatch.setenv("SGL_MSE_NO_LIST", "1")
+        monkeypatch.setenv("SGL_MASK_NO_LIST", "1")
+    m, n, seed, inv = 333, 517, 99, 7
+    A = ora.synth_csc(m, n, 9)
+    rng = np.random.default_rng(k)
+    W = np.abs(rng.standard_normal((m, k)))
+    H = np.abs(rng.standard_normal((n, k))) * (rng.random((n, k)) < 0.8)
+    d = 0.5 + rng.random(k)
+    exp = ora.mse_test(A, W, d, H, seed, inv)
+
+    def shard(lo, hi):
+        sub = ora.CSC(A.x[A.p[lo]:A.p[hi]], A.i[A.p[lo]:A.p[hi]], A.p[lo:hi + 1] - A.p[lo], m, hi - lo)
+        c = sa.Context(0)
+        try:
+            c.upload(to_dgc(sa, sub), None, cell_offset=lo, ncells_total=n)
+            c.fit_init(k, W)
+            if use_lists:   # the lists are built by the masked H-update of a fit; mse_test alone must build what it needs
+                pass
+            c.set_factors(W, d, H[lo:hi])
+            return c.op_mse_test(seed, inv)
+        finally:
+            c.close()
+
+    one = shard(0, n)
+    assert abs(one - exp) <= 1e-11 * abs(exp), (one, exp)
+    two = shard(0, 200) + shard(200, n)
+    assert abs(two - exp) <= 1e-11 * abs(exp), (two, exp)
