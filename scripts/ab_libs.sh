@@ -1,7 +1,7 @@
 # usage: ab_libs.sh "<bench args>" lib1 lib2 ...   (libs under build/, "cur" = the in-tree library); two rounds
 args="$1"; shift
 for rep in 1 2; do for v in "$@"; do
-  if [ $v = cur ]; then unset SGL_LIB_PATH; else export SGL_LIB_PATH=/root/repo/build/lib_$v.so; fi
+  if [ $v = cur ]; then unset SGL_LIB_PATH; else export SGL_LIB_PATH=${GRAFT_REPO_ROOT:-$(pwd)}/build/lib_$v.so; fi
   python bench.py --no-cpu-baseline $args > gpurun_out/ab_$v.json 2>/dev/null
   python - <<PY
 import json

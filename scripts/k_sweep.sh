@@ -1,6 +1,6 @@
 #!/bin/bash
 # ms per ALS iteration and per phase for several ranks on a 200k-cell shard (fast paths stop at k = 64)
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}" || exit 1
 for k in "$@"; do
   timeout 300 python bench.py --k $k --cells 200000 --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 | python3 -c "
 import json,sys

@@ -1,6 +1,6 @@
 #!/bin/bash
 # PMC passes focused on the NNLS lane kernel (scalar-cache / instruction-cache behaviour, issue stalls)
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}" || exit 1
 export TMPDIR=/tmp
 O=gpurun_out
 CMD="python3 bench.py --cells 250000 --steps 2 --warmup 1 --no-cpu-baseline"

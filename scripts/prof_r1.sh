@@ -2,7 +2,7 @@
 # Round-1 profile set (run on the GPU box through gpurun): the default bench command under
 # rocprofv3 --kernel-trace --stats, then separate PMC passes (FETCH_SIZE / WRITE_SIZE / SQ).
 # Summaries land in gpurun_out/r1_*.csv; copy the ones to keep into profiles/.
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}" || exit 1
 export TMPDIR=/tmp
 O=gpurun_out
 mkdir -p $O

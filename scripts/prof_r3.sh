@@ -6,7 +6,7 @@
 #  3. a masked (c_ard_nmf) iteration at 30 000 genes x 200 000 cells, k = 50: kernel stats, FETCH / WRITE and
 #     the matrix-core set (mask_gram_mfma_kernel)                                  -> r3_ard_*.csv
 # Summaries land in gpurun_out/; copy the ones to keep into profiles/.  `prof_r3.sh ard` runs part 3 only, `prof_r3.sh main` parts 1 - 2.
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}" || exit 1
 export TMPDIR=/tmp
 O=gpurun_out
 mkdir -p $O

@@ -431,6 +431,76 @@ class _OneShotFits:
         return c_nmf(self.A, None, *args)
 
 
+class _OneShotListFits:
+    """R's list branch (R/ard_nmf.R:45-76, 109-110, 176-178; R/cross_validate_nmf.R:27-50, 76-77): A is a list of
+    column chunks (dgCMatrix, same rows); every fit goes through c_ard_nmf_sparse_list / c_nmf_sparse_list.  R builds a
+    "distributed transpose" At on the host first (a list of row-block transposes); here At_ = None: the library joins
+    the chunks into one resident matrix with 64-bit column pointers and builds t(A) on the device."""
+
+    def __init__(self, chunks):
+        self.chunks = [as_dgCMatrix(a) for a in chunks]
+
+    def close(self):
+        pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        pass
+
+    def c_ard_nmf(self, *args):
+        return c_ard_nmf_sparse_list(self.chunks, None, *args)
+
+    def c_nmf(self, tol, maxit, verbose, L1_w, L1_h, L2_w, L2_h, threads, w):
+        # c_nmf_sparse_list(A, At, tol, maxit, verbose > 2, L1, L2, threads, w_init_this)   R/ard_nmf.R:178
+        return c_nmf_sparse_list(self.chunks, None, tol, maxit, verbose, L1_w, L2_w, threads, w)
+
+
+class _OneShotDenseFits:
+    """R's dense branch (class(A)[[1]] == "matrix": R/ard_nmf.R:79-86, 105-106, 172-173): c_ard_nmf_dense /
+    c_nmf_dense on the dense matrix (every column is solved, all-zero ones included: src/singlet.cpp:370-381)."""
+
+    def __init__(self, A):
+        self.A = np.asarray(A, dtype=np.float64)
+
+    def close(self):
+        pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        pass
+
+    def c_ard_nmf(self, *args):
+        return c_ard_nmf_dense(self.A, None, *args)
+
+    def c_nmf(self, tol, maxit, verbose, L1_w, L1_h, L2_w, L2_h, threads, w):
+        # R/ard_nmf.R:173 calls c_nmf_dense(A, At, tol, maxit, verbose > 2, L1, L2, threads, w_init_this): nine arguments
+        # for an eleven-argument wrapper (R/RcppExports.R: L1_w, L1_h, L2_w, L2_h) -- an error in R; mirrored as the call
+        # the sparse branch makes (L1, L1, L2, L2), the only reading under which the dense branch returns a model
+        return c_nmf_dense(self.A, None, tol, maxit, verbose, L1_w, L1_h, L2_w, L2_h, threads, w)
+
+
+def _classify_input(A):
+    """-> ("list", chunks) | ("dense", array) | ("sparse", dgCMatrix): the three branches of R/ard_nmf.R:45-90 and
+    R/cross_validate_nmf.R:27-63 (`"list" %in% class(A)`, `class(A)[[1]] == "matrix"`, everything else -> dgCMatrix)."""
+    if isinstance(A, (list, tuple)):
+        chunks = [as_dgCMatrix(a) for a in A]   # "you must provide a list of all 'dgCMatrix' objects"
+        if not chunks:
+            raise ValueError("A is an empty list")
+        if len({c.nrow for c in chunks}) != 1:
+            raise ValueError("number of rows in all provided 'A' matrices are not identical")
+        rn0 = chunks[0].Dimnames[0]
+        if rn0 is not None and any(c.Dimnames[0] is not None and list(c.Dimnames[0]) != list(rn0) for c in chunks[1:]):
+            raise ValueError("rownames of all dgCMatrix objects in list must be identical")
+        return "list", chunks
+    if isinstance(A, np.ndarray) and A.ndim == 2:
+        return "dense", A
+    return "sparse", as_dgCMatrix(A)
+
+
 class CVData(list):
     """cv_data rows: dicts with k, rep, test_error, iter, tol (+ overfit_score from ard_nmf);
     the column sets match R/ard_nmf.R:93,118 and R/cross_validate_nmf.R:90."""
@@ -486,32 +556,45 @@ def GetBestRank(df, tol_overfit=1e-4):
 def ard_nmf(A, k_init=2, k_max=100, k_min=2, n_replicates=1, tol=1e-5, cv_tol=1e-4, maxit=100, verbose=1, L1=0.01,
             L2=0, threads=0, test_density=0.05, learning_rate=1, tol_overfit=1e-3, trace_test_mse=1, seed=None,
             resident=True):
-    """R/ard_nmf.R:31-193 (sparse, single-matrix branch): automatic rank search, then the final fit.
-    resident = True keeps A in HBM across all fits of the search (False: one-shot calls, as the R code does)."""
+    """R/ard_nmf.R:31-193: automatic rank search, then the final fit -- all three input branches: one dgCMatrix
+    (:82-85), a list of dgCMatrix column chunks (:45-76 -> c_*_sparse_list), a dense matrix (:79-86 -> c_*_dense).
+    resident = True keeps a single dgCMatrix in HBM across all fits of the search (False, and always for the list and
+    dense branches: one-shot calls, as the R code makes them)."""
     if not L1 < 1:
         raise ValueError("L1 penalty must be strictly in the range (0, 1]")
     if k_init is None or (isinstance(k_init, float) and math.isnan(k_init)) or k_init < k_min:
         k_init = k_min
     if k_min < 2:
         raise ValueError("k_min cannot be less than 2")
-    A = as_dgCMatrix(A)
+    kind, A = _classify_input(A)
+    if kind == "list":
+        nrow = A[0].nrow
+        rn = A[0].Dimnames[0]
+        cns = [c.Dimnames[1] for c in A]
+        cn = None if any(c is None for c in cns) else [name for c in cns for name in c]   # rownames(At[[1]]): all cells
+        fits = _OneShotListFits(A)
+    elif kind == "dense":
+        nrow, rn, cn = A.shape[0], None, None
+        fits = _OneShotDenseFits(A)
+    else:
+        nrow, (rn, cn) = A.nrow, A.Dimnames
+        fits = _ResidentFits(A) if resident else _OneShotFits(A)
     if verbose > 0:
-        print("running with sparse optimization")
+        print("running with dense optimization" if kind == "dense" else "running with sparse optimization")
     rng = _rng(seed)
     # w_init <- lapply(1:n_replicates, function(x) matrix(runif(nrow(A) * k_max), k_max, nrow(A)))
-    w_init = [rng.random((A.nrow, k_max)).T for _ in range(n_replicates)]
+    w_init = [rng.random((nrow, k_max)).T for _ in range(n_replicates)]
     test_seed = int(rng.integers(1, 2 ** 31 - 1))  # abs(.Random.seed[[3]])
     inv_density = int(round(1 / test_density))
     df = CVData()
-    fits = _ResidentFits(A) if resident else _OneShotFits(A)
     try:
-        return _ard_nmf_search(fits, A, df, w_init, test_seed, inv_density, k_init, k_max, k_min, n_replicates, tol, cv_tol,
+        return _ard_nmf_search(fits, (rn, cn), df, w_init, test_seed, inv_density, k_init, k_max, k_min, n_replicates, tol, cv_tol,
                                maxit, verbose, L1, L2, threads, learning_rate, tol_overfit, trace_test_mse)
     finally:
         fits.close()
 
 
-def _ard_nmf_search(fits, A, df, w_init, test_seed, inv_density, k_init, k_max, k_min, n_replicates, tol, cv_tol, maxit,
+def _ard_nmf_search(fits, dimnames, df, w_init, test_seed, inv_density, k_init, k_max, k_min, n_replicates, tol, cv_tol, maxit,
                     verbose, L1, L2, threads, learning_rate, tol_overfit, trace_test_mse):
     for curr_rep in range(1, n_replicates + 1):
         if verbose >= 1 and n_replicates > 1:
@@ -565,7 +648,7 @@ def _ard_nmf_search(fits, A, df, w_init, test_seed, inv_density, k_init, k_max, 
     w_init_this = w_init[0][:best_rank, :]
     model = fits.c_nmf(tol, maxit, verbose > 2, L1, L1, L2, L2, threads, w_init_this)
     model["cv_data"] = df
-    return _sort_model(model, A.Dimnames[0], A.Dimnames[1])
+    return _sort_model(model, dimnames[0], dimnames[1])
 
 
 def _replica_devices(devices):
@@ -616,16 +699,18 @@ def _run_grid_on_replicas(A, devices, jobs, run):
 
 def cross_validate_nmf(A, ranks, n_replicates=3, tol=1e-4, maxit=100, verbose=1, L1=0.01, L2=0, threads=0,
                        test_density=0.05, tol_overfit=1e-4, trace_test_mse=5, seed=None, resident=True, devices=None):
-    """R/cross_validate_nmf.R:18-105 (sparse, single-matrix branch) -> cv table with k, rep, test_error, iter, tol.
-    resident = True keeps A in HBM across the whole (rank, replicate) grid.  devices (a list, a count, or
+    """R/cross_validate_nmf.R:18-105 -> cv table with k, rep, test_error, iter, tol; one dgCMatrix, a list of dgCMatrix
+    column chunks (:27-50 -> c_ard_nmf_sparse_list) or a dense matrix (:57-60 -> c_ard_nmf_dense).
+    resident = True keeps a single dgCMatrix in HBM across the whole (rank, replicate) grid.  devices (a list, a count, or
     SINGLET_REPLICA_GPUS=N): deal the independent fits of the grid out over several GPUs, each with its own
     resident copy of A (BASELINE config 5 on one node); the table is the one-device table, row for row."""
     if L1 >= 1:
         raise ValueError("L1 penalty must be strictly in the range (0, 1]")
-    A = as_dgCMatrix(A)
+    kind, A = _classify_input(A)
+    nrow = A[0].nrow if kind == "list" else (A.shape[0] if kind == "dense" else A.nrow)
     ranks = [int(r) for r in np.atleast_1d(ranks)]
     rng = _rng(seed)
-    w_init = [rng.random((A.nrow, max(ranks))).T for _ in range(n_replicates)]
+    w_init = [rng.random((nrow, max(ranks))).T for _ in range(n_replicates)]
     seeds = [int(rng.integers(1, 2 ** 31 - 1)) for _ in range(n_replicates)]  # abs(.Random.seed[[3 + rep]])
     inv_density = int(round(1 / test_density))
     df2 = CVData()
@@ -642,6 +727,11 @@ def cross_validate_nmf(A, ranks, n_replicates=3, tol=1e-4, maxit=100, verbose=1,
                         "tol": float(model["tol"][t])})
 
     devs = _replica_devices(devices)
+    if kind != "sparse":
+        fits = _OneShotListFits(A) if kind == "list" else _OneShotDenseFits(A)
+        for k, rep in grid:
+            rows(k, rep, fit(fits, (k, rep)))
+        return df2
     if resident and len(devs) > 1:
         for (k, rep), model in zip(grid, _run_grid_on_replicas(A, devs, grid, fit)):
             rows(k, rep, model)

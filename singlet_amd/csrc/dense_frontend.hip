@@ -90,6 +90,7 @@ struct RocblasApi {
     int (*create_handle)(rb_handle*) = nullptr;
     int (*destroy_handle)(rb_handle) = nullptr;
     int (*set_stream)(rb_handle, hipStream_t) = nullptr;
+    int (*set_atomics_mode)(rb_handle, int) = nullptr;   // optional: rocblas_atomics_not_allowed = 0
     int (*dgemm)(rb_handle, int, int, int, int, int, const double*, const double*, int, const double*, int, const double*, double*,
                  int) = nullptr;
     int (*dgemm_sb)(rb_handle, int, int, int, int, int, const double*, const double*, int, long long, const double*, int, long long,
@@ -101,7 +102,8 @@ static RocblasApi* rocblas_api() {
     static char why[256] = "not found";
     static std::once_flag once;
     std::call_once(once, [] {
-        const char* names[] = {getenv("SGL_ROCBLAS_PATH"), "librocblas.so.5", "librocblas.so", "/opt/rocm/lib/librocblas.so"};
+        const char* names[] = {getenv("SGL_ROCBLAS_PATH"), "librocblas.so.5", "librocblas.so.4", "librocblas.so", "/opt/rocm/lib/librocblas.so.5",
+                               "/opt/rocm/lib/librocblas.so.4", "/opt/rocm/lib/librocblas.so"};
         for (const char* n : names) {
             if (!n || !*n) continue;
             api.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
@@ -118,11 +120,16 @@ static RocblasApi* rocblas_api() {
             api.dgemm = (decltype(api.dgemm))bind("rocblas_dgemm");
             api.dgemm_sb = (decltype(api.dgemm_sb))bind("rocblas_dgemm_strided_batched");
             if (!ok) { dlclose(api.lib); api.lib = nullptr; }
+            else api.set_atomics_mode = (decltype(api.set_atomics_mode))dlsym(api.lib, "rocblas_set_atomics_mode");
         }
     });
     if (!api.lib) { sgl_set_error("rocBLAS (librocblas.so) could not be loaded: %s", why); return nullptr; }
     return &api;
 }
+
+// can the GEMM path run at all?  Asked once at sgl_upload_dense: without rocBLAS the dense fit keeps the CSC image
+// (the path of round 2, slower on dense data but always there) instead of failing in the first iteration
+bool sgl_dense_gemm_available() { return rocblas_api() != nullptr; }
 
 void sgl_dense_release(sgl_ctx* c) {
     if (c->rocblas) {
@@ -142,6 +149,9 @@ int k_dense_rhs(sgl_ctx* c, int which, const double* F, int k, double* B) {
     if (!c->rocblas) {
         rb_handle h = nullptr;
         if (R->create_handle(&h) != 0) { sgl_set_error("rocblas_create_handle failed"); return SGL_EHIP; }
+        // no atomics inside the GEMMs (split-K sums with atomics are not reproducible run to run; everything else in the
+        // library sums in a fixed order).  The default of recent rocBLAS releases already is "not allowed".
+        if (R->set_atomics_mode) (void)R->set_atomics_mode(h, 0);
         c->rocblas = h;
     }
     rb_handle h = (rb_handle)c->rocblas;

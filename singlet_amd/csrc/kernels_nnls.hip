@@ -514,9 +514,11 @@ int k_nnls_wave(hipStream_t s, const double* G, int64_t gstride, const double* B
     const char* qmin = getenv("SGL_NNLS_QUAD_GLOBAL_MIN_COLS");   // (tests lower it to reach the k > 112 instance with small problems)
     const int64_t long_launch = (qmin && atoll(qmin) > 0) ? atoll(qmin) : 65536;
     const int quad_global_max_k = (ncols >= long_launch && !getenv("SGL_NNLS_QUAD_GLOBAL_112")) ? 128 : 112;
-    if (gstride != 0 && k <= quad_global_max_k && !getenv("SGL_NNLS_NO_QUAD_GLOBAL")) {
+    // (k > 48: the instances run coordinates 0 .. 16 (NR - 1) unconditionally and prefetch their rows -- a smaller rank,
+    // reachable only with the LDS quad kernel switched off by SGL_NNLS_NO_QUAD, would read past the column's k x k Gram)
+    if (gstride != 0 && k > 48 && k <= quad_global_max_k && !getenv("SGL_NNLS_NO_QUAD_GLOBAL")) {
         switch ((k + 15) / 16) {
-            case 1: case 2: case 3: case 4: return launch_nnls_quad_global<4>(s, G, gstride, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
+            case 4: return launch_nnls_quad_global<4>(s, G, gstride, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
             case 5: return launch_nnls_quad_global<5>(s, G, gstride, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
             case 6: return launch_nnls_quad_global<6>(s, G, gstride, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
             case 7: return launch_nnls_quad_global<7>(s, G, gstride, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);

@@ -14,6 +14,7 @@ static int launch_half(dim3 g, dim3 b, hipStream_t s, const double* Gpad, double
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
     nnls_half_kernel<KH><<<g, b, lds, s>>>(Gpad, B, X, col_nnz, k, ncols, L1, L2, sweep_counter, ps);
+    HIPCHK(hipGetLastError());   // up to 131 KB of dynamic LDS: a refused launch must not leave X stale unnoticed
     return SGL_OK;
 }
 

@@ -254,6 +254,7 @@ int k_dense_count(hipStream_t s, const double* A, int32_t nrow, int64_t ncol, in
 int k_dense_fill(hipStream_t s, const double* A, int32_t nrow, int64_t ncol, const int64_t* p, int32_t* idx, double* x);
 int k_dense_rhs(sgl_ctx* c, int which, const double* F, int k, double* B);
 void sgl_dense_release(sgl_ctx* c);
+bool sgl_dense_gemm_available();
 
 // input staging (kernels_prep.hip)
 int k_colsum(hipStream_t s, const DevCSC& M, double* sums);

@@ -461,6 +461,7 @@ extern "C" int sgl_upload_dense(sgl_ctx* c, const double* A, int32_t nrow, int32
     SGLCHK(sgl_device_transpose(c));
     const char* e = getenv("SGL_DENSE_GEMM");
     c->dense_gemm = e ? atoi(e) > 0 : (double)nnz > 0.5 * (double)tot;
+    if (c->dense_gemm && !sgl_dense_gemm_available()) c->dense_gemm = false;   // no rocBLAS here: the CSC image runs the fit
     if (!c->dense_gemm) { HIPCHK(hipStreamSynchronize(c->stream)); dev_free(c->Adense); c->Adense = nullptr; }
     return finish_matrix(c);
 }
@@ -562,6 +563,7 @@ extern "C" int sgl_log_normalize(sgl_ctx* c, double scale_factor) {
     if (!c->A.p) { sgl_set_error("no matrix resident"); return SGL_ESTATE; }
     free_fit(c);
     c->k = 0;
+    sgl_dense_release(c);   // the values change in the CSC image only: a dense copy would keep forming right-hand sides of the OLD matrix
     double* sums = nullptr;
     SGLCHK(dev_alloc(&sums, (size_t)std::max<int64_t>(c->A.ncol, 1)));
     int rc = k_colsum(c->stream, c->A, sums);
@@ -581,6 +583,7 @@ extern "C" int sgl_weight_by_split(sgl_ctx* c, const int32_t* split_by, int32_t 
         if (split_by[j] < 0 || split_by[j] >= n_groups) { sgl_set_error("sgl_weight_by_split: group id out of range at cell %lld", (long long)j); return SGL_EINVAL; }
     free_fit(c);
     c->k = 0;
+    sgl_dense_release(c);   // as in sgl_log_normalize: only the CSC image is rewritten
     double *dsums = nullptr, *dgrp = nullptr;
     SGLCHK(dev_alloc(&dsums, (size_t)std::max<int64_t>(n, 1)));
     int rc = dev_alloc(&dgrp, (size_t)n_groups);

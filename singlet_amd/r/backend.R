@@ -1,7 +1,7 @@
 # backend.R -- opt-in switch for the HIP back end (source()d or added to the package's R/).
 #
 # With options(singlet.backend = "hip") (or SINGLET_BACKEND=hip in the environment) the
-# wrappers of R/RcppExports.R:20-38, 78-88 are rebound to the shim's .Call symbols; with the option
+# wrappers of R/RcppExports.R:4-6, 20-38, 78-88 are rebound to the shim's .Call symbols; with the option
 # unset nothing changes and the package's own OpenMP code runs.  run_nmf / ard_nmf /
 # cross_validate_nmf / RunNMF / project_model call these wrappers by name, so they need no edit.
 
@@ -36,6 +36,9 @@ singlet_hip_enable <- function(shim = Sys.getenv("SINGLET_HIP_SHIM", "singlet_hi
     .Call(dll[["_singlet_c_project_model"]], A, w, L1, L2, threads))
   rebind("Rcpp_predict", function(A, w, L1, L2, threads)
     .Call(dll[["_singlet_Rcpp_predict"]], A, w, L1, L2, threads))
+  # R/RunNMF.R:86-93 re-weights the matrix by group before the fit (R/RcppExports.R: weight_by_split(A_, split_by, n_groups))
+  rebind("weight_by_split", function(A_, split_by, n_groups)
+    .Call(dll[["_singlet_weight_by_split"]], A_, split_by, n_groups))
   invisible(TRUE)
 }
 

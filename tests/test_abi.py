@@ -74,3 +74,19 @@ def test_r_shim_matches_the_abi():
                         "-I" + os.path.join(root, "include"), "-I" + os.path.join(root, "tests", "r_api_stub"),
                         os.path.join(root, "singlet_amd", "r", "singlet_hip_shim.c")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_backend_r_rebinds_every_symbol_the_shim_registers():
+    """singlet_amd/r/backend.R must rebind one R wrapper per `.Call` symbol of the shim, with the arity the shim registers
+    (and the reference's R/RcppExports.R declares): a symbol registered but not rebound would leave that wrapper on
+    the CPU path silently (round-3 finding: weight_by_split)."""
+    shim = open(os.path.join(ROOT, "singlet_amd", "r", "singlet_hip_shim.c")).read()
+    backend = open(os.path.join(ROOT, "singlet_amd", "r", "backend.R")).read()
+    registered = dict((n, int(a)) for n, a in re.findall(r'\{"(_singlet_\w+)",\s*\(DL_FUNC\)&\w+,\s*(\d+)\}', shim))
+    assert len(registered) >= 10
+    for sym, arity in registered.items():
+        m = re.search(r'rebind\("%s",\s*function\(([^)]*)\)\s*\.Call\(dll\[\["%s"\]\],([^)]*)\)' % (sym[len("_singlet_"):], sym), backend, flags=re.S)
+        assert m, "backend.R does not rebind %s" % sym
+        formals = [a.strip() for a in m.group(1).split(",")]
+        passed = [a.strip() for a in m.group(2).split(",")]
+        assert len(formals) == arity and passed == formals, (sym, arity, formals, passed)

@@ -199,3 +199,29 @@ def test_one_shot_cache_keeps_the_matrix_resident(sa, ora, monkeypatch):
         assert np.array_equal(changed["w"], ref["w"]) and not np.array_equal(changed["w"], plain8["w"])
     finally:
         _lib.load().sgl_cache_release()
+
+
+def test_r_driver_list_and_dense_branches_equal_the_one_matrix_result(sa, ora):
+    """ard_nmf / cross_validate_nmf on a list of column chunks (R/ard_nmf.R:45-76 -> c_*_sparse_list) and on a dense
+    matrix (R/ard_nmf.R:79-86 -> c_*_dense) against the same call on the one dgCMatrix: the list form joins the chunks into
+    the same resident matrix (bit-identical); the dense form differs only by solving all-zero columns, of which this
+    matrix has none (1e-9)."""
+    O = ora.synth_csc(300, 700, 6)
+    assert np.all(np.diff(O.p) > 0) and np.all(np.diff(O.t().p) > 0)      # no empty cell, no empty gene
+    A = to_dgc(sa, O)
+    cuts = [0, 150, 151, 480, 700]
+    chunks = [sa.dgCMatrix(O.x[O.p[a]:O.p[b]], O.i[O.p[a]:O.p[b]], O.p[a:b + 1] - O.p[a], (300, b - a)) for a, b in zip(cuts[:-1], cuts[1:])]
+    D = O.to_dense()
+    kw = dict(n_replicates=2, maxit=6, verbose=0, trace_test_mse=2, seed=5)
+    one = sa.cross_validate_nmf(A, [3, 6], **kw)
+    lst = sa.cross_validate_nmf(chunks, [3, 6], **kw)
+    den = sa.cross_validate_nmf(D, [3, 6], **kw)
+    assert len(one) == len(lst) == len(den) and all(a == b for a, b in zip(one, lst))
+    for a, b in zip(one, den):
+        assert (a["k"], a["rep"], a["iter"]) == (b["k"], b["rep"], b["iter"])
+        assert abs(a["test_error"] - b["test_error"]) <= 1e-9 * abs(a["test_error"])
+    kw = dict(k_init=2, k_max=10, n_replicates=1, maxit=8, verbose=0, seed=7, tol_overfit=1e-3)
+    m1, ml, md = sa.ard_nmf(A, **kw), sa.ard_nmf(chunks, **kw), sa.ard_nmf(D, **kw)
+    assert [r["k"] for r in m1["cv_data"]] == [r["k"] for r in ml["cv_data"]] == [r["k"] for r in md["cv_data"]]
+    assert np.array_equal(m1["w"], ml["w"]) and np.array_equal(m1["h"], ml["h"]) and np.array_equal(m1["d"], ml["d"])
+    assert rel_fro(md["w"], m1["w"]) < 1e-9 and rel_fro(md["h"], m1["h"]) < 1e-9 and rel_fro(md["d"], m1["d"]) < 1e-9

@@ -427,6 +427,35 @@ def test_c_nmf_dense_and_sparse_list(sa, ora):
     assert fit["w"].shape == (m, 5) and np.all(np.diff(fit["d"]) <= 0)
 
 
+def test_dense_upload_then_log_normalize_fits_the_normalized_matrix(sa, ora):
+    """Round-3 advice: sgl_log_normalize / sgl_weight_by_split rewrite the CSC image only; a dense copy kept for GEMM
+    right-hand sides would go on describing the un-normalized matrix.  upload_dense + log_normalize (+ weight_by_split)
+    must fit exactly what upload(csc) + the same staging fits."""
+    rng = np.random.default_rng(12)
+    m, n, k = 90, 260, 7
+    D = np.floor(rng.random((m, n)) * 6.0)            # counts, > half non-zero: the GEMM path is chosen at upload
+    assert (D != 0).mean() > 0.5
+    split = (np.arange(n) % 3).astype(np.int32)
+    w0 = ora.synth_winit(k, m)
+    outs = []
+    for dense in (True, False):
+        c = sa.Context(0)
+        try:
+            if dense:
+                c.upload_dense(D)
+            else:
+                c.upload(sa.dgCMatrix.from_dense(D), None)
+            c.log_normalize(10000.0)
+            c.weight_by_split(split, 3)
+            c.fit_init(k, w0)
+            c.nmf_run(0.0, 3, 0.01, 0.01, 0.0, 0.0)
+            outs.append(c.get_factors())
+        finally:
+            c.close()
+    (W1, d1, H1), (W2, d2, H2) = outs
+    assert rel_fro(W1, W2) < 1e-11 and rel_fro(H1, H2) < 1e-11 and rel_fro(d1, d2) < 1e-11
+
+
 @pytest.mark.parametrize("m,n,k,zero_frac", [(300, 700, 12, 0.0), (257, 513, 50, 0.3), (120, 400, 70, 0.0)])
 def test_c_nmf_dense_gemm_path(sa, ora, m, n, k, zero_frac, monkeypatch):
     """A matrix that IS dense (more than half non-zero): the right-hand sides of predict are FP64 GEMMs on the dense

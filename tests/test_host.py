@@ -152,3 +152,60 @@ def test_run_nmf_argument_plumbing(sa, monkeypatch):
     assert np.array_equal(m["h"][0], np.arange(4, 8, dtype=float))   # row of the largest d first
     with pytest.raises(ValueError):
         api.project_model(A, np.ones((3, 3)))
+
+
+def test_r_drivers_pick_the_list_and_dense_entry_points(sa, monkeypatch):
+    """R/ard_nmf.R:45-90, 105-111, 172-178 and R/cross_validate_nmf.R:27-63, 72-78: `"list" %in% class(A)` -> the
+    *_sparse_list wrappers, `class(A)[[1]] == "matrix"` -> the *_dense wrappers, else the dgCMatrix ones."""
+    from singlet_amd import api
+
+    def curve(k):
+        return 0.5 + 0.01 * abs(k - 5)
+    curve.best = 5
+    seen = []
+
+    def fake_ard(name):
+        inner, calls = _fake_c_ard(curve)
+
+        def f(A, At, *rest):
+            seen.append((name, type(A).__name__))
+            return inner(_Shape(A), At, *rest)
+        return f
+
+    class _Shape:   # what _fake_c_ard needs of its first argument
+        def __init__(self, A):
+            if isinstance(A, list):
+                self.nrow, self.ncol = A[0].nrow, sum(a.ncol for a in A)
+            elif isinstance(A, np.ndarray):
+                self.nrow, self.ncol = A.shape
+            else:
+                self.nrow, self.ncol = A.nrow, A.ncol
+
+    def fake_nmf(name, nargs):
+        def f(A, At, *rest):
+            assert len(rest) == nargs, (name, len(rest))
+            seen.append((name, type(A).__name__))
+            w = np.asarray(rest[-1])
+            return dict(w=w, d=np.arange(w.shape[0], dtype=float), h=np.zeros((w.shape[0], _Shape(A).ncol)), iter=1, tol=np.array([0.0]))
+        return f
+
+    monkeypatch.setattr(api, "c_ard_nmf", fake_ard("c_ard_nmf"))
+    monkeypatch.setattr(api, "c_ard_nmf_sparse_list", fake_ard("c_ard_nmf_sparse_list"))
+    monkeypatch.setattr(api, "c_ard_nmf_dense", fake_ard("c_ard_nmf_dense"))
+    monkeypatch.setattr(api, "c_nmf", fake_nmf("c_nmf", 9))
+    monkeypatch.setattr(api, "c_nmf_sparse_list", fake_nmf("c_nmf_sparse_list", 7))   # (tol, maxit, verbose, L1, L2, threads, w)
+    monkeypatch.setattr(api, "c_nmf_dense", fake_nmf("c_nmf_dense", 9))
+    D = np.eye(6) + 1.0
+    one = sa.dgCMatrix.from_dense(D)
+    chunks = [sa.dgCMatrix.from_dense(D[:, :2]), sa.dgCMatrix.from_dense(D[:, 2:])]
+    for A, tag in ((one, ""), (chunks, "_sparse_list"), (D, "_dense")):
+        seen.clear()
+        m = api.ard_nmf(A, k_init=2, k_max=12, verbose=0, seed=3, resident=False)
+        names = {n for n, _ in seen}
+        assert names == {"c_ard_nmf" + tag, "c_nmf" + tag}, names
+        assert seen[-1][0] == "c_nmf" + tag and m["w"].shape[0] == 6
+        seen.clear()
+        df = api.cross_validate_nmf(A, [2, 3], n_replicates=2, verbose=0, seed=1, resident=False)
+        assert [n for n, _ in seen] == ["c_ard_nmf" + tag] * 4 and len(df) == 8
+    with pytest.raises(ValueError):   # "number of rows in all provided 'A' matrices are not identical"
+        api.ard_nmf([one, sa.dgCMatrix.from_dense(np.eye(5))], verbose=0)
