@@ -265,8 +265,11 @@ def report(args, run):
     # against its rooflines"): every entry pair costs one ds_read_b128 (the LDS retires one wave instruction per
     # 1.76 ns per CU whatever its width) and 2 FP64 FMAs + 1 address add; micro-benchmark rates of this part,
     # applied to THIS run's stored entry pairs on 256 CUs
-    pairs = lay["entries"] / 2.0
-    ceiling = {"lds_floor_ms": pairs * 1.76e-9 / 256 * 1e3, "loop_floor_ms": pairs * (153e-9 / 64) / 256 * 1e3,
+    # entries served by one LDS instruction: two columns (ranks 33 - 64), four up to rank 32 (quad layout, round 4)
+    nsl = 4 if (k <= 32 and not os.environ.get("SGL_TILED_NO_QUAD")) else 2
+    pairs = lay["entries"] / float(nsl)
+    ceiling = {"columns_per_lds_instruction": nsl,
+               "lds_floor_ms": pairs * 1.76e-9 / 256 * 1e3, "loop_floor_ms": pairs * (153e-9 / 64) / 256 * 1e3,
                "hbm_floor_ms": dom_bytes / (HBM_PEAK_GBS * 1e9) * 1e3,
                "fp64_fma_floor_ms": lay["entries"] * 4.9 / 2.4e9 / 1024 * 1e3,
                "source": "scripts/ubench/lds_rate, valu_rate, mix3 (profiles/r2_acc_tiled_tuning.md): 1.76 ns per LDS "

@@ -219,6 +219,127 @@ class Gen:
         return " \\\n".join(f'    "{ins}\\n\\t"' for ins in self.L)
 
 
+class GenQuad(Gen):
+    """Ranks up to 32: FOUR columns per LDS instruction.
+
+    A lane holds two factors, so 16 lanes -- one DPP row -- cover k <= 32 and the four 16-lane rows of a wave work on
+    four different columns (a column QUAD) at once: per entry quad one v_add_u32_dpp, one ds_read_b128 and two
+    v_fmac_f64_dpp serve FOUR non-zeros where the pair layout serves two.  Stream: a set of 64 slots = 16 entries of each
+    of the quad's four columns, row h of the wave holding column slot h -- exactly the operand layout row_newbcast
+    wants, so there is no set preparation at all (the pair layout copies every set and swaps lane rows: 9 VALU per 64
+    entries): the address adds and the FMAs read the ring registers themselves.  The LDS tile rows are 256 B apart
+    (32 doubles whatever the rank): the 16-lane groups ds_read_b128 is served in take 8 lanes of one DPP row and 8 of
+    its neighbour, i.e. bytes 0-63 + 192-255 of one tile row and 64-191 of another -- conflict-free exactly when all
+    rows start on the same bank.  A wave owns 32 quads = 128 columns (accumulators in v[128:255] as before, group
+    counts in the same 32-byte queue).
+
+    Ring: 8 sets in flight (a set is consumed in two octets -- half the time of a pair-layout set -- and its slot can only
+    be refilled when its last operand has been read): v64..71 row offsets, v72..87 values.  s_waitcnt vmcnt(12) before
+    the first use of slot d + 1: the 14 loads of slots d + 1 .. d + 7 are in flight, its two are the oldest."""
+
+    NS = 8
+    QER = [64 + i for i in range(8)]
+    QEX = [72 + 2 * i for i in range(8)]
+
+    def refill(self, i):
+        A = self.A
+        A(f"global_load_dword v{self.QER[i]}, %[voff4], s[{S_RP}:{S_RP + 1}] offset:{256 * i}")
+        A(f"global_load_dwordx2 {r2(self.QEX[i])}, %[voff8], s[{S_XP}:{S_XP + 1}] offset:{512 * i}")
+        if i == self.NS - 1:
+            A(f"s_add_u32 s{S_RP}, s{S_RP}, {256 * self.NS}")
+            A(f"s_addc_u32 s{S_RP + 1}, s{S_RP + 1}, 0")
+            A(f"s_add_u32 s{S_XP}, s{S_XP}, {512 * self.NS}")
+            A(f"s_addc_u32 s{S_XP + 1}, s{S_XP + 1}, 0")
+
+    def addrs(self, slot, o):
+        """LDS addresses of the 8 entry quads of octet o (0, 1) of the set in ring slot `slot`"""
+        for j in range(8):
+            self.A(f"v_add_u32_dpp v{AD[j]}, v{self.QER[slot]}, %[lane16] row_newbcast:{8 * o + j} row_mask:0xf bank_mask:0xf")
+
+    def octet_fmas(self, slot, o, reads):
+        A = self.A
+        x = self.QEX[slot]
+        for g in range(2):
+            self.group_head(set_m0=(g == 0))
+            A(f"s_waitcnt lgkmcnt({4 if reads else 4 - 4 * g})")
+            for j in range(4 * g, 4 * g + 4):
+                bc = f"row_newbcast:{8 * o + j} row_mask:0xf bank_mask:0xf"
+                A(f"v_fmac_f64_dpp {r2(ACC)}, {r2(x)}, {r2(W[j])} {bc}")
+                A(f"v_fmac_f64_dpp {r2(ACC + 2)}, {r2(x)}, {r2(W[j] + 2)} {bc}")
+                if reads:
+                    A(f"ds_read_b128 v[{W[j]}:{W[j] + 3}], v{AD[j]}")
+
+    def body(self, d, L_body, L_exit):
+        """one set at ring slot d; precondition: its loads have landed, the reads of its octet 0 are issued"""
+        A = self.A
+        dn = (d + 1) % self.NS
+        A(f"{L_body[d]}:")
+        A("s_mov_b32 m0, 0")
+        self.addrs(d, 1)
+        self.octet_fmas(d, 0, True)
+        L_last, L_done = self.label("last"), self.label("done")
+        A("s_mov_b32 m0, 0")
+        A(f"s_cmp_le_u32 s{S_NS}, 1")
+        A(f"s_cbranch_scc1 {L_last}")
+        A(f"s_waitcnt vmcnt({2 * (self.NS - 2)})")   # slot d + 1 has landed (d itself is refilled below: 2 (NS - 1) in flight)
+        self.addrs(dn, 0)
+        self.octet_fmas(d, 1, True)
+        A(f"{L_done}:")
+        hot, self.L = self.L, []
+        A(f"{L_last}:")
+        self.octet_fmas(d, 1, False)
+        A(f"s_branch {L_done}")
+        self.cold2 += self.L
+        self.L = hot
+        # every operand of slot d has been read (VALU issue is in order): fetch the set NS ahead into it
+        self.refill(d)
+        A(f"s_sub_u32 s{S_NS}, s{S_NS}, 1")
+        A(f"s_cmp_eq_u32 s{S_NS}, 0")
+        A(f"s_cbranch_scc1 {L_exit[d]}")
+        if d == self.NS - 1:
+            A(f"s_branch {L_body[0]}")
+
+    def chunk(self):
+        A = self.A
+        n = self.NS
+        L_body = [self.label(f"b{d}") for d in range(n)]
+        L_pro = [self.label(f"p{d}") for d in range(n)]
+        L_exit = [self.label(f"x{d}") for d in range(n)]
+        L_end = self.label("end")
+        A(f"s_mov_b64 s[{S_RP}:{S_RP + 1}], %[rp]")
+        A(f"s_mov_b64 s[{S_XP}:{S_XP + 1}], %[xp]")
+        A(f"s_mov_b32 s{S_NS}, %[ns]")
+        for w in range(4):
+            A(f"s_mov_b64 s[{S_Q + 2 * w}:{S_Q + 2 * w + 1}], %[q{w}]")
+        A(f"s_mov_b32 s{S_REM}, 0")
+        A(f"s_mov_b32 s{S_S}, -1")
+        A(f"s_mov_b32 s{S_ACC}, 0")
+        A(f"s_set_gpr_idx_on s{S_ACC}, 0")
+        A("s_mov_b32 m0, 0")
+        for d in range(1, n):
+            A(f"s_cmp_eq_u32 %[phase], {d}")
+            A(f"s_cbranch_scc1 {L_pro[d]}")
+        for d in range(n):
+            A(f"{L_pro[d]}:")
+            A(f"s_waitcnt vmcnt({2 * (n - 1)})")   # all NS slots in flight, slot d the oldest
+            self.addrs(d, 0)
+            for j in range(8):
+                A(f"ds_read_b128 v[{W[j]}:{W[j] + 3}], v{AD[j]}")
+            A(f"s_branch {L_body[d]}")
+        for d in range(n):
+            self.body(d, L_body, L_exit)
+        for d in range(n):
+            A(f"{L_exit[d]}:")
+            A(f"s_mov_b32 %[phase], {(d + 1) % n}")
+            A(f"s_branch {L_end}")
+        self.L += self.cold2 + self.cold
+        A(f"{L_end}:")
+        A("s_mov_b32 m0, 0")
+        A("s_set_gpr_idx_off")
+        A(f"s_mov_b64 %[rp], s[{S_RP}:{S_RP + 1}]")
+        A(f"s_mov_b64 %[xp], s[{S_XP}:{S_XP + 1}]")
+
+
 def main():
     out = ["// generated by gen_acc_tiled.py -- do not edit", "#pragma once"]
     g = Gen()
@@ -241,6 +362,20 @@ def main():
     out.append("")
     clob = [f'"s{r}"' for r in range(S_T, S_Q + 8)] + ['"memory"', '"scc"']
     out.append("#define ACC_TILED_CLOBBERS " + ", ".join(clob))
+    # ---- four columns per LDS instruction (ranks up to 32)
+    out.append("")
+    g = GenQuad()
+    g.chunk()
+    out.append(f"#define ACC_TILED4_CHUNK_ASM \\\n{g.text()}")
+    out.append("")
+    g = GenQuad()
+    g.A(f"s_mov_b64 s[{S_RP}:{S_RP + 1}], %[rp]")
+    g.A(f"s_mov_b64 s[{S_XP}:{S_XP + 1}], %[xp]")
+    for i in range(GenQuad.NS):
+        g.refill(i)
+    g.A(f"s_mov_b64 %[rp], s[{S_RP}:{S_RP + 1}]")
+    g.A(f"s_mov_b64 %[xp], s[{S_XP}:{S_XP + 1}]")
+    out.append(f"#define ACC_TILED4_RING_FILL_ASM \\\n{g.text()}")
     sys.stdout.write("\n".join(out) + "\n")
 
 

@@ -31,6 +31,13 @@
 // Inside a column the products are added in stored (ascending row) order, as
 // in the reference; pads add x = 0 times a finite F entry.
 //
+// Ranks up to 32 use FOUR columns per LDS instruction instead of two (NSL = 4, round 4): a lane still holds two
+// factors, so one 16-lane DPP row covers the rank and the four rows of a wave work on four columns (a column QUAD);
+// a set of 64 stream slots holds 16 entries of each of the quad's columns -- the operand layout row_newbcast wants,
+// so a set needs no preparation -- a wave owns 32 quads = 128 columns, and the LDS tile rows are 256 B apart whatever
+// the rank (every tile row starts on bank 0: the 16-lane groups of ds_read_b128 mix two DPP rows and stay
+// conflict-free only then).  Everything below is written for NSL column slots per instruction (2 or 4).
+//
 // When the column count is too small to fill the chip (W-update: 30 k genes)
 // the tile range is split over blockIdx.y; each split writes a partial k x ncol
 // slab and acc_tiled_reduce sums the slabs in a fixed order.
@@ -45,20 +52,21 @@
 #define TILED_CW 64          // columns per wave
 #define TILED_NP 32          // column pairs per wave
 #define TILED_LDS_BYTES (160 * 1024 - 512)  // the whole 160 KiB of a CU minus the read-past-the-row slack
+#define TILED_SLACK 1024     // stream entries readable past the end (ring prefetch)
 
 // ---------------------------------------------------------------- build -----
 // groups per (wb, t, pair) and entries per chunk
 // Slot (half h, pair p) of wave block wb holds the column at SORTED position wb * 64 + 2p + h: the columns are taken in
 // the order of descending non-zero count (perm), so the two columns of a pair are neighbours in that order and the
 // runs they are padded to are of similar length whatever the skew of the matrix.
-__device__ __forceinline__ int64_t tiled_slot_col(const int32_t* __restrict__ perm, int64_t ncol, int64_t wb, int h, int p) {
-    const int64_t pos = wb * TILED_CW + 2 * p + h;
+__device__ __forceinline__ int64_t tiled_slot_col(const int32_t* __restrict__ perm, int64_t ncol, int64_t wb, int h, int p, int nsl) {
+    const int64_t pos = wb * (TILED_NP * nsl) + nsl * p + h;
     if (pos >= ncol) return -1;
     return perm ? (int64_t)perm[pos] : pos;
 }
 
 __global__ void tiled_count_kernel(const int64_t* __restrict__ seg, const int32_t* __restrict__ perm, int64_t ncol, int T, int64_t nwb,
-                                   uint8_t* __restrict__ cnt, int64_t* __restrict__ chunk_entries) {
+                                   uint8_t* __restrict__ cnt, int64_t* __restrict__ chunk_entries, int nsl) {
     const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // u = wb * T + t
     if (u >= nwb * T) return;
     const int64_t wb = u / T;
@@ -66,19 +74,20 @@ __global__ void tiled_count_kernel(const int64_t* __restrict__ seg, const int32_
     int64_t tot = 0;
     for (int p = 0; p < TILED_NP; ++p) {
         int64_t n = 0;
-        for (int h = 0; h < 2; ++h) {
-            const int64_t col = tiled_slot_col(perm, ncol, wb, h, p);
+        for (int h = 0; h < nsl; ++h) {
+            const int64_t col = tiled_slot_col(perm, ncol, wb, h, p, nsl);
             if (col >= 0) {
                 const int64_t c = seg[(int64_t)(t + 1) * ncol + col] - seg[(int64_t)t * ncol + col];
                 n = c > n ? c : n;
             }
         }
         int g = (int)((n + 3) >> 2);
-        if (p == TILED_NP - 1) g += (int)((8 - ((tot + g) & 7)) & 7);  // half-stream = whole 32-entry steps
+        const int gps = 16 / nsl;   // groups (of 4 entries per slot) in a 64-slot set: whole sets per chunk
+        if (p == TILED_NP - 1) g += (int)((gps - ((tot + g) & (gps - 1))) & (gps - 1));
         cnt[u * TILED_NP + p] = (uint8_t)g;
         tot += g;
     }
-    chunk_entries[u] = tot * 8;  // both halves
+    chunk_entries[u] = tot * 4 * nsl;  // all slots
 }
 
 // one wave per chunk (wb, t): copy / pad the runs of the 32 column pairs
@@ -89,8 +98,9 @@ __global__ __launch_bounds__(256) void tiled_fill_kernel(const double* __restric
                                                          const int64_t* __restrict__ cstart,
                                                          uint32_t* __restrict__ sroff, double* __restrict__ sx,
                                                          int masked, uint64_t seed, SglDiv inv_density, int mask_t,
-                                                         int64_t col_off, int64_t row_off) {
+                                                         int64_t col_off, int64_t row_off, int nsl) {
     const int lane = threadIdx.x & 63;
+    const int eps = 64 / nsl, eps_sh = nsl == 4 ? 4 : 5;   // entries of one column slot in a 64-slot set
     const int64_t gw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
     for (int64_t u = gw; u < nwb * T; u += nw) {
@@ -101,8 +111,8 @@ __global__ __launch_bounds__(256) void tiled_fill_kernel(const double* __restric
         for (int p = 0; p < TILED_NP; ++p) {
             const int n4 = 4 * (int)cnt[u * TILED_NP + p];
             if (n4 == 0) continue;
-            for (int h = 0; h < 2; ++h) {
-                const int64_t col = tiled_slot_col(perm, ncol, wb, h, p);
+            for (int h = 0; h < nsl; ++h) {
+                const int64_t col = tiled_slot_col(perm, ncol, wb, h, p, nsl);
                 int64_t a = 0, b = 0;
                 if (col >= 0) { a = seg[(int64_t)t * ncol + col]; b = seg[(int64_t)(t + 1) * ncol + col]; }
                 for (int q = lane; q < n4; q += 64) {
@@ -118,7 +128,7 @@ __global__ __launch_bounds__(256) void tiled_fill_kernel(const double* __restric
                         }
                     }
                     const int pos = P + q;
-                    const int64_t dst = c0 + (int64_t)(pos >> 5) * 64 + h * 32 + (pos & 31);
+                    const int64_t dst = c0 + (int64_t)(pos >> eps_sh) * 64 + h * eps + (pos & (eps - 1));
                     if (sroff != nullptr) sroff[dst] = ro;
                     sx[dst] = xv;
                 }
@@ -201,14 +211,20 @@ static int tiled_build_perm(sgl_ctx* c, const DevCSC& M, DevTiled& S) {
     }
     // share of the non-zeros held by the heaviest workgroup's columns (the first 8 x 64 of the order): the tile-range
     // split below sizes its work units by it
-    uint32_t top[TILED_NW * TILED_CW];
-    const int64_t ntop = std::min<int64_t>(n, TILED_NW * TILED_CW);
+    static_assert(TILED_CW == 64, "pair layout: 64 columns per wave");
+    std::vector<uint32_t> top_v((size_t)TILED_NW * TILED_CW * 2);   // quad layout: 128 columns per wave
+    uint32_t* top = top_v.data();
+    const int64_t ntop = std::min<int64_t>(n, (int64_t)top_v.size());
     if (rc == SGL_OK && ntop > 0 && hipMemcpyAsync(top, keys_out, sizeof(uint32_t) * (size_t)ntop, hipMemcpyDeviceToHost, s) != hipSuccess) rc = SGL_EHIP;
     const hipError_t e = hipStreamSynchronize(s);
     if (rc == SGL_OK && e == hipSuccess) {
-        int64_t tn = 0;
-        for (int64_t q = 0; q < ntop; ++q) tn += top[q];
+        int64_t tn = 0, tn2 = 0;
+        for (int64_t q = 0; q < ntop; ++q) {
+            if (q < TILED_NW * TILED_CW) tn += top[q];
+            tn2 += top[q];
+        }
         S.top_share = M.nnz > 0 ? (double)tn / (double)M.nnz : 0.0;
+        S.top_share4 = M.nnz > 0 ? (double)tn2 / (double)M.nnz : 0.0;
     }
     if (keys) (void)hipFree(keys);
     if (keys_out) (void)hipFree(keys_out);
@@ -222,14 +238,20 @@ static int tiled_build_perm(sgl_ctx* c, const DevCSC& M, DevTiled& S) {
 
 int sgl_tiled_build(sgl_ctx* c, const DevCSC& M, int k, DevTiled& S) {
     hipStream_t s = c->stream;
+    // ranks up to 32: four columns per LDS instruction (SGL_TILED_NO_QUAD=1: the pair layout at every rank; A/B, tests)
+    const int nsl = (k <= 32 && !getenv("SGL_TILED_NO_QUAD")) ? 4 : 2;
     // same matrix (any change of it frees the streams), same part size: the stream is still valid
-    if (S.built && S.k == k && S.ncol == M.ncol && S.nrow == M.nrow && S.src_nnz == M.nnz && (S.perm != nullptr) == tiled_sort_columns())
+    if (S.built && S.k == k && S.NSL == nsl && S.ncol == M.ncol && S.nrow == M.nrow && S.src_nnz == M.nnz && (S.perm != nullptr) == tiled_sort_columns())
         return SGL_OK;
     S.built = false;
     S.xm_mask_t = -1;   // the masked value array follows the stream layout
     S.k = k;
-    S.CW = TILED_CW;
-    const int KS = (k + 1) & ~1;  // LDS row stride in doubles: rows start 16-byte aligned
+    S.NSL = nsl;
+    S.CW = TILED_NP * nsl;
+    // LDS row stride in doubles.  Pair layout: k rounded up to even (rows start 16-byte aligned).  Quad layout: 32 for
+    // every rank -- all tile rows must start on the same bank (header comment)
+    const int KS = nsl == 4 ? 32 : ((k + 1) & ~1);
+    S.KS = KS;
     int TR = TILED_LDS_BYTES / (KS * 8);
     TR = TR / 8 * 8;
     if (TR > 984) TR = 984;  // groups per pair (+ <= 7 chunk-padding groups) must fit a byte
@@ -263,7 +285,7 @@ int sgl_tiled_build(sgl_ctx* c, const DevCSC& M, int k, DevTiled& S) {
     if (rc == SGL_OK) rc = t_reserve(&S.cstart, &S.cap_cstart, (size_t)nchunks + 1);
     if (rc == SGL_OK) {
         tiled_count_kernel<<<dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, s>>>(S.seg, S.perm, M.ncol, S.T, S.nwb, S.cnt,
-                                                                                         chunk_entries);
+                                                                                         chunk_entries, nsl);
         if (hipGetLastError() != hipSuccess) { sgl_set_error("tiled build: count kernel launch failed"); rc = SGL_EHIP; }
     }
     if (rc == SGL_OK) rc = k_exclusive_scan(c, chunk_entries, S.cstart, nchunks);
@@ -274,18 +296,18 @@ int sgl_tiled_build(sgl_ctx* c, const DevCSC& M, int k, DevTiled& S) {
             hipStreamSynchronize(s) != hipSuccess) { sgl_set_error("tiled build: reading the stream size failed"); rc = SGL_EHIP; }
     }
     S.E = E;
-    // + 512 entries of slack: the kernel prefetches four 64-entry sets past the end
-    if (rc == SGL_OK) rc = t_reserve(&S.roff, &S.cap_roff, (size_t)E + 512);
-    if (rc == SGL_OK) rc = t_reserve(&S.x, &S.cap_x, (size_t)E + 512);
+    // + TILED_SLACK entries of slack: the kernel prefetches its ring (four or eight 64-entry sets) past the end
+    if (rc == SGL_OK) rc = t_reserve(&S.roff, &S.cap_roff, (size_t)E + TILED_SLACK);
+    if (rc == SGL_OK) rc = t_reserve(&S.x, &S.cap_x, (size_t)E + TILED_SLACK);
     if (rc == SGL_OK) {
-        if (hipMemsetAsync(S.roff + E, 0, 512 * sizeof(uint32_t), s) != hipSuccess ||
-            hipMemsetAsync(S.x + E, 0, 512 * sizeof(double), s) != hipSuccess) { sgl_set_error("tiled build: clearing the stream slack failed"); rc = SGL_EHIP; }
+        if (hipMemsetAsync(S.roff + E, 0, TILED_SLACK * sizeof(uint32_t), s) != hipSuccess ||
+            hipMemsetAsync(S.x + E, 0, TILED_SLACK * sizeof(double), s) != hipSuccess) { sgl_set_error("tiled build: clearing the stream slack failed"); rc = SGL_EHIP; }
     }
     if (rc == SGL_OK && nchunks > 0) {
         int64_t blocks = (nchunks + 3) / 4;
         if (blocks > 256 * 64) blocks = 256 * 64;
         tiled_fill_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(M.x, M.i, S.seg, S.perm, M.ncol, S.T, S.nwb, TR, KS * 8,
-                                                                       S.cnt, S.cstart, S.roff, S.x, 0, 0, sgl_div_make(1), 0, 0, 0);
+                                                                       S.cnt, S.cstart, S.roff, S.x, 0, 0, sgl_div_make(1), 0, 0, 0, nsl);
         if (hipGetLastError() != hipSuccess) { sgl_set_error("tiled build: fill kernel launch failed"); rc = SGL_EHIP; }
     }
     // split of the tile range over blockIdx.y so that the grid fills 256 CUs (1 workgroup per CU)
@@ -298,23 +320,56 @@ int sgl_tiled_build(sgl_ctx* c, const DevCSC& M, int k, DevTiled& S) {
     const int r_fill = nwg_x < 1024 ? (int)std::max<int64_t>(1, (512 + nwg_x - 1) / nwg_x) : 1;
     // (only when that workgroup really stands out: on i.i.d. columns its share is 1 / nwg_x and the fill rule decides,
     // with the column groups running fastest -- sizing by balance there cost 8 GB of factor-tile traffic per pass)
-    const bool skewed = S.perm && S.top_share * (double)nwg_x > 1.5;
-    const int r_bal = skewed ? (int)std::min<double>(256.0, ceil(S.top_share * 256.0 / 0.35)) : 1;
-    if (std::max(r_fill, r_bal) > 1) {
+    const double top_share = nsl == 4 ? S.top_share4 : S.top_share;   // of the heaviest workgroup's 512 / 1024 columns
+    const bool skewed = S.perm && top_share * (double)nwg_x > 1.5;
+    const int r_bal = skewed ? (int)std::min<double>(256.0, ceil(top_share * 256.0 / 0.35)) : 1;
+    if (r_bal > r_fill) {
         double best = -1.0;
         // (a fill factor beyond the tile count leaves the range whole, as it always did: such a matrix is tiny)
         const int rmin = std::max(r_fill, (int)std::min<int64_t>(r_bal, std::max(1, S.T)));
-        for (int r = rmin; r <= std::min<int64_t>(S.T, r_bal > r_fill ? rmin + rmin / 4 + 4 : 4 * rmin); ++r) {
+        for (int r = rmin; r <= std::min<int64_t>(S.T, rmin + rmin / 4 + 4); ++r) {
             const int tpr = (S.T + r - 1) / r;
             const int reff = (S.T + tpr - 1) / tpr;  // ranges actually non-empty
             const double wgs = (double)nwg_x * reff;
             const double eff = wgs / (ceil(wgs / 256.0) * 256.0);
             if (eff > best + 1e-9) { best = eff; R = reff; }
         }
+    } else if (r_fill > 1 && S.T > 1 && E >= (4ll << 20) && !getenv("SGL_TILED_OLD_SPLIT")) {
+        // (below ~4 M entries a pass takes microseconds either way: the range stays whole and every b_j is summed in
+        // exactly the reference's order -- a split adds the ranges' partial sums, equal up to rounding)
+        // Too few column groups to fill the chip: cut the tile range into R pieces (sizes floor / ceil of T / R).  Round 4:
+        // R by a cost model instead of "the count of workgroups nearest a multiple of 256" -- that rule took R = T at
+        // BASELINE config 2 in the quad layout (49 column groups x 32 tiles: 1568 workgroups of ONE tile each, every
+        // one clearing and staging 160 KB and writing a 245 KB slab: 0.41 ms per pass; 5 ranges: see profiles/).
+        //   time(R) = rounds x (largest unit x t_tile + t_wg) + t_reduce(R),   rounds = ceil(groups x R / 256 CUs)
+        // t_tile = one workgroup's entry tuples of one tile at the measured 2.4 ns per tuple per CU + 2.5 us of staging,
+        // t_wg = 6 us per workgroup (launch, zeroing, output), t_reduce = the slabs written and read back at 4 TB/s.
+        const double t_tile = (double)E / (double)nsl / ((double)nwg_x * (double)S.T) * 2.4e-9 + 2.5e-6;
+        const double t_wg = 6e-6;
+        double best = 1e300;
+        for (int r = 1; r <= std::min<int64_t>(S.T, 64); ++r) {
+            const double wgs = (double)nwg_x * r;
+            const double rounds = ceil(wgs / 256.0);
+            const int largest = (S.T + r - 1) / r;
+            const double cost = rounds * ((double)largest * t_tile + t_wg) + (r > 1 ? (double)r * (double)k * (double)M.ncol * 16.0 / 4e12 : 0.0);
+            if (cost < best * (1.0 - 1e-9)) { best = cost; R = r; }
+        }
+    } else if (r_fill > 1 && getenv("SGL_TILED_OLD_SPLIT")) {   // rounds 1 - 3: the workgroup count nearest a multiple of 256 (A/B)
+        double best = -1.0;
+        for (int r = r_fill; r <= std::min<int64_t>(S.T, 4 * r_fill); ++r) {
+            const int tpr = (S.T + r - 1) / r;
+            const int reff = (S.T + tpr - 1) / tpr;
+            const double wgs = (double)nwg_x * reff;
+            const double eff = wgs / (ceil(wgs / 256.0) * 256.0);
+            if (eff > best + 1e-9) { best = eff; R = reff; }
+        }
+    }
+    if (const char* fr = getenv("SGL_TILED_RANGES")) {   // tests: force the slab path (or the whole range) on small matrices
+        if (atoi(fr) > 0) R = atoi(fr);
     }
     S.range_fastest = r_bal > r_fill;
-    S.tiles_per_range = (S.T + R - 1) / R;
-    S.R = (S.T + S.tiles_per_range - 1) / S.tiles_per_range;
+    S.R = std::max(1, std::min(R, std::max(1, S.T)));   // range y = tiles [y T / R, (y + 1) T / R): none empty
+    S.tiles_per_range = (S.T + S.R - 1) / S.R;
     if (rc == SGL_OK && S.R > 1) rc = t_reserve(&S.part, &S.cap_part, (size_t)S.R * (size_t)k * (size_t)M.ncol);
     hipError_t e = hipStreamSynchronize(s);
     if (chunk_entries) (void)hipFree(chunk_entries);
@@ -339,16 +394,16 @@ int sgl_tiled_mask_values(sgl_ctx* c, const DevCSC& M, DevTiled& S, uint64_t see
     if (S.xm && S.xm_seed == seed && S.xm_inv == inv_density && S.xm_mask_t == mask_t) return SGL_OK;
     hipStream_t s = c->stream;
     S.xm_mask_t = -1;
-    SGLCHK(t_reserve(&S.xm, &S.cap_xm, (size_t)S.E + 512));
-    HIPCHK(hipMemsetAsync(S.xm + S.E, 0, 512 * sizeof(double), s));
+    SGLCHK(t_reserve(&S.xm, &S.cap_xm, (size_t)S.E + TILED_SLACK));
+    HIPCHK(hipMemsetAsync(S.xm + S.E, 0, TILED_SLACK * sizeof(double), s));
     const int64_t nchunks = S.nwb * S.T;
     if (nchunks > 0) {
-        const int KS = (S.k + 1) & ~1;
+        const int KS = S.KS;
         int64_t blocks = (nchunks + 3) / 4;
         if (blocks > 256 * 64) blocks = 256 * 64;
         tiled_fill_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(M.x, M.i, S.seg, S.perm, M.ncol, S.T, S.nwb, S.TR, KS * 8, S.cnt,
                                                                        S.cstart, nullptr, S.xm, 1, seed, sgl_div_make(inv_density),
-                                                                       mask_t, col_off, row_off);
+                                                                       mask_t, col_off, row_off, S.NSL);
         HIPCHK(hipGetLastError());
     }
     S.xm_seed = seed; S.xm_inv = inv_density; S.xm_mask_t = mask_t;
@@ -397,6 +452,7 @@ __device__ __forceinline__ void acc_load(int idx4, double& v0, double& v1) {
 // The chunk loop is the hand-scheduled inline asm of gen_acc_tiled.py (register plan there).  The compiler's budget
 // is v0..v63 (amdgpu_waves_per_eu(8, 8) caps its allocation at 512 / 8 registers); the clobber makes the kernel
 // descriptor allocate all 256: v64..v255 belong to the asm, whose stream ring stays in flight across compiler code.
+template <int NSL>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) void acc_tiled_kernel(
     const uint32_t* __restrict__ sroff, const double* __restrict__ sx, const int64_t* __restrict__ cstart,
     const uint8_t* __restrict__ cnt, int T, int64_t nwb, const double* __restrict__ F, int k, int TR, int64_t nrow,
@@ -421,12 +477,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         by = unit - bx * nranges;
     }
     const int64_t wb = (int64_t)bx * TILED_NW + wave;
-    const int t0 = by * tiles_per_range;
-    const int t1 = (t0 + tiles_per_range < T) ? (t0 + tiles_per_range) : T;
+    // tile range `by` of gridDim.y: sizes floor / ceil of T / ranges (tiles_per_range = the ceil, kept for the layout query)
+    const unsigned nry = gridDim.y;
+    const int t0 = (int)(((int64_t)by * T) / nry);
+    const int t1 = (int)((((int64_t)by + 1) * T) / nry);
     const bool wact = wb < nwb;
     typedef __attribute__((address_space(3))) char lds_char;
-    // LDS byte address of this lane's pair of factor rows inside a tile row
-    const unsigned lane16 = (unsigned)(uintptr_t)(lds_char*)smem + (lane & 31) * 16;
+    // LDS byte address of this lane's pair of factor rows inside a tile row (NSL = 4: 16 lanes cover a column)
+    constexpr int LMASK = NSL == 4 ? 15 : 31;
+    const unsigned lane16 = (unsigned)(uintptr_t)(lds_char*)smem + (lane & LMASK) * 16;
     const unsigned voff4 = lane * 4, voff8 = lane * 8;
 
     asm volatile(ACC_TILED_ZERO_ASM ::: "memory");
@@ -445,7 +504,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         const uint64_t r_ = reinterpret_cast<uint64_t>(sroff + pos), x_ = reinterpret_cast<uint64_t>(sx + pos);
         rp = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((unsigned)(r_ >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((unsigned)r_);
         xp = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((unsigned)(x_ >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((unsigned)x_);
-        asm volatile(ACC_TILED_RING_FILL_ASM : [rp] "+s"(rp), [xp] "+s"(xp) : [voff4] "v"(voff4), [voff8] "v"(voff8) : ACC_TILED_CLOBBERS);
+        if constexpr (NSL == 4)
+            asm volatile(ACC_TILED4_RING_FILL_ASM : [rp] "+s"(rp), [xp] "+s"(xp) : [voff4] "v"(voff4), [voff8] "v"(voff8) : ACC_TILED_CLOBBERS);
+        else
+            asm volatile(ACC_TILED_RING_FILL_ASM : [rp] "+s"(rp), [xp] "+s"(xp) : [voff4] "v"(voff4), [voff8] "v"(voff8) : ACC_TILED_CLOBBERS);
+    }
+    if constexpr (NSL == 4) {
+        // the tile rows are 256 B apart whatever the rank: bytes k * 8 .. 255 of a row are never staged; clear them
+        // once (they only ever reach accumulator lanes that are not written out, but must stay finite: 0 * NaN)
+        for (int e = (int)threadIdx.x; e < TILED_LDS_BYTES / 8; e += 64 * TILED_NW) tile[e] = 0.0;
     }
 
     int64_t pos_cur = wact ? cstart[wb * T + t0] : 0;
@@ -464,7 +531,47 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         const int rows = (int)((nrow - row0 < TR) ? (nrow - row0) : TR);
         const int n = rows * k;
         const double* __restrict__ src = F + row0 * ldf;
-        if (KS == k && ldf == k) {
+        if constexpr (NSL == 4) {
+            // Quad layout: LDS rows of 32 doubles.  16 lanes per tile row (lane c moves the 16-byte piece c, or -- odd
+            // rank / unaligned rows -- the doubles c and c + 16), 32 rows per round of the workgroup: no divisions, every
+            // row's k * 8 contiguous bytes read by neighbouring lanes.  First round's loads before the barrier.
+            const int c16 = (int)threadIdx.x & 15, r0 = (int)threadIdx.x >> 4;
+            constexpr int RPR = 64 * TILED_NW / 16;   // rows per round
+            const bool vec = ((k | ldf) & 1) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0;
+            if (vec) {
+                constexpr int RST = 4;
+                double2 stg[RST];
+                const bool cact = 2 * c16 < k;
+#pragma unroll
+                for (int j = 0; j < RST; ++j) {
+                    const int r = r0 + j * RPR;
+                    stg[j] = double2{0.0, 0.0};
+                    if (cact && r < rows) stg[j] = *reinterpret_cast<const double2*>(src + (int64_t)r * ldf + 2 * c16);
+                }
+                __syncthreads();  // everyone is done reading the previous tile
+                for (int rb = 0; rb < rows; rb += RST * RPR) {
+#pragma unroll
+                    for (int j = 0; j < RST; ++j) {
+                        const int r = rb + r0 + j * RPR;
+                        if (cact && r < rows) *reinterpret_cast<double2*>(tile + r * 32 + 2 * c16) = stg[j];
+                    }
+                    if (rb + RST * RPR < rows) {
+#pragma unroll
+                        for (int j = 0; j < RST; ++j) {
+                            const int r = rb + RST * RPR + r0 + j * RPR;
+                            stg[j] = double2{0.0, 0.0};
+                            if (cact && r < rows) stg[j] = *reinterpret_cast<const double2*>(src + (int64_t)r * ldf + 2 * c16);
+                        }
+                    }
+                }
+            } else {
+                __syncthreads();
+                for (int r = r0; r < rows; r += RPR) {
+                    if (c16 < k) tile[r * 32 + c16] = src[(int64_t)r * ldf + c16];
+                    if (c16 + 16 < k) tile[r * 32 + c16 + 16] = src[(int64_t)r * ldf + c16 + 16];
+                }
+            }
+        } else if (KS == k && ldf == k) {
             // Each thread moves up to NRND * RST 16-byte pieces of the (contiguous) tile in NRND rounds of
             // RST loads in flight.  The loads of the first round are issued before the barrier: they overlap
             // the tail of the previous tile's work of the other waves.
@@ -520,23 +627,30 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
         __syncthreads();
         if (wact && nsets > 0) {
-            asm volatile(ACC_TILED_CHUNK_ASM
-                         : [rp] "+s"(rp), [xp] "+s"(xp), [phase] "+s"(phase)
-                         : [ns] "s"(nsets), [q0] "s"(q0), [q1] "s"(q1), [q2] "s"(q2), [q3] "s"(q3), [lane16] "v"(lane16),
-                           [voff4] "v"(voff4), [voff8] "v"(voff8)
-                         : ACC_TILED_CLOBBERS);
+            if constexpr (NSL == 4)
+                asm volatile(ACC_TILED4_CHUNK_ASM
+                             : [rp] "+s"(rp), [xp] "+s"(xp), [phase] "+s"(phase)
+                             : [ns] "s"(nsets), [q0] "s"(q0), [q1] "s"(q1), [q2] "s"(q2), [q3] "s"(q3), [lane16] "v"(lane16),
+                               [voff4] "v"(voff4), [voff8] "v"(voff8)
+                             : ACC_TILED_CLOBBERS);
+            else
+                asm volatile(ACC_TILED_CHUNK_ASM
+                             : [rp] "+s"(rp), [xp] "+s"(xp), [phase] "+s"(phase)
+                             : [ns] "s"(nsets), [q0] "s"(q0), [q1] "s"(q1), [q2] "s"(q2), [q3] "s"(q3), [lane16] "v"(lane16),
+                               [voff4] "v"(voff4), [voff8] "v"(voff8)
+                             : ACC_TILED_CLOBBERS);
         }
     }
-    // Up to four refills (issued past the end of this wave's range, into the stream's slack) are still in flight;
-    // they write the ring registers v64..v75 only, which nothing below touches
+    // Up to four (eight) refills (issued past the end of this wave's range, into the stream's slack) are still in
+    // flight; they write the ring registers v64..v75 (v64..v87) only, which nothing below touches
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (wact) {
         double* out = Bout + (size_t)by * (size_t)slab;
-        const int f = 2 * (lane & 31);
+        const int f = 2 * (lane & LMASK);
         for (int p = 0; p < TILED_NP; ++p) {
             double v0, v1;
             acc_load(4 * p, v0, v1);
-            const int64_t col = tiled_slot_col(perm, ncol, wb, lane >> 5, p);
+            const int64_t col = tiled_slot_col(perm, ncol, wb, NSL == 4 ? (lane >> 4) : (lane >> 5), p, NSL);
             if (col >= 0) {
                 if (f < k) out[col * ldb + f] = v0;
                 if (f + 1 < k) out[col * ldb + f + 1] = v1;
@@ -564,14 +678,16 @@ __global__ void acc_tiled_reduce_kernel(const double* __restrict__ part, int R, 
 int k_acc_tiled(hipStream_t s, const DevTiled& S, const double* F, int ldf, double* B, int ldb, int kf, const double* xvals) {
     if (S.ncol <= 0) return SGL_OK;
     if (kf <= 0 || kf > S.k) { sgl_set_error("k_acc_tiled: bad part size %d (stream built for %d)", kf, S.k); return SGL_EINVAL; }
-    const int KS = (S.k + 1) & ~1;
-    const size_t lds = (size_t)S.TR * KS * 8 + 512;
+    const int KS = S.KS;
+    const size_t lds = S.NSL == 4 ? (size_t)TILED_LDS_BYTES + 512 : (size_t)S.TR * KS * 8 + 512;
     // the attribute belongs to the (function, device) pair: one process may drive several devices
     static std::atomic<bool> attr_set[64];   // several host threads may drive devices at once (replica sweep)
     int dev = 0;
     HIPCHK(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&acc_tiled_kernel),
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&acc_tiled_kernel<2>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, TILED_LDS_BYTES + 512));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&acc_tiled_kernel<4>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, TILED_LDS_BYTES + 512));
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
@@ -579,9 +695,14 @@ int k_acc_tiled(hipStream_t s, const DevTiled& S, const double* F, int ldf, doub
     const bool slabs = S.R > 1;
     double* out = slabs ? S.part : B;
     const int64_t n = (int64_t)kf * S.ncol;
-    acc_tiled_kernel<<<dim3((unsigned)nwg_x, (unsigned)S.R), dim3(64 * TILED_NW), lds, s>>>(
-        S.roff, xvals ? xvals : S.x, S.cstart, S.cnt, S.T, S.nwb, F, kf, S.TR, S.nrow, S.tiles_per_range, out, S.ncol, KS, ldf,
-        slabs ? kf : ldb, slabs ? n : 0, S.perm, S.range_fastest ? 1 : 0);
+    if (S.NSL == 4)
+        acc_tiled_kernel<4><<<dim3((unsigned)nwg_x, (unsigned)S.R), dim3(64 * TILED_NW), lds, s>>>(
+            S.roff, xvals ? xvals : S.x, S.cstart, S.cnt, S.T, S.nwb, F, kf, S.TR, S.nrow, S.tiles_per_range, out, S.ncol, KS, ldf,
+            slabs ? kf : ldb, slabs ? n : 0, S.perm, S.range_fastest ? 1 : 0);
+    else
+        acc_tiled_kernel<2><<<dim3((unsigned)nwg_x, (unsigned)S.R), dim3(64 * TILED_NW), lds, s>>>(
+            S.roff, xvals ? xvals : S.x, S.cstart, S.cnt, S.T, S.nwb, F, kf, S.TR, S.nrow, S.tiles_per_range, out, S.ncol, KS, ldf,
+            slabs ? kf : ldb, slabs ? n : 0, S.perm, S.range_fastest ? 1 : 0);
     HIPCHK(hipGetLastError());
     if (slabs) {
         int64_t blocks = (n + 255) / 256;

@@ -61,6 +61,7 @@ struct DevTiled {
     int64_t perm_nnz = -1;      // the matrix (by its non-zero count) perm was computed for
     bool range_fastest = false; // work units ordered (column group, tile range) instead of (tile range, column group)
     double top_share = 0.0;     // share of the non-zeros in the first 512 columns of that order (the heaviest workgroup)
+    double top_share4 = 0.0;    // ... in the first 1024 (the heaviest workgroup of the quad layout)
     // The buffers outlive a fit: a rank sweep re-inits the fit tens of times on one matrix, and hipMalloc / hipFree of
     // tens of GB cost up to seconds each at config-5 size.  cap_* = allocated element counts; `built` = the stream
     // content is valid for (k, src_nnz); any change of the matrix frees everything (sgl_tiled_free).
@@ -68,6 +69,8 @@ struct DevTiled {
     bool built = false;
     int64_t src_nnz = -1;
     int32_t TR = 0, T = 0, CW = 0, k = 0, R = 1, tiles_per_range = 0;
+    int32_t NSL = 2;            // column slots per LDS instruction: 2 (pairs, k <= 64) or 4 (quads, k <= 32); CW = 32 * NSL
+    int32_t KS = 0;             // LDS row stride in doubles the row offsets were built for
     int64_t nwb = 0, E = 0, ncol = 0, nrow = 0;
 };
 

@@ -145,27 +145,86 @@ def test_rhs_both_orientations(ctx, ora, sa, k):
     assert rel_fro(ctx.op_rhs(1, H), ora.rhs(At, H)) < 1e-14
 
 
-@pytest.mark.parametrize("k", [2, 7, 31, 50, 64, 65, 70, 100, 127, 128])
+@pytest.mark.parametrize("k", [1, 2, 7, 10, 16, 30, 31, 32, 33, 50, 64, 65, 70, 100, 127, 128])
 def test_rhs_tiled_kernel_all_ranks(ctx, ora, sa, k):
-    """The LDS-tiled accumulate (which = 2 / 3): one pass for k <= 64, two passes over factor halves
-    for 64 < k <= 128 (strided factor rows and outputs), odd ranks through the re-pitched staging."""
+    """The LDS-tiled accumulate (which = 2 / 3): four columns per LDS instruction up to k = 32 (256-byte tile rows),
+    two up to k = 64, two passes over factor halves for 64 < k <= 128 (strided factor rows and outputs), odd ranks
+    through the re-pitched staging.  Bit-equal to the plain CSC kernel (same products, same order), 1e-14 to the oracle."""
     A = ora.synth_csc(700, 900, 12)
     At = A.t()
     ctx.upload(to_dgc(sa, A), to_dgc(sa, At))
     rng = np.random.default_rng(k)
     W = rng.random((A.nrow, k))
     H = rng.random((A.ncol, k))
-    assert rel_fro(ctx.op_rhs(2, W), ora.rhs(A, W)) < 1e-14
-    assert rel_fro(ctx.op_rhs(3, H), ora.rhs(At, H)) < 1e-14
+    for which, F, M in ((2, W, A), (3, H, At)):
+        got = ctx.op_rhs(which, F)
+        assert rel_fro(got, ora.rhs(M, F)) < 1e-14
+        if k <= 64:
+            assert np.array_equal(got, ctx.op_rhs(which - 2, F))
 
 
+@pytest.mark.parametrize("k", [2, 10, 16, 30, 32])
+def test_rhs_tiled_quad_layout_equals_the_pair_layout(sa, ora, k, monkeypatch):
+    """Ranks up to 32 on a matrix with several row tiles, column blocks and tile ranges (2500 x 3000, ~10 % non-zero):
+    the quad layout (default) against the pair layout (SGL_TILED_NO_QUAD=1) and the plain kernel, bit for bit, and its
+    stream is the one the layout query reports (128 columns per block, 632-row tiles)."""
+    A = ora.synth_csc(2500, 3000, 10)
+    At = A.t()
+    rng = np.random.default_rng(100 + k)
+    W, H = rng.random((A.nrow, k)), rng.random((A.ncol, k))
+    out, lay = {}, {}
+    for quad in (True, False):
+        if quad:
+            monkeypatch.delenv("SGL_TILED_NO_QUAD", raising=False)
+        else:
+            monkeypatch.setenv("SGL_TILED_NO_QUAD", "1")
+        c = sa.Context(0)
+        try:
+            c.upload(to_dgc(sa, A), to_dgc(sa, At))
+            out[quad] = (c.op_rhs(2, W), c.op_rhs(3, H), c.op_rhs(0, W), c.op_rhs(1, H))
+            c.fit_init(k, ora.synth_winit(k, A.nrow))
+            lay[quad] = c.layout_get()
+        finally:
+            c.close()
+    for q in range(2):
+        assert np.array_equal(out[True][q], out[False][q]) and np.array_equal(out[True][q], out[True][q + 2])
+    assert rel_fro(out[True][0], ora.rhs(A, W)) < 1e-14 and rel_fro(out[True][1], ora.rhs(At, H)) < 1e-14
+    assert lay[True]["A"]["col_blocks"] == (3000 + 127) // 128 and lay[False]["A"]["col_blocks"] == (3000 + 63) // 64
+    assert lay[True]["A"]["tile_rows"] == 632 and lay[True]["A"]["tiles"] == 4
+
+
+@pytest.mark.parametrize("k,ranges", [(10, 3), (30, 4), (50, 2), (50, 5)])
+def test_rhs_tiled_split_tile_ranges(sa, ora, k, ranges, monkeypatch):
+    """The tile range cut over blockIdx.y (what fills the chip when the columns are few: the W side of every config):
+    ranges of floor / ceil of T / R tiles, partial slabs summed in range order.  The sums are those of the whole range up
+    to rounding (1e-14 to the oracle), not bit for bit; forced here on a small matrix with SGL_TILED_RANGES."""
+    monkeypatch.setenv("SGL_TILED_RANGES", str(ranges))
+    A = ora.synth_csc(3300, 700, 10)      # 6 tiles of 632 rows (k <= 32), 9 of 408 at k = 50
+    At = A.t()
+    rng = np.random.default_rng(7 * k + ranges)
+    W, H = rng.random((A.nrow, k)), rng.random((A.ncol, k))
+    c = sa.Context(0)
+    try:
+        c.upload(to_dgc(sa, A), to_dgc(sa, At))
+        got = c.op_rhs(2, W), c.op_rhs(3, H)
+        c.fit_init(k, ora.synth_winit(k, A.nrow))
+        lay = c.layout_get()
+    finally:
+        c.close()
+    assert lay["A"]["tile_ranges"] == ranges and lay["At"]["tile_ranges"] == min(ranges, lay["At"]["tiles"])
+    assert rel_fro(got[0], ora.rhs(A, W)) < 1e-14 and rel_fro(got[1], ora.rhs(At, H)) < 1e-14
+
+
+@pytest.mark.parametrize("layout", ["quad", "pair"])
 @pytest.mark.parametrize("shape", ["very_sparse", "dense_blocks", "one_pair_only"])
-def test_rhs_tiled_pair_bookkeeping_extremes(ctx, ora, sa, shape):
+def test_rhs_tiled_pair_bookkeeping_extremes(ctx, ora, sa, shape, layout, monkeypatch):
     """The chunk loop of the tiled accumulate walks a byte queue of per-pair group counts (gen_acc_tiled.py): most
     counts zero (long skips, queue rotation over empty 64-bit words), counts near the byte's limit (whole columns
     dense inside a tile), and a chunk whose entries all belong to one pair.  Against the plain kernel and the oracle."""
+    if layout == "pair":
+        monkeypatch.setenv("SGL_TILED_NO_QUAD", "1")
     rng = np.random.default_rng({"very_sparse": 1, "dense_blocks": 2, "one_pair_only": 3}[shape])
-    m, n, k = 2300, 200, 10                     # k = 10: tiles of 984 rows (the cap), 3 tiles
+    m, n, k = 2300, 200, 10                     # k = 10: tiles of 984 rows (the cap; 632 in the quad layout)
     D = np.zeros((m, n))
     if shape == "very_sparse":
         idx = rng.integers(0, m * n, size=150)  # a handful of entries: almost every (chunk, pair) is empty

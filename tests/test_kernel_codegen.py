@@ -26,11 +26,13 @@ def tiled_asm(tmp_path_factory):
     subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-S",
                     "--cuda-device-only", "-o", out, SRC], check=True, capture_output=True, timeout=600)
     text = open(out).read()
-    m = re.search(r"^_Z16acc_tiled_kernel.*?:\n(.*?)s_endpgm", text, re.S | re.M)
-    assert m, "acc_tiled_kernel not found in the assembly"
-    meta = text[text.index("s_endpgm", m.start()):]
-    end = meta.find(".end_amdhsa_kernel")
-    return m.group(1), meta[:end if end > 0 else 6000]
+    inst = {}
+    for nsl in (2, 4):   # acc_tiled_kernel<NSL>: pairs (k <= 64) and quads (k <= 32) of columns per LDS instruction
+        m = re.search(r"^(_Z16acc_tiled_kernelILi%dEE\w*):[^\n]*\n(.*?)s_endpgm" % nsl, text, re.S | re.M)
+        assert m, "acc_tiled_kernel<%d> not found in the assembly" % nsl
+        meta = text[text.index(".amdhsa_kernel " + m.group(1)):]
+        inst[nsl] = (m.group(2), meta[:meta.index(".end_amdhsa_kernel")])
+    return inst
 
 
 def _vregs(line):
@@ -41,8 +43,9 @@ def _vregs(line):
     return regs
 
 
-def test_compiler_stays_below_v64_and_keeps_scratch_out_of_the_loop(tiled_asm):
-    body, meta = tiled_asm
+@pytest.mark.parametrize("nsl", [2, 4])
+def test_compiler_stays_below_v64_and_keeps_scratch_out_of_the_loop(tiled_asm, nsl):
+    body, meta = tiled_asm[nsl]
     in_asm, worst = False, -1
     for line in body.splitlines():
         if "#ASMSTART" in line:
@@ -68,7 +71,7 @@ def test_chunk_loop_is_the_generated_asm_with_counted_waits(tiled_asm):
     """The chunk loop must be the generated block: four ring-slot bodies + four prologues, each preparing a set behind
     the counted stream wait vmcnt(6); one counted LDS wait per group of four entry pairs (a full drain only in front
     of the last group of a chunk), no vmcnt(0); vector destinations are only written while M0 indexes nothing."""
-    body, _ = tiled_asm
+    body, _ = tiled_asm[2]
     blocks = re.findall(r"#ASMSTART(.*?)#ASMEND", body, re.S)
     chunk = [b for b in blocks if "v_fmac_f64_dpp" in b]
     assert len(chunk) == 1, "expected exactly one asm block with the FMAs"
@@ -89,6 +92,40 @@ def test_chunk_loop_is_the_generated_asm_with_counted_waits(tiled_asm):
         elif l.startswith(".Ltiled_last") or l.startswith(".Ltiled_sw"):
             m0 = "cold"    # out-of-line code: FMAs behind a group head, no vector-destination VALU besides them
         elif l.startswith(("v_add_u32_dpp", "v_mov_b32", "v_permlane16_swap")):
+            assert m0 == "0", "VALU with a vector destination while M0 indexes destinations: %s" % l
+
+
+def test_quad_chunk_loop_reads_its_operands_from_the_ring(tiled_asm):
+    """acc_tiled_kernel<4> (ranks up to 32, four columns per LDS instruction): eight ring-slot bodies of two octets, no
+    set preparation (no v_mov / v_permlane16_swap: the DPP operands are the ring registers, written by vector loads
+    only -- no VALU-write -> DPP-read hazard can exist), counted stream waits, destinations written only with M0 off."""
+    body, _ = tiled_asm[4]
+    blocks = re.findall(r"#ASMSTART(.*?)#ASMEND", body, re.S)
+    chunk = [b for b in blocks if "v_fmac_f64_dpp" in b]
+    assert len(chunk) == 1
+    text = chunk[0]
+    assert "v_permlane16_swap" not in text and "v_mov_b32 v" not in text and "v_readlane" not in text
+    assert "vmcnt(0)" not in text
+    assert text.count("s_waitcnt vmcnt(14)") == 8 and text.count("s_waitcnt vmcnt(12)") == 8
+    assert text.count("v_fmac_f64_dpp") == 8 * (2 + 1) * 16
+    assert text.count("ds_read_b128") == 8 * 8 + 8 * 2 * 8
+    assert text.count("global_load_dword ") == 8 and text.count("global_load_dwordx2") == 8
+    # DPP sources: ring registers only (v64..v71 row offsets, v[72:87] values)
+    for l in (x.strip() for x in text.splitlines()):
+        if l.startswith("v_add_u32_dpp"):
+            src = int(re.match(r"v_add_u32_dpp v\d+, v(\d+),", l).group(1))
+            assert 64 <= src <= 71, l
+        elif l.startswith("v_fmac_f64_dpp"):
+            src = int(re.match(r"v_fmac_f64_dpp v\[\d+:\d+\], v\[(\d+):\d+\],", l).group(1))
+            assert 72 <= src <= 86 and src % 2 == 0, l
+    hot = text[:text.index("s_set_gpr_idx_off")]
+    m0 = None
+    for l in (x.strip() for x in hot.splitlines()):
+        if l.startswith("s_mov_b32 m0"):
+            m0 = l.split(",")[1].strip()
+        elif l.startswith(".Ltiled_last") or l.startswith(".Ltiled_sw"):
+            m0 = "cold"
+        elif l.startswith("v_add_u32_dpp"):
             assert m0 == "0", "VALU with a vector destination while M0 indexes destinations: %s" % l
 
 
