@@ -340,6 +340,27 @@ class GenQuad(Gen):
         A(f"s_mov_b64 %[xp], s[{S_XP}:{S_XP + 1}]")
 
 
+class GenPairRing(GenQuad):
+    """The pair layout (two columns per LDS instruction, ranks 33 - 64) on the quad loop's structure (round 4): the
+    stream format is unchanged -- sets of 64 slots = 32 entries of the A half, 32 of the B half -- but a ring slot now
+    takes HALF a set, loaded with the lane rows doubled: lanes 0-15 and 16-31 both read the A half's entries
+    16 s .. 16 s + 15, lanes 32-47 and 48-63 the B half's (duplicate addresses inside one load cost nothing: same cache
+    lines).  That is the [A A B B] operand layout the DPP row broadcasts want, so the six v_mov + three
+    v_permlane16_swap + waits that turned [A0 A1 B0 B1] into it for every set are gone; the address adds and the FMAs
+    read the ring registers directly.  %[voff4] / %[voff8] carry the doubled lane mapping."""
+
+    def refill(self, i):
+        A = self.A
+        st, sub = i >> 1, i & 1
+        A(f"global_load_dword v{self.QER[i]}, %[voff4], s[{S_RP}:{S_RP + 1}] offset:{256 * st + 64 * sub}")
+        A(f"global_load_dwordx2 {r2(self.QEX[i])}, %[voff8], s[{S_XP}:{S_XP + 1}] offset:{512 * st + 128 * sub}")
+        if i == self.NS - 1:
+            A(f"s_add_u32 s{S_RP}, s{S_RP}, {128 * self.NS}")
+            A(f"s_addc_u32 s{S_RP + 1}, s{S_RP + 1}, 0")
+            A(f"s_add_u32 s{S_XP}, s{S_XP}, {256 * self.NS}")
+            A(f"s_addc_u32 s{S_XP + 1}, s{S_XP + 1}, 0")
+
+
 def main():
     out = ["// generated by gen_acc_tiled.py -- do not edit", "#pragma once"]
     g = Gen()
@@ -376,6 +397,20 @@ def main():
     g.A(f"s_mov_b64 %[rp], s[{S_RP}:{S_RP + 1}]")
     g.A(f"s_mov_b64 %[xp], s[{S_XP}:{S_XP + 1}]")
     out.append(f"#define ACC_TILED4_RING_FILL_ASM \\\n{g.text()}")
+    # ---- the pair layout on the same loop structure (half-set ring slots, no set preparation)
+    out.append("")
+    g = GenPairRing()
+    g.chunk()
+    out.append(f"#define ACC_TILED2R_CHUNK_ASM \\\n{g.text()}")
+    out.append("")
+    g = GenPairRing()
+    g.A(f"s_mov_b64 s[{S_RP}:{S_RP + 1}], %[rp]")
+    g.A(f"s_mov_b64 s[{S_XP}:{S_XP + 1}], %[xp]")
+    for i in range(GenPairRing.NS):
+        g.refill(i)
+    g.A(f"s_mov_b64 %[rp], s[{S_RP}:{S_RP + 1}]")
+    g.A(f"s_mov_b64 %[xp], s[{S_XP}:{S_XP + 1}]")
+    out.append(f"#define ACC_TILED2R_RING_FILL_ASM \\\n{g.text()}")
     sys.stdout.write("\n".join(out) + "\n")
 
 

@@ -452,7 +452,9 @@ __device__ __forceinline__ void acc_load(int idx4, double& v0, double& v1) {
 // The chunk loop is the hand-scheduled inline asm of gen_acc_tiled.py (register plan there).  The compiler's budget
 // is v0..v63 (amdgpu_waves_per_eu(8, 8) caps its allocation at 512 / 8 registers); the clobber makes the kernel
 // descriptor allocate all 256: v64..v255 belong to the asm, whose stream ring stays in flight across compiler code.
-template <int NSL>
+// MODE 2: pairs of columns, sets prepared (rounds 2 - 3; SGL_TILED_PREP=1);  MODE 3: pairs of columns on half-set ring
+// slots loaded with doubled lane rows, no preparation (round 4, the default for ranks 33 - 64);  MODE 4: quads of columns
+template <int MODE>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) void acc_tiled_kernel(
     const uint32_t* __restrict__ sroff, const double* __restrict__ sx, const int64_t* __restrict__ cstart,
     const uint8_t* __restrict__ cnt, int T, int64_t nwb, const double* __restrict__ F, int k, int TR, int64_t nrow,
@@ -461,6 +463,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     // k = factor rows handled by this launch (a part of the rank when it is above 64), KS = LDS row
     // stride the stream's offsets were built for, ldf / ldb = strides (doubles) between rows of F /
     // columns of the output, slab = doubles between the outputs of two tile ranges (blockIdx.y)
+    constexpr int NSL = MODE == 4 ? 4 : 2;
     asm volatile("" ::: "v255");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* tile = reinterpret_cast<double*>(smem);
@@ -486,7 +489,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     // LDS byte address of this lane's pair of factor rows inside a tile row (NSL = 4: 16 lanes cover a column)
     constexpr int LMASK = NSL == 4 ? 15 : 31;
     const unsigned lane16 = (unsigned)(uintptr_t)(lds_char*)smem + (lane & LMASK) * 16;
-    const unsigned voff4 = lane * 4, voff8 = lane * 8;
+    // stream slot this lane loads of a (half) set.  MODE 3: lane rows doubled -- lanes 0-15 and 16-31 the A half's 16
+    // entries, lanes 32-47 and 48-63 the B half's (slots 32 ..): the [A A B B] layout the row broadcasts read
+    const unsigned slot = MODE == 3 ? (unsigned)((lane >> 5) * 32 + (lane & 15)) : (unsigned)lane;
+    const unsigned voff4 = slot * 4, voff8 = slot * 8;
 
     asm volatile(ACC_TILED_ZERO_ASM ::: "memory");
 
@@ -504,8 +510,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         const uint64_t r_ = reinterpret_cast<uint64_t>(sroff + pos), x_ = reinterpret_cast<uint64_t>(sx + pos);
         rp = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((unsigned)(r_ >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((unsigned)r_);
         xp = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((unsigned)(x_ >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((unsigned)x_);
-        if constexpr (NSL == 4)
+        if constexpr (MODE == 4)
             asm volatile(ACC_TILED4_RING_FILL_ASM : [rp] "+s"(rp), [xp] "+s"(xp) : [voff4] "v"(voff4), [voff8] "v"(voff8) : ACC_TILED_CLOBBERS);
+        else if constexpr (MODE == 3)
+            asm volatile(ACC_TILED2R_RING_FILL_ASM : [rp] "+s"(rp), [xp] "+s"(xp) : [voff4] "v"(voff4), [voff8] "v"(voff8) : ACC_TILED_CLOBBERS);
         else
             asm volatile(ACC_TILED_RING_FILL_ASM : [rp] "+s"(rp), [xp] "+s"(xp) : [voff4] "v"(voff4), [voff8] "v"(voff8) : ACC_TILED_CLOBBERS);
     }
@@ -627,10 +635,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
         __syncthreads();
         if (wact && nsets > 0) {
-            if constexpr (NSL == 4)
+            if constexpr (MODE == 4)
                 asm volatile(ACC_TILED4_CHUNK_ASM
                              : [rp] "+s"(rp), [xp] "+s"(xp), [phase] "+s"(phase)
                              : [ns] "s"(nsets), [q0] "s"(q0), [q1] "s"(q1), [q2] "s"(q2), [q3] "s"(q3), [lane16] "v"(lane16),
+                               [voff4] "v"(voff4), [voff8] "v"(voff8)
+                             : ACC_TILED_CLOBBERS);
+            else if constexpr (MODE == 3)
+                asm volatile(ACC_TILED2R_CHUNK_ASM
+                             : [rp] "+s"(rp), [xp] "+s"(xp), [phase] "+s"(phase)
+                             : [ns] "s"(2 * nsets), [q0] "s"(q0), [q1] "s"(q1), [q2] "s"(q2), [q3] "s"(q3), [lane16] "v"(lane16),
                                [voff4] "v"(voff4), [voff8] "v"(voff8)
                              : ACC_TILED_CLOBBERS);
             else
@@ -689,6 +703,8 @@ int k_acc_tiled(hipStream_t s, const DevTiled& S, const double* F, int ldf, doub
                                    hipFuncAttributeMaxDynamicSharedMemorySize, TILED_LDS_BYTES + 512));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&acc_tiled_kernel<4>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, TILED_LDS_BYTES + 512));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&acc_tiled_kernel<3>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, TILED_LDS_BYTES + 512));
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
     const int64_t nwg_x = (S.nwb + TILED_NW - 1) / TILED_NW;
@@ -697,6 +713,10 @@ int k_acc_tiled(hipStream_t s, const DevTiled& S, const double* F, int ldf, doub
     const int64_t n = (int64_t)kf * S.ncol;
     if (S.NSL == 4)
         acc_tiled_kernel<4><<<dim3((unsigned)nwg_x, (unsigned)S.R), dim3(64 * TILED_NW), lds, s>>>(
+            S.roff, xvals ? xvals : S.x, S.cstart, S.cnt, S.T, S.nwb, F, kf, S.TR, S.nrow, S.tiles_per_range, out, S.ncol, KS, ldf,
+            slabs ? kf : ldb, slabs ? n : 0, S.perm, S.range_fastest ? 1 : 0);
+    else if (!getenv("SGL_TILED_PREP"))
+        acc_tiled_kernel<3><<<dim3((unsigned)nwg_x, (unsigned)S.R), dim3(64 * TILED_NW), lds, s>>>(
             S.roff, xvals ? xvals : S.x, S.cstart, S.cnt, S.T, S.nwb, F, kf, S.TR, S.nrow, S.tiles_per_range, out, S.ncol, KS, ldf,
             slabs ? kf : ldb, slabs ? n : 0, S.perm, S.range_fastest ? 1 : 0);
     else

@@ -27,7 +27,7 @@ def tiled_asm(tmp_path_factory):
                     "--cuda-device-only", "-o", out, SRC], check=True, capture_output=True, timeout=600)
     text = open(out).read()
     inst = {}
-    for nsl in (2, 4):   # acc_tiled_kernel<NSL>: pairs (k <= 64) and quads (k <= 32) of columns per LDS instruction
+    for nsl in (2, 3, 4):   # acc_tiled_kernel<MODE>: pairs with prepared sets, pairs on the ring layout, quads (k <= 32)
         m = re.search(r"^(_Z16acc_tiled_kernelILi%dEE\w*):[^\n]*\n(.*?)s_endpgm" % nsl, text, re.S | re.M)
         assert m, "acc_tiled_kernel<%d> not found in the assembly" % nsl
         meta = text[text.index(".amdhsa_kernel " + m.group(1)):]
@@ -43,7 +43,7 @@ def _vregs(line):
     return regs
 
 
-@pytest.mark.parametrize("nsl", [2, 4])
+@pytest.mark.parametrize("nsl", [2, 3, 4])
 def test_compiler_stays_below_v64_and_keeps_scratch_out_of_the_loop(tiled_asm, nsl):
     body, meta = tiled_asm[nsl]
     in_asm, worst = False, -1
@@ -95,11 +95,12 @@ def test_chunk_loop_is_the_generated_asm_with_counted_waits(tiled_asm):
             assert m0 == "0", "VALU with a vector destination while M0 indexes destinations: %s" % l
 
 
-def test_quad_chunk_loop_reads_its_operands_from_the_ring(tiled_asm):
+@pytest.mark.parametrize("mode", [4, 3])
+def test_quad_chunk_loop_reads_its_operands_from_the_ring(tiled_asm, mode):
     """acc_tiled_kernel<4> (ranks up to 32, four columns per LDS instruction): eight ring-slot bodies of two octets, no
     set preparation (no v_mov / v_permlane16_swap: the DPP operands are the ring registers, written by vector loads
     only -- no VALU-write -> DPP-read hazard can exist), counted stream waits, destinations written only with M0 off."""
-    body, _ = tiled_asm[4]
+    body, _ = tiled_asm[mode]   # (mode 3: the pair layout on the same loop, half-set ring slots with doubled lane rows)
     blocks = re.findall(r"#ASMSTART(.*?)#ASMEND", body, re.S)
     chunk = [b for b in blocks if "v_fmac_f64_dpp" in b]
     assert len(chunk) == 1
