@@ -19,8 +19,8 @@ layouts = json.loads(open(bench_json).read().strip().splitlines()[-1])["roofline
 def load(path, counter):
     rows = {}
     for r in csv.DictReader(open(path)):
-        if r["counter"] == counter and r["kernel"].startswith("acc_tiled"):
-            rows[(r["kernel"], int(r["grid_y"]))] = float(r["avg_per_dispatch"]) * 1024.0
+        if r["counter"] == counter and "acc_tiled_kernel" in r["kernel"]:   # (round 4: a template, "void acc_tiled_kernel<3>")
+            rows[("acc_tiled_kernel", int(r["grid_y"]))] = float(r["avg_per_dispatch"]) * 1024.0
     return rows
 
 
@@ -36,6 +36,6 @@ for (kern, gy), v in f.items():
 json.dump({"workload": {"genes": 30000, "cells": 1000000, "k": 50, "inv_density": 20},
            "layout": layouts,
            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python3 bench.py --steps 2 --warmup 1 "
-                     "--no-cpu-baseline`, scripts/prof_r3.sh; per launch of acc_tiled_kernel, averaged over its dispatches",
+                     "--no-cpu-baseline`, scripts/prof_r4.sh; per launch of acc_tiled_kernel, averaged over its dispatches",
            "bytes_per_launch": res}, open(out, "w"), indent=1)
 print(open(out).read())
