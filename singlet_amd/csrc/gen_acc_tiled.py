@@ -361,6 +361,139 @@ class GenPairRing(GenQuad):
             A(f"s_addc_u32 s{S_XP + 1}, s{S_XP + 1}, 0")
 
 
+S_TP = 92            # s[92:93]: next 64-byte block of the schedule table to load (even-aligned pair)
+TAB0, TAB1 = 52, 68  # s[52:67] the running lap's 32 schedule words (u16), s[68:83] the next lap's
+
+
+class GenTab(GenQuad):
+    """Round 4: the column-unit bookkeeping as a SCHEDULE TABLE instead of a countdown.
+
+    The counters say the pass is bound by instruction issue (each SIMD's two waves are "active" 96 % of the time between
+    them; profiles/r4_pmc_sq_*.csv), and 1.35 of the 5.7 instructions per entry pair are scalar: a countdown + branch in
+    front of every group of four entry tuples, M0 written every other group, ~15 instructions per switch of the column
+    unit on a byte queue of group counts.  Now the stream builder writes one u16 per GROUP -- the M0 word of the column
+    unit the group belongs to (0x8000 | 4 * unit: destination-relative index) -- and a group head is ONE instruction,
+        s_bfe_u32 m0, s[TAB0 + g / 2], <16 bits at 16 (g & 1)>
+    with g = 4 d + 2 o + group static in the unrolled lap of 8 ring slots x 2 octets x 2 groups = 32 groups = 64 bytes
+    of table = one s_load_dwordx16.  No countdown, no branch, no switch code.  The next lap's words are loaded a lap
+    ahead into TAB1 and moved down at the wrap of the ring (s_waitcnt lgkmcnt(0) there: SMEM returns out of order, so
+    only a full drain proves it has landed; LDS waits in between stay correct with the scalar load outstanding -- the
+    counter then only over-counts).  A chunk entered at ring slot `phase` loads the lap that contains its first group
+    (table address of the chunk - 8 * phase bytes) and the one behind it.
+
+    pair = True: two columns per LDS instruction (half-set ring slots, doubled lane rows: GenPairRing's loads);
+    pair = False: four (GenQuad's)."""
+
+    def __init__(self, pair):
+        super().__init__()
+        self.pair = pair
+
+    def refill(self, i):
+        if self.pair:
+            GenPairRing.refill(self, i)
+        else:
+            GenQuad.refill(self, i)
+
+    def group_head_tab(self, d, o, g):
+        gi = 4 * d + 2 * o + g
+        self.A(f"s_bfe_u32 m0, s{TAB0 + gi // 2}, {hex((16 * (gi & 1)) | (16 << 16))}")
+
+    def octet(self, d, o, reads):
+        A = self.A
+        x = self.QEX[d]
+        for g in range(2):
+            self.group_head_tab(d, o, g)
+            A(f"s_waitcnt lgkmcnt({4 if reads else 4 - 4 * g})")
+            for j in range(4 * g, 4 * g + 4):
+                bc = f"row_newbcast:{8 * o + j} row_mask:0xf bank_mask:0xf"
+                A(f"v_fmac_f64_dpp {r2(ACC)}, {r2(x)}, {r2(W[j])} {bc}")
+                A(f"v_fmac_f64_dpp {r2(ACC + 2)}, {r2(x)}, {r2(W[j] + 2)} {bc}")
+                if reads:
+                    A(f"ds_read_b128 v[{W[j]}:{W[j] + 3}], v{AD[j]}")
+
+    def body(self, d, L_body, L_exit):
+        A = self.A
+        dn = (d + 1) % self.NS
+        A(f"{L_body[d]}:")
+        A("s_mov_b32 m0, 0")
+        self.addrs(d, 1)
+        self.octet(d, 0, True)
+        L_last, L_done = self.label("last"), self.label("done")
+        A("s_mov_b32 m0, 0")
+        A(f"s_cmp_le_u32 s{S_NS}, 1")
+        A(f"s_cbranch_scc1 {L_last}")
+        A(f"s_waitcnt vmcnt({2 * (self.NS - 2)})")
+        self.addrs(dn, 0)
+        self.octet(d, 1, True)
+        A(f"{L_done}:")
+        hot, self.L = self.L, []
+        A(f"{L_last}:")
+        self.octet(d, 1, False)
+        A(f"s_branch {L_done}")
+        self.cold2 += self.L
+        self.L = hot
+        self.refill(d)
+        A(f"s_sub_u32 s{S_NS}, s{S_NS}, 1")
+        A(f"s_cmp_eq_u32 s{S_NS}, 0")
+        A(f"s_cbranch_scc1 {L_exit[d]}")
+        if d == self.NS - 1:
+            # wrap of the ring = end of a lap of 32 groups: the next lap's schedule words move down, the one behind is fetched
+            A("s_waitcnt lgkmcnt(0)")
+            for w in range(8):
+                A(f"s_mov_b64 s[{TAB0 + 2 * w}:{TAB0 + 2 * w + 1}], s[{TAB1 + 2 * w}:{TAB1 + 2 * w + 1}]")
+            A(f"s_load_dwordx16 s[{TAB1}:{TAB1 + 15}], s[{S_TP}:{S_TP + 1}], 0x0")
+            A(f"s_add_u32 s{S_TP}, s{S_TP}, 64")
+            A(f"s_addc_u32 s{S_TP + 1}, s{S_TP + 1}, 0")
+            A(f"s_branch {L_body[0]}")
+
+    def chunk(self):
+        A = self.A
+        n = self.NS
+        L_body = [self.label(f"b{d}") for d in range(n)]
+        L_pro = [self.label(f"p{d}") for d in range(n)]
+        L_exit = [self.label(f"x{d}") for d in range(n)]
+        L_end = self.label("end")
+        A(f"s_mov_b64 s[{S_RP}:{S_RP + 1}], %[rp]")
+        A(f"s_mov_b64 s[{S_XP}:{S_XP + 1}], %[xp]")
+        A(f"s_mov_b32 s{S_NS}, %[ns]")
+        # schedule words: the lap holding the chunk's first group starts 4 * phase groups = 8 * phase bytes before it
+        A(f"s_lshl_b32 s{S_ACC}, %[phase], 3")
+        A(f"s_mov_b64 s[{S_TP}:{S_TP + 1}], %[tp]")
+        A(f"s_sub_u32 s{S_TP}, s{S_TP}, s{S_ACC}")
+        A(f"s_subb_u32 s{S_TP + 1}, s{S_TP + 1}, 0")
+        A(f"s_load_dwordx16 s[{TAB0}:{TAB0 + 15}], s[{S_TP}:{S_TP + 1}], 0x0")
+        A(f"s_load_dwordx16 s[{TAB1}:{TAB1 + 15}], s[{S_TP}:{S_TP + 1}], 0x40")
+        A(f"s_add_u32 s{S_TP}, s{S_TP}, 128")
+        A(f"s_addc_u32 s{S_TP + 1}, s{S_TP + 1}, 0")
+        A(f"s_mov_b32 s{S_ACC}, 0")
+        A(f"s_set_gpr_idx_on s{S_ACC}, 0")   # index mode on, no operand indexed while M0[15:12] = 0
+        A("s_mov_b32 m0, 0")
+        for d in range(1, n):
+            A(f"s_cmp_eq_u32 %[phase], {d}")
+            A(f"s_cbranch_scc1 {L_pro[d]}")
+        for d in range(n):
+            A(f"{L_pro[d]}:")
+            A(f"s_waitcnt vmcnt({2 * (n - 1)})")
+            self.addrs(d, 0)
+            for j in range(8):
+                A(f"ds_read_b128 v[{W[j]}:{W[j] + 3}], v{AD[j]}")
+            A("s_waitcnt lgkmcnt(0)")        # the schedule words (and the first reads) have landed
+            A(f"s_branch {L_body[d]}")
+        for d in range(n):
+            self.body(d, L_body, L_exit)
+        for d in range(n):
+            A(f"{L_exit[d]}:")
+            A(f"s_mov_b32 %[phase], {(d + 1) % n}")
+            A(f"s_branch {L_end}")
+        self.L += self.cold2
+        A(f"{L_end}:")
+        A("s_waitcnt lgkmcnt(0)")            # a schedule load may still be in flight: its registers are not ours past this block
+        A("s_mov_b32 m0, 0")
+        A("s_set_gpr_idx_off")
+        A(f"s_mov_b64 %[rp], s[{S_RP}:{S_RP + 1}]")
+        A(f"s_mov_b64 %[xp], s[{S_XP}:{S_XP + 1}]")
+
+
 def main():
     out = ["// generated by gen_acc_tiled.py -- do not edit", "#pragma once"]
     g = Gen()
@@ -411,6 +544,14 @@ def main():
     g.A(f"s_mov_b64 %[rp], s[{S_RP}:{S_RP + 1}]")
     g.A(f"s_mov_b64 %[xp], s[{S_XP}:{S_XP + 1}]")
     out.append(f"#define ACC_TILED2R_RING_FILL_ASM \\\n{g.text()}")
+    # ---- schedule-table bookkeeping (default): pairs and quads
+    for tag, pair in (("2T", True), ("4T", False)):
+        out.append("")
+        g = GenTab(pair)
+        g.chunk()
+        out.append(f"#define ACC_TILED{tag}_CHUNK_ASM \\\n{g.text()}")
+    tclob = [f'"s{r}"' for r in range(TAB0, S_Q + 8)] + ['"memory"', '"scc"']
+    out.append("#define ACC_TILEDT_CLOBBERS " + ", ".join(tclob))
     sys.stdout.write("\n".join(out) + "\n")
 
 

@@ -138,6 +138,24 @@ __global__ __launch_bounds__(256) void tiled_fill_kernel(const double* __restric
     }
 }
 
+// schedule table of the chunk loop (gen_acc_tiled.py, GenTab): one u16 per group of four entry tuples, in stream order --
+// the M0 word (destination-relative register index 4 * unit, 0x8000 = VDST_REL) of the column unit the group belongs
+// to; the padding groups at the end of a chunk are booked on the last unit, like their entries.  One wave per chunk.
+__global__ __launch_bounds__(256) void tiled_gtab_kernel(const uint8_t* __restrict__ cnt, const int64_t* __restrict__ cstart,
+                                                         int64_t nchunks, int nsl, uint16_t* __restrict__ gtab) {
+    const int lane = threadIdx.x & 63;
+    const int64_t gw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t u = gw; u < nchunks; u += nw) {
+        int64_t g0 = cstart[u] / (4 * nsl);
+        for (int p = 0; p < TILED_NP; ++p) {
+            const int n = (int)cnt[u * TILED_NP + p];
+            for (int q = lane; q < n; q += 64) gtab[g0 + q] = (uint16_t)(0x8000u | (unsigned)(4 * p));
+            g0 += n;
+        }
+    }
+}
+
 template <typename T_>
 static int t_alloc(T_** p, size_t count) {
     *p = nullptr;
@@ -172,6 +190,7 @@ void sgl_tiled_free(DevTiled& S) {
     if (S.x) (void)hipFree(S.x);
     if (S.cstart) (void)hipFree(S.cstart);
     if (S.cnt) (void)hipFree(S.cnt);
+    if (S.gtab) (void)hipFree(S.gtab);
     if (S.part) (void)hipFree(S.part);
     if (S.xm) (void)hipFree(S.xm);
     S = DevTiled();
@@ -309,6 +328,18 @@ int sgl_tiled_build(sgl_ctx* c, const DevCSC& M, int k, DevTiled& S) {
         tiled_fill_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(M.x, M.i, S.seg, S.perm, M.ncol, S.T, S.nwb, TR, KS * 8,
                                                                        S.cnt, S.cstart, S.roff, S.x, 0, 0, sgl_div_make(1), 0, 0, 0, nsl);
         if (hipGetLastError() != hipSuccess) { sgl_set_error("tiled build: fill kernel launch failed"); rc = SGL_EHIP; }
+    }
+    // the chunk loop's schedule table: E / (4 nsl) groups + slack (a lap of 32 groups is loaded one ahead)
+    const size_t ngroups = (size_t)(E / (4 * nsl));
+    if (rc == SGL_OK) rc = t_reserve(&S.gtab, &S.cap_gtab, ngroups + 256);
+    if (rc == SGL_OK) {
+        if (hipMemsetAsync(S.gtab + ngroups, 0, 256 * sizeof(uint16_t), s) != hipSuccess) { sgl_set_error("tiled build: clearing the schedule slack failed"); rc = SGL_EHIP; }
+    }
+    if (rc == SGL_OK && nchunks > 0) {
+        int64_t blocks = (nchunks + 3) / 4;
+        if (blocks > 256 * 64) blocks = 256 * 64;
+        tiled_gtab_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(S.cnt, S.cstart, nchunks, nsl, S.gtab);
+        if (hipGetLastError() != hipSuccess) { sgl_set_error("tiled build: schedule kernel launch failed"); rc = SGL_EHIP; }
     }
     // split of the tile range over blockIdx.y so that the grid fills 256 CUs (1 workgroup per CU)
     // Two reasons to split: too few column groups to fill the chip (W-update: 30 k genes = 59 workgroups), and -- with
@@ -452,6 +483,7 @@ __device__ __forceinline__ void acc_load(int idx4, double& v0, double& v1) {
 // The chunk loop is the hand-scheduled inline asm of gen_acc_tiled.py (register plan there).  The compiler's budget
 // is v0..v63 (amdgpu_waves_per_eu(8, 8) caps its allocation at 512 / 8 registers); the clobber makes the kernel
 // descriptor allocate all 256: v64..v255 belong to the asm, whose stream ring stays in flight across compiler code.
+// MODE 6 / 7: MODE 3 / 4 with the schedule table instead of the countdown + byte queue (round 4, the default);
 // MODE 2: pairs of columns, sets prepared (rounds 2 - 3; SGL_TILED_PREP=1);  MODE 3: pairs of columns on half-set ring
 // slots loaded with doubled lane rows, no preparation (round 4, the default for ranks 33 - 64);  MODE 4: quads of columns
 template <int MODE>
@@ -459,11 +491,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const uint32_t* __restrict__ sroff, const double* __restrict__ sx, const int64_t* __restrict__ cstart,
     const uint8_t* __restrict__ cnt, int T, int64_t nwb, const double* __restrict__ F, int k, int TR, int64_t nrow,
     int tiles_per_range, double* __restrict__ Bout, int64_t ncol, int KS, int ldf, int ldb, int64_t slab,
-    const int32_t* __restrict__ perm, int range_fastest) {
+    const int32_t* __restrict__ perm, int range_fastest, const uint16_t* __restrict__ gtab) {
     // k = factor rows handled by this launch (a part of the rank when it is above 64), KS = LDS row
     // stride the stream's offsets were built for, ldf / ldb = strides (doubles) between rows of F /
     // columns of the output, slab = doubles between the outputs of two tile ranges (blockIdx.y)
-    constexpr int NSL = MODE == 4 ? 4 : 2;
+    constexpr int NSL = (MODE == 4 || MODE == 7) ? 4 : 2;
+    constexpr bool RING8 = MODE != 2;            // half-set / quad-set ring slots, eight deep
+    constexpr bool PAIRRING = MODE == 3 || MODE == 6;
     asm volatile("" ::: "v255");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* tile = reinterpret_cast<double*>(smem);
@@ -491,7 +525,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const unsigned lane16 = (unsigned)(uintptr_t)(lds_char*)smem + (lane & LMASK) * 16;
     // stream slot this lane loads of a (half) set.  MODE 3: lane rows doubled -- lanes 0-15 and 16-31 the A half's 16
     // entries, lanes 32-47 and 48-63 the B half's (slots 32 ..): the [A A B B] layout the row broadcasts read
-    const unsigned slot = MODE == 3 ? (unsigned)((lane >> 5) * 32 + (lane & 15)) : (unsigned)lane;
+    const unsigned slot = PAIRRING ? (unsigned)((lane >> 5) * 32 + (lane & 15)) : (unsigned)lane;
     const unsigned voff4 = slot * 4, voff8 = slot * 8;
 
     asm volatile(ACC_TILED_ZERO_ASM ::: "memory");
@@ -510,9 +544,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         const uint64_t r_ = reinterpret_cast<uint64_t>(sroff + pos), x_ = reinterpret_cast<uint64_t>(sx + pos);
         rp = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((unsigned)(r_ >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((unsigned)r_);
         xp = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((unsigned)(x_ >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((unsigned)x_);
-        if constexpr (MODE == 4)
+        if constexpr (NSL == 4)
             asm volatile(ACC_TILED4_RING_FILL_ASM : [rp] "+s"(rp), [xp] "+s"(xp) : [voff4] "v"(voff4), [voff8] "v"(voff8) : ACC_TILED_CLOBBERS);
-        else if constexpr (MODE == 3)
+        else if constexpr (PAIRRING)
             asm volatile(ACC_TILED2R_RING_FILL_ASM : [rp] "+s"(rp), [xp] "+s"(xp) : [voff4] "v"(voff4), [voff8] "v"(voff8) : ACC_TILED_CLOBBERS);
         else
             asm volatile(ACC_TILED_RING_FILL_ASM : [rp] "+s"(rp), [xp] "+s"(xp) : [voff4] "v"(voff4), [voff8] "v"(voff8) : ACC_TILED_CLOBBERS);
@@ -527,6 +561,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     for (int t = t0; t < t1; ++t) {
         const uint64_t q0 = qn0, q1 = qn1, q2 = qn2, q3 = qn3;
         const int nsets = (int)((pos_next - pos_cur) >> 6);  // 64-entry sets (32 per half) of this chunk
+        const int64_t pos_chunk = pos_cur;                   // its first entry
         pos_cur = pos_next;
         if (wact && t + 1 < t1) {
             const uint64_t* cq = reinterpret_cast<const uint64_t*>(cnt + (wb * T + t + 1) * TILED_NP);
@@ -635,7 +670,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
         __syncthreads();
         if (wact && nsets > 0) {
-            if constexpr (MODE == 4)
+            if constexpr (MODE == 6 || MODE == 7) {
+                // first schedule word of this chunk (wave-uniform address)
+                const uint64_t t_ = reinterpret_cast<uint64_t>(gtab + pos_chunk / (4 * NSL));
+                const uint64_t tp = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((unsigned)(t_ >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((unsigned)t_);
+                if constexpr (MODE == 6)
+                    asm volatile(ACC_TILED2T_CHUNK_ASM
+                                 : [rp] "+s"(rp), [xp] "+s"(xp), [phase] "+s"(phase)
+                                 : [ns] "s"(2 * nsets), [tp] "s"(tp), [lane16] "v"(lane16), [voff4] "v"(voff4), [voff8] "v"(voff8)
+                                 : ACC_TILEDT_CLOBBERS);
+                else
+                    asm volatile(ACC_TILED4T_CHUNK_ASM
+                                 : [rp] "+s"(rp), [xp] "+s"(xp), [phase] "+s"(phase)
+                                 : [ns] "s"(nsets), [tp] "s"(tp), [lane16] "v"(lane16), [voff4] "v"(voff4), [voff8] "v"(voff8)
+                                 : ACC_TILEDT_CLOBBERS);
+            } else if constexpr (MODE == 4)
                 asm volatile(ACC_TILED4_CHUNK_ASM
                              : [rp] "+s"(rp), [xp] "+s"(xp), [phase] "+s"(phase)
                              : [ns] "s"(nsets), [q0] "s"(q0), [q1] "s"(q1), [q2] "s"(q2), [q3] "s"(q3), [lane16] "v"(lane16),
@@ -705,24 +754,37 @@ int k_acc_tiled(hipStream_t s, const DevTiled& S, const double* F, int ldf, doub
                                    hipFuncAttributeMaxDynamicSharedMemorySize, TILED_LDS_BYTES + 512));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&acc_tiled_kernel<3>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, TILED_LDS_BYTES + 512));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&acc_tiled_kernel<6>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, TILED_LDS_BYTES + 512));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&acc_tiled_kernel<7>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, TILED_LDS_BYTES + 512));
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
     const int64_t nwg_x = (S.nwb + TILED_NW - 1) / TILED_NW;
     const bool slabs = S.R > 1;
     double* out = slabs ? S.part : B;
     const int64_t n = (int64_t)kf * S.ncol;
-    if (S.NSL == 4)
+    const bool table = !getenv("SGL_TILED_NO_TABLE") && !getenv("SGL_TILED_PREP") && S.gtab != nullptr;
+    if (S.NSL == 4 && table)
+        acc_tiled_kernel<7><<<dim3((unsigned)nwg_x, (unsigned)S.R), dim3(64 * TILED_NW), lds, s>>>(
+            S.roff, xvals ? xvals : S.x, S.cstart, S.cnt, S.T, S.nwb, F, kf, S.TR, S.nrow, S.tiles_per_range, out, S.ncol, KS, ldf,
+            slabs ? kf : ldb, slabs ? n : 0, S.perm, S.range_fastest ? 1 : 0, S.gtab);
+    else if (S.NSL == 2 && table)
+        acc_tiled_kernel<6><<<dim3((unsigned)nwg_x, (unsigned)S.R), dim3(64 * TILED_NW), lds, s>>>(
+            S.roff, xvals ? xvals : S.x, S.cstart, S.cnt, S.T, S.nwb, F, kf, S.TR, S.nrow, S.tiles_per_range, out, S.ncol, KS, ldf,
+            slabs ? kf : ldb, slabs ? n : 0, S.perm, S.range_fastest ? 1 : 0, S.gtab);
+    else if (S.NSL == 4)
         acc_tiled_kernel<4><<<dim3((unsigned)nwg_x, (unsigned)S.R), dim3(64 * TILED_NW), lds, s>>>(
             S.roff, xvals ? xvals : S.x, S.cstart, S.cnt, S.T, S.nwb, F, kf, S.TR, S.nrow, S.tiles_per_range, out, S.ncol, KS, ldf,
-            slabs ? kf : ldb, slabs ? n : 0, S.perm, S.range_fastest ? 1 : 0);
+            slabs ? kf : ldb, slabs ? n : 0, S.perm, S.range_fastest ? 1 : 0, S.gtab);
     else if (!getenv("SGL_TILED_PREP"))
         acc_tiled_kernel<3><<<dim3((unsigned)nwg_x, (unsigned)S.R), dim3(64 * TILED_NW), lds, s>>>(
             S.roff, xvals ? xvals : S.x, S.cstart, S.cnt, S.T, S.nwb, F, kf, S.TR, S.nrow, S.tiles_per_range, out, S.ncol, KS, ldf,
-            slabs ? kf : ldb, slabs ? n : 0, S.perm, S.range_fastest ? 1 : 0);
+            slabs ? kf : ldb, slabs ? n : 0, S.perm, S.range_fastest ? 1 : 0, S.gtab);
     else
         acc_tiled_kernel<2><<<dim3((unsigned)nwg_x, (unsigned)S.R), dim3(64 * TILED_NW), lds, s>>>(
             S.roff, xvals ? xvals : S.x, S.cstart, S.cnt, S.T, S.nwb, F, kf, S.TR, S.nrow, S.tiles_per_range, out, S.ncol, KS, ldf,
-            slabs ? kf : ldb, slabs ? n : 0, S.perm, S.range_fastest ? 1 : 0);
+            slabs ? kf : ldb, slabs ? n : 0, S.perm, S.range_fastest ? 1 : 0, S.gtab);
     HIPCHK(hipGetLastError());
     if (slabs) {
         int64_t blocks = (n + 255) / 256;

@@ -51,6 +51,8 @@ struct DevTiled {
     double* x = nullptr;        // value per entry (0 for pads)
     int64_t* cstart = nullptr;  // [nwb * T + 1] first entry of chunk (wb, t)
     uint8_t* cnt = nullptr;     // [nwb * T * CW] 4-entry groups of slot s in chunk (wb, t)
+    uint16_t* gtab = nullptr;   // [E / (4 NSL) + slack] schedule: the M0 word (0x8000 | 4 * column unit) of every group of 4 entry tuples
+    size_t cap_gtab = 0;
     double* part = nullptr;     // [R][k * ncol] partial slabs when the tile range is split
     double* xm = nullptr;       // value per entry with the cross-validation mask applied (0 at drawn entries), per fit
     uint64_t xm_seed = 0, xm_inv = 0;

@@ -27,7 +27,7 @@ def tiled_asm(tmp_path_factory):
                     "--cuda-device-only", "-o", out, SRC], check=True, capture_output=True, timeout=600)
     text = open(out).read()
     inst = {}
-    for nsl in (2, 3, 4):   # acc_tiled_kernel<MODE>: pairs with prepared sets, pairs on the ring layout, quads (k <= 32)
+    for nsl in (2, 3, 4, 6, 7):   # acc_tiled_kernel<MODE>: pairs with prepared sets, pairs on the ring layout, quads (k <= 32); 6 / 7: 3 / 4 with the schedule table
         m = re.search(r"^(_Z16acc_tiled_kernelILi%dEE\w*):[^\n]*\n(.*?)s_endpgm" % nsl, text, re.S | re.M)
         assert m, "acc_tiled_kernel<%d> not found in the assembly" % nsl
         meta = text[text.index(".amdhsa_kernel " + m.group(1)):]
@@ -43,7 +43,7 @@ def _vregs(line):
     return regs
 
 
-@pytest.mark.parametrize("nsl", [2, 3, 4])
+@pytest.mark.parametrize("nsl", [2, 3, 4, 6, 7])
 def test_compiler_stays_below_v64_and_keeps_scratch_out_of_the_loop(tiled_asm, nsl):
     body, meta = tiled_asm[nsl]
     in_asm, worst = False, -1
@@ -128,6 +128,42 @@ def test_quad_chunk_loop_reads_its_operands_from_the_ring(tiled_asm, mode):
             m0 = "cold"
         elif l.startswith("v_add_u32_dpp"):
             assert m0 == "0", "VALU with a vector destination while M0 indexes destinations: %s" % l
+
+
+@pytest.mark.parametrize("mode", [6, 7])
+def test_schedule_table_chunk_loop(tiled_asm, mode):
+    """acc_tiled_kernel<6 / 7> (the default): one s_bfe_u32 m0 per group of four entry tuples out of the 32 schedule words of
+    the running lap, no countdown, no switch code, no branch inside an octet; the next lap's words loaded a lap ahead and
+    waited with a full lgkmcnt drain (SMEM returns out of order); operands straight from the ring."""
+    body, _ = tiled_asm[mode]
+    blocks = re.findall(r"#ASMSTART(.*?)#ASMEND", body, re.S)
+    chunk = [b for b in blocks if "v_fmac_f64_dpp" in b]
+    assert len(chunk) == 1
+    text = chunk[0]
+    assert "v_permlane16_swap" not in text and "v_mov_b32 v" not in text and "v_readlane" not in text
+    assert "vmcnt(0)" not in text
+    assert text.count("v_fmac_f64_dpp") == 8 * (2 + 1) * 16
+    heads = re.findall(r"s_bfe_u32 m0, s(\d+), (0x[0-9a-f]+)", text)
+    assert len(heads) == 8 * (2 + 1) * 2                     # one per group; the last-octet copies included
+    hot = [(int(r), int(f, 16)) for r, f in heads[:0]]
+    seen = {(int(r), int(f, 16)) for r, f in heads}
+    assert seen == {(52 + g // 2, (16 * (g & 1)) | (16 << 16)) for g in range(32)}   # every group of the lap, static
+    assert text.count("s_load_dwordx16") == 3                # chunk entry (2) + the wrap of the ring (1)
+    assert "s_sub_u32 s89" not in text and ".Ltiled_sw" not in text   # no group countdown, no switch code
+    # between a group head and the end of its four tuples nothing but the wait, the FMAs and their reads
+    for m in re.finditer(r"s_bfe_u32 m0[^\n]*\n(.*?)(?=s_bfe_u32 m0|s_mov_b32 m0, 0|s_branch|\Z)", text, re.S):
+        for l in (x.strip().strip('"').strip() for x in m.group(1).splitlines()):
+            if l and not l.endswith(":"):
+                assert l.startswith(("s_waitcnt lgkmcnt", "v_fmac_f64_dpp", "ds_read_b128", "global_load", "s_add", "s_addc", "s_sub_u32 s88", "s_cmp", "s_cbranch", "s_waitcnt vmcnt", "s_mov_b64 s[", "s_load_dwordx16")), l
+    hot_txt = text[:text.index("s_set_gpr_idx_off")]
+    m0 = None
+    for l in (x.strip() for x in hot_txt.splitlines()):
+        if l.startswith("s_mov_b32 m0"):
+            m0 = "0"
+        elif l.startswith("s_bfe_u32 m0"):
+            m0 = "idx"
+        elif l.startswith("v_add_u32_dpp"):
+            assert m0 == "0", "address add while M0 indexes destinations: %s" % l
 
 
 def _dst_src0(code):
