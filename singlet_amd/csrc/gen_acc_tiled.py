@@ -411,51 +411,59 @@ class GenTab(GenQuad):
                 if reads:
                     A(f"ds_read_b128 v[{W[j]}:{W[j] + 3}], v{AD[j]}")
 
-    def body(self, d, L_body, L_exit):
+    def wrap(self):
+        """wrap of the ring = end of a lap of 32 groups: the next lap's schedule words move down, the one behind is fetched"""
+        A = self.A
+        A("s_waitcnt lgkmcnt(0)")
+        for w in range(8):
+            A(f"s_mov_b64 s[{TAB0 + 2 * w}:{TAB0 + 2 * w + 1}], s[{TAB1 + 2 * w}:{TAB1 + 2 * w + 1}]")
+        A(f"s_load_dwordx16 s[{TAB1}:{TAB1 + 15}], s[{S_TP}:{S_TP + 1}], 0x0")
+        A(f"s_add_u32 s{S_TP}, s{S_TP}, 64")
+        A(f"s_addc_u32 s{S_TP + 1}, s{S_TP + 1}, 0")
+
+    def body(self, d, L_body, L_last):
+        """a half-set that is NOT the chunk's last one: both octets fetch ahead; s[S_NS] counts the fetching half-sets still to
+        come and its borrow sends the flow to the last half-set's own code (no test inside the body)"""
         A = self.A
         dn = (d + 1) % self.NS
         A(f"{L_body[d]}:")
         A("s_mov_b32 m0, 0")
         self.addrs(d, 1)
         self.octet(d, 0, True)
-        L_last, L_done = self.label("last"), self.label("done")
         A("s_mov_b32 m0, 0")
-        A(f"s_cmp_le_u32 s{S_NS}, 1")
-        A(f"s_cbranch_scc1 {L_last}")
         A(f"s_waitcnt vmcnt({2 * (self.NS - 2)})")
         self.addrs(dn, 0)
         self.octet(d, 1, True)
-        A(f"{L_done}:")
-        hot, self.L = self.L, []
-        A(f"{L_last}:")
-        self.octet(d, 1, False)
-        A(f"s_branch {L_done}")
-        self.cold2 += self.L
-        self.L = hot
         self.refill(d)
-        A(f"s_sub_u32 s{S_NS}, s{S_NS}, 1")
-        A(f"s_cmp_eq_u32 s{S_NS}, 0")
-        A(f"s_cbranch_scc1 {L_exit[d]}")
         if d == self.NS - 1:
-            # wrap of the ring = end of a lap of 32 groups: the next lap's schedule words move down, the one behind is fetched
-            A("s_waitcnt lgkmcnt(0)")
-            for w in range(8):
-                A(f"s_mov_b64 s[{TAB0 + 2 * w}:{TAB0 + 2 * w + 1}], s[{TAB1 + 2 * w}:{TAB1 + 2 * w + 1}]")
-            A(f"s_load_dwordx16 s[{TAB1}:{TAB1 + 15}], s[{S_TP}:{S_TP + 1}], 0x0")
-            A(f"s_add_u32 s{S_TP}, s{S_TP}, 64")
-            A(f"s_addc_u32 s{S_TP + 1}, s{S_TP + 1}, 0")
+            self.wrap()
+        A(f"s_sub_u32 s{S_NS}, s{S_NS}, 1")
+        A(f"s_cbranch_scc1 {L_last[dn]}")
+        if d == self.NS - 1:
             A(f"s_branch {L_body[0]}")
+
+    def last(self, d, L_last, L_end):
+        """the chunk's last half-set at ring slot d: nothing of the next chunk is fetched (another tile will be in LDS)"""
+        A = self.A
+        A(f"{L_last[d]}:")
+        A("s_mov_b32 m0, 0")
+        self.addrs(d, 1)
+        self.octet(d, 0, True)
+        self.octet(d, 1, False)
+        self.refill(d)
+        A(f"s_mov_b32 %[phase], {(d + 1) % self.NS}")
+        A(f"s_branch {L_end}")
 
     def chunk(self):
         A = self.A
         n = self.NS
         L_body = [self.label(f"b{d}") for d in range(n)]
         L_pro = [self.label(f"p{d}") for d in range(n)]
-        L_exit = [self.label(f"x{d}") for d in range(n)]
+        L_last = [self.label(f"last{d}") for d in range(n)]
         L_end = self.label("end")
         A(f"s_mov_b64 s[{S_RP}:{S_RP + 1}], %[rp]")
         A(f"s_mov_b64 s[{S_XP}:{S_XP + 1}], %[xp]")
-        A(f"s_mov_b32 s{S_NS}, %[ns]")
+        A(f"s_sub_u32 s{S_NS}, %[ns], 2")    # fetching half-sets behind the first: ns - 2 more borrows later (ns = 1: straight to `last`)
         # schedule words: the lap holding the chunk's first group starts 4 * phase groups = 8 * phase bytes before it
         A(f"s_lshl_b32 s{S_ACC}, %[phase], 3")
         A(f"s_mov_b64 s[{S_TP}:{S_TP + 1}], %[tp]")
@@ -478,14 +486,13 @@ class GenTab(GenQuad):
             for j in range(8):
                 A(f"ds_read_b128 v[{W[j]}:{W[j] + 3}], v{AD[j]}")
             A("s_waitcnt lgkmcnt(0)")        # the schedule words (and the first reads) have landed
+            A(f"s_cmp_eq_u32 %[ns], 1")
+            A(f"s_cbranch_scc1 {L_last[d]}")
             A(f"s_branch {L_body[d]}")
         for d in range(n):
-            self.body(d, L_body, L_exit)
+            self.body(d, L_body, L_last)
         for d in range(n):
-            A(f"{L_exit[d]}:")
-            A(f"s_mov_b32 %[phase], {(d + 1) % n}")
-            A(f"s_branch {L_end}")
-        self.L += self.cold2
+            self.last(d, L_last, L_end)
         A(f"{L_end}:")
         A("s_waitcnt lgkmcnt(0)")            # a schedule load may still be in flight: its registers are not ours past this block
         A("s_mov_b32 m0, 0")

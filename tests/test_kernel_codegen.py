@@ -142,9 +142,9 @@ def test_schedule_table_chunk_loop(tiled_asm, mode):
     text = chunk[0]
     assert "v_permlane16_swap" not in text and "v_mov_b32 v" not in text and "v_readlane" not in text
     assert "vmcnt(0)" not in text
-    assert text.count("v_fmac_f64_dpp") == 8 * (2 + 1) * 16
+    assert text.count("v_fmac_f64_dpp") == 8 * (2 + 2) * 16      # eight bodies + eight copies for a chunk's last half-set
     heads = re.findall(r"s_bfe_u32 m0, s(\d+), (0x[0-9a-f]+)", text)
-    assert len(heads) == 8 * (2 + 1) * 2                     # one per group; the last-octet copies included
+    assert len(heads) == 8 * (2 + 2) * 2                     # one per group; the last half-sets' copies included
     hot = [(int(r), int(f, 16)) for r, f in heads[:0]]
     seen = {(int(r), int(f, 16)) for r, f in heads}
     assert seen == {(52 + g // 2, (16 * (g & 1)) | (16 << 16)) for g in range(32)}   # every group of the lap, static
@@ -154,7 +154,7 @@ def test_schedule_table_chunk_loop(tiled_asm, mode):
     for m in re.finditer(r"s_bfe_u32 m0[^\n]*\n(.*?)(?=s_bfe_u32 m0|s_mov_b32 m0, 0|s_branch|\Z)", text, re.S):
         for l in (x.strip().strip('"').strip() for x in m.group(1).splitlines()):
             if l and not l.endswith(":"):
-                assert l.startswith(("s_waitcnt lgkmcnt", "v_fmac_f64_dpp", "ds_read_b128", "global_load", "s_add", "s_addc", "s_sub_u32 s88", "s_cmp", "s_cbranch", "s_waitcnt vmcnt", "s_mov_b64 s[", "s_load_dwordx16")), l
+                assert l.startswith(("s_waitcnt lgkmcnt", "v_fmac_f64_dpp", "ds_read_b128", "global_load", "s_add", "s_addc", "s_sub_u32 s88", "s_cmp", "s_cbranch", "s_waitcnt vmcnt", "s_mov_b64 s[", "s_load_dwordx16", "s_mov_b32 %", "s_mov_b32 s")), l
     hot_txt = text[:text.index("s_set_gpr_idx_off")]
     m0 = None
     for l in (x.strip() for x in hot_txt.splitlines()):
