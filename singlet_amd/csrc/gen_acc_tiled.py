@@ -25,6 +25,7 @@ Register plan (asm-owned; the compiler is capped at v0..v63 by amdgpu_waves_per_
     s[84:85] / s[86:87] next set to load (row offsets / values), s88 sets left, s89 groups left of the running
     pair, s90 running pair, s91 its M0 word, s[92:99] the chunk's group counts
 """
+import os
 import sys
 
 ER = [64 + i for i in range(4)]
@@ -394,6 +395,11 @@ class GenTab(GenQuad):
         else:
             GenQuad.refill(self, i)
 
+    def addrs(self, slot, o):
+        if "noadd" in os.environ.get("SGL_GEN_ABLATE", ""):
+            return
+        GenQuad.addrs(self, slot, o)
+
     def group_head_tab(self, d, o, g):
         gi = 4 * d + 2 * o + g
         self.A(f"s_bfe_u32 m0, s{TAB0 + gi // 2}, {hex((16 * (gi & 1)) | (16 << 16))}")
@@ -401,14 +407,16 @@ class GenTab(GenQuad):
     def octet(self, d, o, reads):
         A = self.A
         x = self.QEX[d]
+        abl = os.environ.get("SGL_GEN_ABLATE", "")   # timing ablations only (results are wrong): nofma, noread, noadd
         for g in range(2):
             self.group_head_tab(d, o, g)
             A(f"s_waitcnt lgkmcnt({4 if reads else 4 - 4 * g})")
             for j in range(4 * g, 4 * g + 4):
                 bc = f"row_newbcast:{8 * o + j} row_mask:0xf bank_mask:0xf"
-                A(f"v_fmac_f64_dpp {r2(ACC)}, {r2(x)}, {r2(W[j])} {bc}")
-                A(f"v_fmac_f64_dpp {r2(ACC + 2)}, {r2(x)}, {r2(W[j] + 2)} {bc}")
-                if reads:
+                if "nofma" not in abl:
+                    A(f"v_fmac_f64_dpp {r2(ACC)}, {r2(x)}, {r2(W[j])} {bc}")
+                    A(f"v_fmac_f64_dpp {r2(ACC + 2)}, {r2(x)}, {r2(W[j] + 2)} {bc}")
+                if reads and "noread" not in abl:
                     A(f"ds_read_b128 v[{W[j]}:{W[j] + 3}], v{AD[j]}")
 
     def wrap(self):
