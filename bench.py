@@ -262,22 +262,25 @@ def report(args, run):
     staged_bytes = 8 * k * nrows_dom * ((lay["col_blocks"] + 7) // 8)
     traffic = measured_traffic(args, world, dom, lay) if args.data == "iid" else None
     # Why 0.60 of the HBM peak is out of reach for this formulation in FP64 at k = 50 (DESIGN.md "The sparse update
-    # against its rooflines"): every entry pair costs one ds_read_b128 (the LDS retires one wave instruction per
-    # 1.76 ns per CU whatever its width) and 2 FP64 FMAs + 1 address add; micro-benchmark rates of this part,
-    # applied to THIS run's stored entry pairs on 256 CUs
-    # entries served by one LDS instruction: two columns (ranks 33 - 64), four up to rank 32 (quad layout, round 4)
+    # against its rooflines"): every entry tuple (2 entries; 4 at ranks up to 32) costs one ds_read_b128 -- 4.1 LDS cycles
+    # per CU by SQ_LDS_IDX_ACTIVE / SQ_INSTS_LDS, the chip at ~2.05 GHz inside this kernel -- one broadcast address add and
+    # two FP64 FMAs (4 cycles each per SIMD).  Round-4 ablations of the full problem (profiles/README.md): the loop without
+    # its FMAs 8.35 ms, without its LDS reads 8.38 ms, complete 10.57 ms per pass.
     nsl = 4 if (k <= 32 and not os.environ.get("SGL_TILED_NO_QUAD")) else 2
-    pairs = lay["entries"] / float(nsl)
+    tuples = lay["entries"] / float(nsl)
+    clk = 2.05e9
     ceiling = {"columns_per_lds_instruction": nsl,
-               "lds_floor_ms": pairs * 1.76e-9 / 256 * 1e3, "loop_floor_ms": pairs * (153e-9 / 64) / 256 * 1e3,
+               "lds_floor_ms": tuples * 4.1 / clk / 256 * 1e3,
+               "fp64_fma_floor_ms": tuples * 2 * 4.0 / clk / 1024 * 1e3,
+               "valu_floor_ms": tuples * 3 * 4.0 / clk / 1024 * 1e3,
+               "loop_floor_ms": tuples * 2.35e-9 / 256 * 1e3,
                "hbm_floor_ms": dom_bytes / (HBM_PEAK_GBS * 1e9) * 1e3,
-               "fp64_fma_floor_ms": lay["entries"] * 4.9 / 2.4e9 / 1024 * 1e3,
-               "source": "scripts/ubench/lds_rate, valu_rate, mix3 (profiles/r2_acc_tiled_tuning.md): 1.76 ns per LDS "
-                         "wave-instruction per CU; 153 ns per round of 8 waves x 8 entry pairs for the complete 64-entry set "
-                         "loop; 4.9 cycles per v_fmac_f64 wave-instruction per SIMD",
-               "note": "the kernel is bound by LDS operand delivery + FP64 issue, not by HBM: the frac below cannot exceed "
-                       "hbm_floor_ms / loop_floor_ms with one LDS read per entry pair"}
-    ceiling["max_frac_of_this_formulation"] = (ceiling["hbm_floor_ms"] / ceiling["loop_floor_ms"]) if pairs > 0 else None
+               "source": "profiles/r4_pmc_sq_insts.csv, r4_pmc_sq_cycles.csv (4.1 LDS cycles per ds_read_b128, ~2.05 GHz, 4 cycles per "
+                         "VALU instruction) and the round-4 ablations in profiles/README.md: 2.35 ns per entry tuple per CU for the loop "
+                         "with either its FMAs or its LDS reads removed",
+               "note": "the kernel is bound by LDS operand delivery and FP64 issue, which overlap incompletely at two waves per "
+                       "SIMD, not by HBM: the frac below cannot exceed hbm_floor_ms / loop_floor_ms with one LDS read per entry tuple"}
+    ceiling["max_frac_of_this_formulation"] = (ceiling["hbm_floor_ms"] / ceiling["loop_floor_ms"]) if tuples > 0 else None
     comm = run["comm"]
     default_shape = (args.genes, args.cells, args.k, args.inv_density) == (30000, 1000000, 50, 20)
     out = {
