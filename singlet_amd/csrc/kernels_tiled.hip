@@ -401,7 +401,32 @@ int sgl_tiled_build(sgl_ctx* c, const DevCSC& M, int k, DevTiled& S) {
     S.range_fastest = r_bal > r_fill;
     S.R = std::max(1, std::min(R, std::max(1, S.T)));   // range y = tiles [y T / R, (y + 1) T / R): none empty
     S.tiles_per_range = (S.T + S.R - 1) / S.R;
+    // Tail split (round 4).  With enough column groups to fill the chip the range stays whole (R = 1), but the workgroups then
+    // run in rounds of 256: config 3's H side has 1954 of them = 7.63 rounds -- the last round keeps 37 % of the CUs idle for a
+    // whole workgroup's 74 tiles (4.6 % of the pass).  Only the workgroups of that last, partly filled round get their tile
+    // range cut into tail_R pieces (dispatched last: blockIdx.x ascends), so that the pieces fill whole rounds of their own;
+    // only their columns go through slabs.  Same cost model as above.
+    S.tail_wg0 = -1;
+    S.tail_R = 1;
+    if (S.R == 1 && !S.range_fastest && nwg_x > 256 && S.T > 1 && E >= (4ll << 20) && !getenv("SGL_TILED_NO_TAIL")) {
+        const int64_t tail = nwg_x % 256;
+        if (tail > 0) {
+            const double t_tile = (double)E / (double)nsl / ((double)nwg_x * (double)S.T) * 2.4e-9 + 2.5e-6;
+            const double t_wg = 6e-6;
+            const double tail_cols = (double)tail * TILED_NW * S.CW;
+            double best = (double)S.T * t_tile + t_wg;   // left whole: one more round of full length
+            int Rt = 1;
+            for (int r = 2; r <= std::min<int64_t>(S.T, 16); ++r) {
+                const double rounds = ceil((double)tail * r / 256.0);
+                const double cost = rounds * ((double)((S.T + r - 1) / r) * t_tile + t_wg) + (double)r * (double)k * tail_cols * 16.0 / 4e12;
+                if (cost < best * (1.0 - 1e-9)) { best = cost; Rt = r; }
+            }
+            if (Rt > 1) { S.tail_wg0 = nwg_x - tail; S.tail_R = Rt; }
+        }
+    }
     if (rc == SGL_OK && S.R > 1) rc = t_reserve(&S.part, &S.cap_part, (size_t)S.R * (size_t)k * (size_t)M.ncol);
+    if (rc == SGL_OK && S.tail_R > 1)
+        rc = t_reserve(&S.part, &S.cap_part, (size_t)S.tail_R * (size_t)k * (size_t)((nwg_x - S.tail_wg0) * TILED_NW * S.CW));
     hipError_t e = hipStreamSynchronize(s);
     if (chunk_entries) (void)hipFree(chunk_entries);
     if (rc == SGL_OK && e != hipSuccess) { sgl_set_error("tiled build failed: %s", hipGetErrorString(e)); rc = SGL_EHIP; }
@@ -491,7 +516,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const uint32_t* __restrict__ sroff, const double* __restrict__ sx, const int64_t* __restrict__ cstart,
     const uint8_t* __restrict__ cnt, int T, int64_t nwb, const double* __restrict__ F, int k, int TR, int64_t nrow,
     int tiles_per_range, double* __restrict__ Bout, int64_t ncol, int KS, int ldf, int ldb, int64_t slab,
-    const int32_t* __restrict__ perm, int range_fastest, const uint16_t* __restrict__ gtab) {
+    const int32_t* __restrict__ perm, int range_fastest, const uint16_t* __restrict__ gtab, int tail_wg0, int tail_R,
+    double* __restrict__ tail_part, int64_t tail_slab) {
     // k = factor rows handled by this launch (a part of the rank when it is above 64), KS = LDS row
     // stride the stream's offsets were built for, ldf / ldb = strides (doubles) between rows of F /
     // columns of the output, slab = doubles between the outputs of two tile ranges (blockIdx.y)
@@ -513,9 +539,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         bx = unit / nranges;
         by = unit - bx * nranges;
     }
+    // tail split: the workgroups of the last, partly filled round of 256 come as tail_R pieces each (x = tail_wg0 + u)
+    unsigned nry = gridDim.y;
+    bool tail_piece = false;
+    if (tail_R > 1 && (int)bx >= tail_wg0) {
+        const unsigned u = bx - (unsigned)tail_wg0;
+        bx = (unsigned)tail_wg0 + u / (unsigned)tail_R;
+        by = u % (unsigned)tail_R;
+        nry = (unsigned)tail_R;
+        tail_piece = true;
+    }
     const int64_t wb = (int64_t)bx * TILED_NW + wave;
-    // tile range `by` of gridDim.y: sizes floor / ceil of T / ranges (tiles_per_range = the ceil, kept for the layout query)
-    const unsigned nry = gridDim.y;
+    // tile range `by` of nry: sizes floor / ceil of T / ranges (tiles_per_range = the ceil, kept for the layout query)
     const int t0 = (int)(((int64_t)by * T) / nry);
     const int t1 = (int)((((int64_t)by + 1) * T) / nry);
     const bool wact = wb < nwb;
@@ -710,13 +745,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     if (wact) {
         double* out = Bout + (size_t)by * (size_t)slab;
         const int f = 2 * (lane & LMASK);
+        const int64_t tail_pos0 = (int64_t)tail_wg0 * TILED_NW * (TILED_NP * NSL);
         for (int p = 0; p < TILED_NP; ++p) {
             double v0, v1;
             acc_load(4 * p, v0, v1);
-            const int64_t col = tiled_slot_col(perm, ncol, wb, NSL == 4 ? (lane >> 4) : (lane >> 5), p, NSL);
+            const int h = NSL == 4 ? (lane >> 4) : (lane >> 5);
+            const int64_t col = tiled_slot_col(perm, ncol, wb, h, p, NSL);
             if (col >= 0) {
-                if (f < k) out[col * ldb + f] = v0;
-                if (f + 1 < k) out[col * ldb + f + 1] = v1;
+                if (tail_piece) {   // compact slab of this piece, indexed by the column's position in the stream's order
+                    const int64_t pos = wb * (TILED_NP * NSL) + NSL * p + h;
+                    double* o = tail_part + (size_t)by * (size_t)tail_slab + (pos - tail_pos0) * k;
+                    if (f < k) o[f] = v0;
+                    if (f + 1 < k) o[f + 1] = v1;
+                } else {
+                    if (f < k) out[col * ldb + f] = v0;
+                    if (f + 1 < k) out[col * ldb + f + 1] = v1;
+                }
             }
         }
     }
@@ -733,6 +777,19 @@ __global__ void acc_tiled_reduce_kernel(const double* __restrict__ part, int R, 
             const int64_t col = e / k;
             B[col * ldb + (e - col * k)] = s;
         }
+    }
+}
+
+// tail split: B[col(pos) * ldb + f] = sum over the pieces' compact slabs, in piece order, for the stream positions pos >= pos0
+__global__ void acc_tiled_reduce_tail_kernel(const double* __restrict__ part, int R, int64_t slab, int64_t pos0, int64_t ncol,
+                                             const int32_t* __restrict__ perm, int k, int ldb, double* __restrict__ B) {
+    const int64_t n = (ncol - pos0) * k;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        double s = part[e];
+        for (int r = 1; r < R; ++r) s += part[(size_t)r * slab + e];
+        const int64_t q = e / k;
+        const int64_t col = perm ? (int64_t)perm[pos0 + q] : pos0 + q;
+        B[col * ldb + (e - q * k)] = s;
     }
 }
 
@@ -764,28 +821,34 @@ int k_acc_tiled(hipStream_t s, const DevTiled& S, const double* F, int ldf, doub
     const bool slabs = S.R > 1;
     double* out = slabs ? S.part : B;
     const int64_t n = (int64_t)kf * S.ncol;
+    const bool tail = !slabs && S.tail_R > 1 && S.tail_wg0 >= 0;
+    const int64_t tail_cols = tail ? (nwg_x - S.tail_wg0) * TILED_NW * S.CW : 0;
+    const int64_t tail_slab = tail_cols * kf;
+    const dim3 grid(tail ? (unsigned)(S.tail_wg0 + (nwg_x - S.tail_wg0) * S.tail_R) : (unsigned)nwg_x, (unsigned)S.R);
     const bool table = !getenv("SGL_TILED_NO_TABLE") && !getenv("SGL_TILED_PREP") && S.gtab != nullptr;
-    if (S.NSL == 4 && table)
-        acc_tiled_kernel<7><<<dim3((unsigned)nwg_x, (unsigned)S.R), dim3(64 * TILED_NW), lds, s>>>(
+    auto launch = [&](auto mode) {
+        constexpr int MODE = decltype(mode)::value;
+        acc_tiled_kernel<MODE><<<grid, dim3(64 * TILED_NW), lds, s>>>(
             S.roff, xvals ? xvals : S.x, S.cstart, S.cnt, S.T, S.nwb, F, kf, S.TR, S.nrow, S.tiles_per_range, out, S.ncol, KS, ldf,
-            slabs ? kf : ldb, slabs ? n : 0, S.perm, S.range_fastest ? 1 : 0, S.gtab);
-    else if (S.NSL == 2 && table)
-        acc_tiled_kernel<6><<<dim3((unsigned)nwg_x, (unsigned)S.R), dim3(64 * TILED_NW), lds, s>>>(
-            S.roff, xvals ? xvals : S.x, S.cstart, S.cnt, S.T, S.nwb, F, kf, S.TR, S.nrow, S.tiles_per_range, out, S.ncol, KS, ldf,
-            slabs ? kf : ldb, slabs ? n : 0, S.perm, S.range_fastest ? 1 : 0, S.gtab);
-    else if (S.NSL == 4)
-        acc_tiled_kernel<4><<<dim3((unsigned)nwg_x, (unsigned)S.R), dim3(64 * TILED_NW), lds, s>>>(
-            S.roff, xvals ? xvals : S.x, S.cstart, S.cnt, S.T, S.nwb, F, kf, S.TR, S.nrow, S.tiles_per_range, out, S.ncol, KS, ldf,
-            slabs ? kf : ldb, slabs ? n : 0, S.perm, S.range_fastest ? 1 : 0, S.gtab);
-    else if (!getenv("SGL_TILED_PREP"))
-        acc_tiled_kernel<3><<<dim3((unsigned)nwg_x, (unsigned)S.R), dim3(64 * TILED_NW), lds, s>>>(
-            S.roff, xvals ? xvals : S.x, S.cstart, S.cnt, S.T, S.nwb, F, kf, S.TR, S.nrow, S.tiles_per_range, out, S.ncol, KS, ldf,
-            slabs ? kf : ldb, slabs ? n : 0, S.perm, S.range_fastest ? 1 : 0, S.gtab);
-    else
-        acc_tiled_kernel<2><<<dim3((unsigned)nwg_x, (unsigned)S.R), dim3(64 * TILED_NW), lds, s>>>(
-            S.roff, xvals ? xvals : S.x, S.cstart, S.cnt, S.T, S.nwb, F, kf, S.TR, S.nrow, S.tiles_per_range, out, S.ncol, KS, ldf,
-            slabs ? kf : ldb, slabs ? n : 0, S.perm, S.range_fastest ? 1 : 0, S.gtab);
+            slabs ? kf : ldb, slabs ? n : 0, S.perm, S.range_fastest ? 1 : 0, S.gtab, tail ? (int)S.tail_wg0 : -1, tail ? S.tail_R : 1,
+            S.part, tail_slab);
+    };
+    if (S.NSL == 4 && table) launch(std::integral_constant<int, 7>());
+    else if (S.NSL == 2 && table) launch(std::integral_constant<int, 6>());
+    else if (S.NSL == 4) launch(std::integral_constant<int, 4>());
+    else if (!getenv("SGL_TILED_PREP")) launch(std::integral_constant<int, 3>());
+    else launch(std::integral_constant<int, 2>());
     HIPCHK(hipGetLastError());
+    if (tail) {
+        const int64_t pos0 = S.tail_wg0 * TILED_NW * S.CW;
+        const int64_t ne = (S.ncol - pos0) * kf;
+        if (ne > 0) {
+            int64_t blocks = (ne + 255) / 256;
+            if (blocks > 4096) blocks = 4096;
+            acc_tiled_reduce_tail_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(S.part, S.tail_R, tail_slab, pos0, S.ncol, S.perm, kf, ldb, B);
+            HIPCHK(hipGetLastError());
+        }
+    }
     if (slabs) {
         int64_t blocks = (n + 255) / 256;
         if (blocks > 4096) blocks = 4096;

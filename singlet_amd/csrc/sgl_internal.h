@@ -71,6 +71,8 @@ struct DevTiled {
     bool built = false;
     int64_t src_nnz = -1;
     int32_t TR = 0, T = 0, CW = 0, k = 0, R = 1, tiles_per_range = 0;
+    int64_t tail_wg0 = -1;      // tail split (R == 1): first workgroup (x) of the last, partly filled round of 256 (-1: none)
+    int32_t tail_R = 1;         //   its workgroups' tile ranges are cut into this many pieces (own slabs, summed in order)
     int32_t NSL = 2;            // column slots per LDS instruction: 2 (pairs, k <= 64) or 4 (quads, k <= 32); CW = 32 * NSL
     int32_t KS = 0;             // LDS row stride in doubles the row offsets were built for
     int64_t nwb = 0, E = 0, ncol = 0, nrow = 0;

@@ -193,6 +193,36 @@ def test_rhs_tiled_quad_layout_equals_the_pair_layout(sa, ora, k, monkeypatch):
     assert lay[True]["A"]["tile_rows"] == 632 and lay[True]["A"]["tiles"] == 4
 
 
+@pytest.mark.parametrize("k", [12, 50, 70])
+def test_rhs_tiled_tail_split(sa, ora, k, monkeypatch):
+    """More than 256 column groups: the workgroups run in rounds of 256 and only those of the last, partly filled round
+    have their tile range cut into pieces (own compact slabs, summed in piece order).  140 000 cells x 2500 genes: 274 (137
+    at k <= 32) groups of 512 (1024) columns; with and without the tail split (SGL_TILED_NO_TAIL) the sums agree to rounding,
+    and both with the oracle."""
+    A = ora.synth_csc(2500, 280000 if k <= 32 else 140000, 20)
+    rng = np.random.default_rng(k)
+    W = rng.random((A.nrow, k))
+    out = {}
+    monkeypatch.setenv("SGL_TILED_RANGES", "1")   # (below 1024 groups the uniform split would be chosen: keep the range whole)
+    for tail in (True, False):
+        if tail:
+            monkeypatch.delenv("SGL_TILED_NO_TAIL", raising=False)
+        else:
+            monkeypatch.setenv("SGL_TILED_NO_TAIL", "1")
+        c = sa.Context(0)
+        try:
+            c.upload(to_dgc(sa, A), None)
+            out[tail] = c.op_rhs(2, W)
+        finally:
+            c.close()
+    assert not np.array_equal(out[True], out[False])          # the split really ran (its columns are summed in another order)
+    assert rel_fro(out[True], out[False]) < 1e-14
+    sel = np.r_[0:300, A.ncol - 300:A.ncol]
+    sub = ora.CSC(np.concatenate([A.x[A.p[c]:A.p[c + 1]] for c in sel]), np.concatenate([A.i[A.p[c]:A.p[c + 1]] for c in sel]),
+                  np.concatenate([[0], np.cumsum([A.p[c + 1] - A.p[c] for c in sel])]), A.nrow, len(sel))
+    assert rel_fro(out[True][sel], ora.rhs(sub, W)) < 1e-14
+
+
 @pytest.mark.parametrize("k,ranges", [(10, 3), (30, 4), (50, 2), (50, 5)])
 def test_rhs_tiled_split_tile_ranges(sa, ora, k, ranges, monkeypatch):
     """The tile range cut over blockIdx.y (what fills the chip when the columns are few: the W side of every config):
