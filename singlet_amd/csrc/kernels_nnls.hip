@@ -87,11 +87,85 @@ void nnls_scratch_free(NnlsScratch& sc) {
     if (sc.it_state) (void)hipFree(sc.it_state);
     if (sc.tol_state) (void)hipFree(sc.tol_state);
     if (sc.xt) (void)hipFree(sc.xt);
+    if (sc.prev_it) (void)hipFree(sc.prev_it);
+    if (sc.packed) (void)hipFree(sc.packed);
+    if (sc.sort_ws) (void)hipFree(sc.sort_ws);
     sc = NnlsScratch();
 }
 
+// ---- packing by sweep count -------------------------------------------------------------------------------------
+// Lanes of a wave run in lock-step, so a wave executes its slowest column's sweeps: 35 at config 3 (with the re-packing
+// passes) where the columns need 27 - 29.  How many sweeps a column needs carries over from one ALS iteration to the
+// next (correlation 0.57 - 0.79 on the oracle's counts), so the first pass takes the columns in DESCENDING order of the
+// sweeps their previous solve needed (nnls_lane_kernel writes them to prev_it): neighbours in that order share a wave.
+// A column's own arithmetic does not depend on where it is packed: bit-identical.  Counting sort on the device, three
+// small kernels per solve (keys 0 .. 100 in a byte; the order inside a key is whatever the atomics give).
+#define SGL_PACK_BINS 128
+#define SGL_PACK_CPB 2048   // columns per block
+__global__ __launch_bounds__(256) void nnls_pack_hist_kernel(const uint8_t* __restrict__ key, int64_t n, int nblocks, uint32_t* __restrict__ hist) {
+    __shared__ unsigned h[SGL_PACK_BINS];
+    if (threadIdx.x < SGL_PACK_BINS) h[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t c0 = (int64_t)blockIdx.x * SGL_PACK_CPB;
+    for (int q = threadIdx.x; q < SGL_PACK_CPB; q += 256) {
+        const int64_t c = c0 + q;
+        if (c < n) atomicAdd(&h[key[c] & (SGL_PACK_BINS - 1)], 1u);
+    }
+    __syncthreads();
+    // bin-major, longest first: entry (bin b, block) at [(BINS - 1 - b) * nblocks + block]
+    if (threadIdx.x < SGL_PACK_BINS) hist[(size_t)(SGL_PACK_BINS - 1 - threadIdx.x) * nblocks + blockIdx.x] = h[threadIdx.x];
+}
+// exclusive scan of the BINS * nblocks counts in place (one workgroup; <= 128 * 512 entries at a million columns)
+__global__ __launch_bounds__(1024) void nnls_pack_scan_kernel(uint32_t* __restrict__ hist, int total, uint32_t* __restrict__ n_out) {
+    __shared__ unsigned part[1024];
+    const int per = (total + 1023) / 1024;
+    const int a = threadIdx.x * per, b = (a + per < total) ? a + per : total;
+    unsigned s = 0;
+    for (int e = a; e < b; ++e) s += hist[e];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const unsigned v = (threadIdx.x >= (unsigned)off) ? part[threadIdx.x - off] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    unsigned run = part[threadIdx.x] - s;
+    for (int e = a; e < b; ++e) { const unsigned c = hist[e]; hist[e] = run; run += c; }
+    if (threadIdx.x == 1023) *n_out = part[1023];
+}
+__global__ __launch_bounds__(256) void nnls_pack_scatter_kernel(const uint8_t* __restrict__ key, int64_t n, int nblocks,
+                                                                const uint32_t* __restrict__ offs, int32_t* __restrict__ packed) {
+    __shared__ unsigned cur[SGL_PACK_BINS];
+    if (threadIdx.x < SGL_PACK_BINS) cur[threadIdx.x] = offs[(size_t)(SGL_PACK_BINS - 1 - threadIdx.x) * nblocks + blockIdx.x];
+    __syncthreads();
+    const int64_t c0 = (int64_t)blockIdx.x * SGL_PACK_CPB;
+    for (int q = threadIdx.x; q < SGL_PACK_CPB; q += 256) {
+        const int64_t c = c0 + q;
+        if (c < n) packed[atomicAdd(&cur[key[c] & (SGL_PACK_BINS - 1)], 1u)] = (int32_t)c;
+    }
+}
+
+int nnls_pack_alloc(NnlsScratch& sc, int64_t ncols) {
+    if (sc.prev_it && sc.pack_cap >= ncols) return SGL_OK;
+    if (sc.prev_it) (void)hipFree(sc.prev_it);
+    if (sc.packed) (void)hipFree(sc.packed);
+    if (sc.sort_ws) (void)hipFree(sc.sort_ws);
+    sc.prev_it = nullptr; sc.packed = nullptr; sc.sort_ws = nullptr; sc.pack_cap = 0;
+    const int64_t nblocks = (ncols + SGL_PACK_CPB - 1) / SGL_PACK_CPB;
+    if (hipMalloc(&sc.prev_it, (size_t)ncols) != hipSuccess || hipMalloc(&sc.packed, sizeof(int32_t) * (size_t)ncols) != hipSuccess ||
+        hipMalloc(&sc.sort_ws, sizeof(uint32_t) * ((size_t)SGL_PACK_BINS * nblocks + 4)) != hipSuccess ||
+        hipMemset(sc.prev_it, 0, (size_t)ncols) != hipSuccess) {
+        (void)hipGetLastError();
+        sgl_set_error("NNLS packing scratch: out of device memory");
+        return SGL_ENOMEM;
+    }
+    sc.pack_cap = ncols;
+    return SGL_OK;
+}
+
 int k_nnls_lane(hipStream_t s, const double* Gpad, int KP, double* B, double* X, const int64_t* col_nnz, int k,
-                int64_t ncols, double L1, double L2, unsigned long long* sweep_counter, const NnlsScratch* scr) {
+                int64_t ncols, double L1, double L2, unsigned long long* sweep_counter, const NnlsScratch* scr, bool pack_by_sweeps) {
     if (ncols <= 0) return SGL_OK;
     auto launch_lane = (KP <= 40) ? k_nnls_lane_launch1 : (KP <= 64 ? k_nnls_lane_launch2 : (KP <= 104 ? k_nnls_lane_launch3 : k_nnls_lane_launch4));
     const bool half = nnls_use_half(KP);
@@ -107,8 +181,24 @@ int k_nnls_lane(hipStream_t s, const double* Gpad, int KP, double* B, double* X,
     double* xt = nnls_needs_xt(KP) ? scr->xt : nullptr;
     const dim3 g((unsigned)((ncols + 255) / 256)), b(256);
     const bool repack = scr != nullptr && scr->list[0] != nullptr && scr->cap >= ncols && ncols >= nnls_repack_min_cols();
+    // first pass in descending order of the previous solve's sweep counts (lane instances up to k = 64; SGL_NNLS_NO_PACK: A/B)
+    const bool pack = pack_by_sweeps && !half && scr != nullptr && scr->prev_it != nullptr && scr->pack_cap >= ncols && ncols >= 65536 &&
+                      !getenv("SGL_NNLS_NO_PACK");
+    const int32_t* list0 = nullptr;
+    const uint32_t* count0 = nullptr;
+    if (pack) {
+        const int nblocks = (int)((ncols + SGL_PACK_CPB - 1) / SGL_PACK_CPB);
+        uint32_t* n_dev = scr->sort_ws + (size_t)SGL_PACK_BINS * nblocks;
+        nnls_pack_hist_kernel<<<dim3((unsigned)nblocks), dim3(256), 0, s>>>(scr->prev_it, ncols, nblocks, scr->sort_ws);
+        nnls_pack_scan_kernel<<<dim3(1), dim3(1024), 0, s>>>(scr->sort_ws, SGL_PACK_BINS * nblocks, n_dev);
+        nnls_pack_scatter_kernel<<<dim3((unsigned)nblocks), dim3(256), 0, s>>>(scr->prev_it, ncols, nblocks, scr->sort_ws, scr->packed);
+        HIPCHK(hipGetLastError());
+        list0 = scr->packed;
+        count0 = n_dev;   // = ncols
+    }
+    uint8_t* prev_it = pack_by_sweeps && !half && scr != nullptr && scr->prev_it != nullptr && scr->pack_cap >= ncols ? scr->prev_it : nullptr;
     if (!repack) {
-        const NnlsPass one = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, xt, ncols};
+        const NnlsPass one = {list0, count0, nullptr, nullptr, nullptr, nullptr, 0, xt, ncols, 1, prev_it};
         SGLCHK(launch(s, Gpad, KP, B, X, col_nnz, k, ncols, L1, L2, sweep_counter, one, g, b));
         HIPCHK(hipGetLastError());
         return SGL_OK;
@@ -120,8 +210,10 @@ int k_nnls_lane(hipStream_t s, const double* Gpad, int KP, double* B, double* X,
     for (int p = 0; p < SGL_NNLS_MAX_PASSES; ++p) {
         const bool last = (p == SGL_NNLS_MAX_PASSES - 1);
         NnlsPass ps;
-        ps.list = p ? scr->list[(p - 1) & 1] : nullptr;
-        ps.count = p ? scr->counts + p : nullptr;
+        ps.list = p ? scr->list[(p - 1) & 1] : list0;
+        ps.count = p ? scr->counts + p : count0;
+        ps.fresh = p ? 0 : 1;
+        ps.prev_it = prev_it;
         ps.next_list = last ? nullptr : scr->list[p & 1];
         ps.next_count = last ? nullptr : scr->counts + p + 1;
         ps.it_state = scr->it_state;

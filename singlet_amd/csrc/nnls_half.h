@@ -87,7 +87,8 @@ __global__ __launch_bounds__(KH > 52 ? 256 : 512) __attribute__((amdgpu_waves_pe
     const int64_t gid = (int64_t)blockIdx.x * cpb + (threadIdx.x >> 6) * 32 + (lane & 31);   // position in this pass
     const bool in_range = gid < n_in;
     const int64_t col = in_range ? (ps.list ? (int64_t)ps.list[gid] : gid) : 0;
-    const bool valid = in_range && (ps.list != nullptr || col_nnz == nullptr || col_nnz[col] != 0);
+    const bool resume = ps.list != nullptr && !ps.fresh;
+    const bool valid = in_range && (resume || col_nnz == nullptr || col_nnz[col] != 0);
     const bool to_end = (ps.next_list == nullptr) || n_in <= (int64_t)ps.final_below;
     constexpr int KLOW = KP - 7;   // coordinates below it always exist (an instance serves KP - 7 <= k <= KP)
     int one = 1;
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(KH > 52 ? 256 : 512) __attribute__((amdgpu_waves_pe
     const double kd = (double)k;
     double tol = 1.0;
     int it = 0;
-    if (valid && ps.list != nullptr) {
+    if (valid && resume) {
         tol = ps.tol_state[col];
         it = (int)ps.it_state[col];
     }

@@ -74,7 +74,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SGL_NNLS_WP
     const bool in_range = gid < n_in;
     const int64_t col = in_range ? (ps.list ? (int64_t)ps.list[gid] : gid) : 0;
     // empty columns are skipped and keep their stale values (src/singlet.cpp:340)
-    const bool valid = in_range && (ps.list != nullptr || col_nnz == nullptr || col_nnz[col] != 0);
+    const bool resume = ps.list != nullptr && !ps.fresh;   // a later pass: the column's state was saved by the previous one
+    const bool valid = in_range && (resume || col_nnz == nullptr || col_nnz[col] != 0);
     const bool to_end = (ps.next_list == nullptr) || n_in <= (int64_t)ps.final_below;
     constexpr int PF = XM ? 2 : 4;   // coordinates of x read ahead (XM)
     // An instance serves KP - 1 <= k <= KP (KP - 7 <= k above 64): for the coordinates below KLOW the run-time test
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SGL_NNLS_WP
     const double kd = (double)k;
     double tol = 1.0;
     int it = 0;
-    if (valid && ps.list != nullptr) {
+    if (valid && resume) {
         tol = ps.tol_state[col];
         it = (int)ps.it_state[col];
     }
@@ -232,6 +233,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SGL_NNLS_WP
         ps.tol_state[col] = tol;
         ps.it_state[col] = (uint8_t)it;
     }
+    if (valid && !unfinished && ps.prev_it != nullptr) ps.prev_it[col] = (uint8_t)it;   // packing key of the next solve
     const unsigned long long um = __ballot(unfinished);
     if (um != 0ull) {  // wave-aggregated append
         const int lane = threadIdx.x & 63;

@@ -95,6 +95,8 @@ struct NnlsPass {
     int32_t final_below;  // a pass over at most this many columns runs them to the end
     double* xt;           // k > 64: scratch holding x, xt[i * xt_stride + position in this pass]
     int64_t xt_stride;
+    int32_t fresh;        // list != nullptr but nothing to resume: a first pass over columns given in packing order (below)
+    uint8_t* prev_it;     // sweeps a column needed, written when it stops: the packing key of the NEXT solve (nullptr: not kept)
 };
 // device scratch of the multi-pass solve, sized for `cap` columns (owned by the caller)
 struct NnlsScratch {
@@ -104,6 +106,12 @@ struct NnlsScratch {
     double* tol_state = nullptr;
     double* xt = nullptr;         // k x cap doubles when the fit's rank is above 64
     int64_t cap = 0;
+    // packing by sweep count (H side of a plain fit): per column the sweeps of the previous solve, the columns in descending
+    // order of it, and the counting sort's workspace
+    uint8_t* prev_it = nullptr;
+    int32_t* packed = nullptr;
+    uint32_t* sort_ws = nullptr;  // [128 * nblocks + 2]
+    int64_t pack_cap = 0;
 };
 
 // The cross-validation mask of one orientation as lists: idx[ptr[c] .. ptr[c + 1]) = the rows r (ascending) with
@@ -181,7 +189,7 @@ struct sgl_ctx {
 int sgl_team_size(const sgl_ctx* c);   // 1 without a team
 // internals of singlet_hip.hip used by multi.hip
 int sgl_nnls_shared(sgl_ctx* c, const double* G, double* B, double* X, const int64_t* col_nnz, int64_t ncols,
-                    double L1, double L2, unsigned long long* counter);
+                    double L1, double L2, unsigned long long* counter, bool h_side = false);
 int sgl_scale_w_enqueue(sgl_ctx* c);            // scale(w, d); cor(w, w_prev) -> device scalar
 int sgl_scale_w_fetch(sgl_ctx* c, double* tol); // copy it out (synchronises the stream)
 int sgl_fetch_sweeps(sgl_ctx* c);
@@ -278,7 +286,9 @@ int nnls_scratch_alloc(NnlsScratch& sc, int64_t cap, int k_for_xt);
 void nnls_scratch_free(NnlsScratch& sc);
 // B is destroyed (and used as the spill space of b between passes).  scr == nullptr: one pass.
 int k_nnls_lane(hipStream_t s, const double* Gpad, int KP, double* B, double* X, const int64_t* col_nnz,
-                int k, int64_t ncols, double L1, double L2, unsigned long long* sweep_counter, const NnlsScratch* scr);
+                int k, int64_t ncols, double L1, double L2, unsigned long long* sweep_counter, const NnlsScratch* scr,
+                bool pack_by_sweeps = false);
+int nnls_pack_alloc(NnlsScratch& sc, int64_t ncols);
 int k_nnls_wave(hipStream_t s, const double* G, int64_t gstride, const double* B, double* X, const int64_t* col_nnz,
                 int k, int64_t ncols, double L1, double L2, unsigned long long* sweep_counter);
 

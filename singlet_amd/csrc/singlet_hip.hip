@@ -651,6 +651,7 @@ static int fit_init_impl(sgl_ctx* c, int32_t k, const double* w_init, uint64_t s
     {
         const int64_t cap = std::max<int64_t>(c->A.ncol, c->A.nrow);
         if (k <= SGL_LANE_NNLS_MAX_K) SGLCHK(nnls_scratch_alloc(c->nnls_scr, cap, k));
+        if (k <= 64 && c->A.ncol >= 65536) SGLCHK(nnls_pack_alloc(c->nnls_scr, c->A.ncol));   // sweep-count packing of the H-side solve
     }
     HIPCHK(hipMemsetAsync(c->W, 0, sizeof(double) * ((size_t)k * mpad + 2), c->stream));
     HIPCHK(hipMemsetAsync(c->red, 0, sizeof(double) * ((size_t)k * mpad + (size_t)k * k + (size_t)k), c->stream));
@@ -726,12 +727,13 @@ static int gene_counts(sgl_ctx* c, const int64_t** out) {
 
 // NNLS dispatch for a Gram shared by all columns.
 int sgl_nnls_shared(sgl_ctx* c, const double* G, double* B, double* X, const int64_t* col_nnz, int64_t ncols,
-                       double L1, double L2, unsigned long long* counter) {
+                       double L1, double L2, unsigned long long* counter, bool h_side) {
     const int k = c->k;
     if (k <= SGL_LANE_NNLS_MAX_K) {
         const int KP = lane_kp(k);
         SGLCHK(k_pad_gram(c->stream, G, k, KP, nnls_gram_stride(KP), c->Gpad));
-        return k_nnls_lane(c->stream, c->Gpad, KP, B, X, col_nnz, k, ncols, L1, L2, counter, &c->nnls_scr);
+        // the H side of a plain fit packs its waves by the sweep counts of the previous iteration (kernels_nnls.hip)
+        return k_nnls_lane(c->stream, c->Gpad, KP, B, X, col_nnz, k, ncols, L1, L2, counter, &c->nnls_scr, h_side && ncols == c->A.ncol);
     }
     return k_nnls_wave(c->stream, G, 0, B, X, col_nnz, k, ncols, L1, L2, counter);
 }
@@ -754,7 +756,7 @@ extern "C" int sgl_step_h(sgl_ctx* c, double L1, double L2) {
       else SGLCHK(k_acc(c->stream, c->A, c->W, k, c->B, 0, 1, 0, 0, 0));
       if (c->link_h) SGLCHK(k_link_mul(c->stream, c->B, c->link_h, k, c->link_h_rows, c->A.ncol)); }  // predict_link l.429-430
     { Phase ph(c, SGL_PH_NNLS_H);
-      SGLCHK(sgl_nnls_shared(c, c->G, c->B, c->H, c->solve_empty ? nullptr : c->col_nnz_A, c->A.ncol, L1, L2, c->sweep_counters + 0)); }
+      SGLCHK(sgl_nnls_shared(c, c->G, c->B, c->H, c->solve_empty ? nullptr : c->col_nnz_A, c->A.ncol, L1, L2, c->sweep_counters + 0, true)); }
     return SGL_OK;
 }
 

@@ -570,3 +570,39 @@ def test_edge_arguments(sa, ora, ctx):
     bad.i[s0], bad.i[s0 + 1] = A.i[s0 + 1], A.i[s0]    # not ascending inside the first column
     with pytest.raises(sa.SingletHipError):
         sa.c_nmf(bad, None, 0.0, 1, False, 0.0, 0.0, 0.0, 0.0, 0, w0.T)
+
+
+def test_nnls_packing_by_sweep_counts_is_bit_identical(sa, monkeypatch):
+    """From the second iteration on the H-side solve takes its columns in descending order of the sweeps their previous
+    solve needed (neighbours share a wave: less lock-step waste).  A column's arithmetic does not depend on its lane: the
+    factors, tol trace and sweep totals are those of the unpacked solve, bit for bit (70 000 cells: above the packing
+    threshold; with and without the re-packing passes)."""
+    genes, cells, k = 1500, 70000, 24
+    runs = {}
+    for repack in ("0", "32768"):
+        for pack in (True, False):
+            if pack:
+                monkeypatch.delenv("SGL_NNLS_NO_PACK", raising=False)
+            else:
+                monkeypatch.setenv("SGL_NNLS_NO_PACK", "1")
+            if repack == "0":
+                monkeypatch.delenv("SGL_NNLS_REPACK_MIN_COLS", raising=False)
+            else:
+                monkeypatch.setenv("SGL_NNLS_REPACK_MIN_COLS", repack)
+            c = sa.Context(0)
+            try:
+                c.synth(genes, cells, 20)
+                c.fit_init(k, None)
+                c.sweeps_get(reset=True)
+                it, tols = c.nmf_run(0.0, 4, 0.01, 0.01, 0.0, 0.0)
+                sw = c.sweeps_get(reset=True)
+                runs[(repack, pack)] = (c.get_factors(), tols, sw["h_sweeps"], sw["w_sweeps"], sw["h_wave_sweeps"])
+            finally:
+                c.close()
+    ref = runs[("0", False)]
+    for key, r in runs.items():
+        for a, b in zip(r[0], ref[0]):
+            assert np.array_equal(a, b), key
+        assert np.array_equal(r[1], ref[1]) and r[2] == ref[2] and r[3] == ref[3], key
+    # the packed solve executes fewer wave-sweeps than the unpacked one (that is its point)
+    assert runs[("0", True)][4] < runs[("0", False)][4]
