@@ -58,8 +58,12 @@ def test_config3_h_and_w_update_slices_equal_the_oracle(full, ora):
     # columns outside the slices are sane too
     assert np.all(np.isfinite(H)) and np.all(H >= 0)
     full.step_scale_h()                                               # scale(h, d)  (:651)
-    _, _, Hs = full.get_factors(w=False, d=False)
+    _, dh, Hs = full.get_factors(w=False)
     assert np.abs(Hs.sum(axis=0) - 1.0).max() < 1e-9
+    # d = rowsums over all 10^6 cells (+ 1e-15), h /= d: against the host's sums of the unscaled h (:219-225)
+    d_host = H.sum(axis=0) + 1e-15
+    assert rel_fro(dh, d_host) < 1e-12
+    assert rel_fro(Hs[:4096], H[:4096] / d_host) < 1e-12 and rel_fro(Hs[-4096:], H[-4096:] / d_host) < 1e-12
     full.step_w(L1, 0.0)                                              # w = predict(At, h, w)  (:654), warm start w0
     W1, _, _ = full.get_factors(h=False)
     groups, cnt = _gene_picks(full)
@@ -70,6 +74,13 @@ def test_config3_h_and_w_update_slices_equal_the_oracle(full, ora):
         got = W1[genes]
         assert rel_fro(got, ref) < 1e-9, (genes, rel_fro(got, ref))
         assert same_zero_pattern(got, ref), genes
+    # scale(w, d); tol = cor(w, w_it)  (:655-659): the oracle's scale and one-pass cor on the downloaded, unscaled w
+    tol = full.step_scale_w()
+    W2, dw, _ = full.get_factors(h=False)
+    Ws, d_ref = ora.scale(W1)
+    assert rel_fro(dw, d_ref) < 1e-12 and rel_fro(W2, Ws) < 1e-12
+    tol_ref = ora.cor(Ws, W0)
+    assert abs(tol - tol_ref) <= 1e-8 * abs(tol_ref), (tol, tol_ref)
 
 
 @pytest.mark.parametrize("k,width", [(50, 256), (100, 128)])
