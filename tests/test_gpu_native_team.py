@@ -175,3 +175,47 @@ def test_sharded_masked_overfit_break_and_rccl_team_of_one(sa, ora):
             r = M.ard_run(0.0, 30, 0.0, 0.0, 5, 10, 1e-5, 1)
         assert list(r["iter"]) == list(one["iter"]) and rel_fro(r["test_mse"], one["test_mse"]) < 1e-10
         assert rel_fro(r["score_overfit"], one["score_overfit"]) < 1e-6
+
+
+@pytest.mark.parametrize("masked", [False, True])
+def test_threaded_and_serial_team_drives_are_bit_identical(sa, ora, masked, monkeypatch):
+    """sgl_multi_* drives its ranks from one host thread per device (round 4; the default) or, with SGL_MULTI_SERIAL=1,
+    from the calling thread with grouped collectives (rounds 2 - 3): same kernels, same exchange, same sums in the same
+    order -- the factors and traces must agree bit for bit, plain and masked, here with three ranks on one device."""
+    m, n, k = 180, 700, 12
+    A = to_dgc(sa, ora.synth_csc(m, n, 10))
+    w0 = ora.synth_winit(k, m)
+    out = {}
+    for serial in (False, True):
+        if serial:
+            monkeypatch.setenv("SGL_MULTI_SERIAL", "1")
+        else:
+            monkeypatch.delenv("SGL_MULTI_SERIAL", raising=False)
+        with sa.Multi([0, 0, 0]) as M:
+            M.upload(A)
+            M.fit_init(k, w0)
+            if masked:
+                r = M.ard_run(0.0, 4, 0.01, 0.0, 99, 8, 1e9, 2)
+                trace = (r["test_mse"], r["tol"], r["iter"])
+            else:
+                it, tols = M.nmf_run(0.0, 4, 0.01, 0.01, 0.0, 0.0)
+                trace = (tols,)
+            out[serial] = (M.get_factors(), trace)
+    for a, b in zip(out[False][0], out[True][0]):
+        assert np.array_equal(a, b)
+    for a, b in zip(out[False][1], out[True][1]):
+        assert np.array_equal(a, b)
+
+
+def test_team_error_reaches_the_caller_from_a_worker_thread(sa, ora):
+    """A failure inside a rank's worker thread (here: a rank above the library's limit, refused by every rank) comes back
+    as the call's error with the rank's message, and the team stays usable."""
+    A = to_dgc(sa, ora.synth_csc(120, 300, 10))
+    with sa.Multi([0, 0]) as M:
+        M.upload(A)
+        with pytest.raises(sa.SingletHipError) as e:
+            M.fit_init(2000, None)
+        assert "unsupported" in str(e.value) or "rank" in str(e.value)
+        M.fit_init(6, ora.synth_winit(6, 120))
+        it, tols = M.nmf_run(0.0, 2, 0.01, 0.01, 0.0, 0.0)
+        assert it == 2 and np.all(np.isfinite(tols))
