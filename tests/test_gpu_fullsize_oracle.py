@@ -38,10 +38,12 @@ def _gene_picks(ctx):
     return groups, cnt
 
 
-def test_config3_h_and_w_update_slices_equal_the_oracle(full, ora):
-    """One H-update and one W-update of c_nmf at k = 50 on the resident config-3 matrix: 3 x 512 cells of h and 7
-    genes of w (first, last, heaviest, lightest) against ora.predict on the regenerated slices."""
-    k, width = 50, 512
+@pytest.mark.parametrize("k", [50, 20])
+def test_config3_h_and_w_update_slices_equal_the_oracle(full, ora, k):
+    """One H-update and one W-update of c_nmf at k = 50 (and k = 20: the four-columns-per-LDS-instruction stream with its
+    tile-range split at this size) on the resident config-3 matrix: 3 x 512 cells of h and 7 genes of w (first, last,
+    heaviest, lightest) against ora.predict on the regenerated slices."""
+    width = 512
     full.fit_init(k, None)
     W0 = ora.synth_winit(k, GENES)
     Wdev, _, _ = full.get_factors(h=False)
@@ -83,7 +85,7 @@ def test_config3_h_and_w_update_slices_equal_the_oracle(full, ora):
     assert abs(tol - tol_ref) <= 1e-8 * abs(tol_ref), (tol, tol_ref)
 
 
-@pytest.mark.parametrize("k,width", [(50, 256), (100, 128)])
+@pytest.mark.parametrize("k,width", [(50, 256), (100, 128), (10, 256)])
 def test_config5_masked_h_and_w_update_slices_equal_the_oracle(full, ora, k, width):
     """The masked half-iterations of c_ard_nmf (predict_mask, :436-466) at k = 50 and k = 100 on the config-5 matrix:
     slices of h with the global cell index in the hash, whole gene columns of w (mask_t = true: draw(cell, gene))."""
