@@ -219,3 +219,28 @@ def test_team_error_reaches_the_caller_from_a_worker_thread(sa, ora):
         M.fit_init(6, ora.synth_winit(6, 120))
         it, tols = M.nmf_run(0.0, 2, 0.01, 0.01, 0.0, 0.0)
         assert it == 2 and np.all(np.isfinite(tols))
+
+
+@pytest.mark.parametrize("argv,mode,n", [(["--gpus", "4", "--loopback"], "loopback", 4),
+                                          (["--gpus", "1", "--single-process"], "native-single-process", 1)])
+def test_bench_launcher_free_forms_print_one_json_line(argv, mode, n):
+    """`python bench.py --gpus N` without a launcher is the library's one-process team: run it end to end on a small
+    shape (all ranks on device 0, or the RCCL team of one) and hold the JSON line to the bench contract's keys."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + argv +
+                       ["--genes", "3000", "--cells", "40000", "--k", "12", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "comm"):
+        assert key in d, key
+    assert d["n_gpus"] == n and d["steps"] == 3 and d["comm"]["mode"] == mode and d["value"] > 0
+    assert d.get("loopback", False) == (mode == "loopback")
+    if mode == "native-single-process":
+        assert d["comm"]["rccl_nranks"] == 1
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(d["roofline"])
