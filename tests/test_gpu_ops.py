@@ -589,3 +589,57 @@ def test_mse_test_op(sa, ora, k, use_lists, monkeypatch):
     assert abs(one - exp) <= 1e-11 * abs(exp), (one, exp)
     two = shard(0, 200) + shard(200, n)
     assert abs(two - exp) <= 1e-11 * abs(exp), (two, exp)
+
+
+def _random_csc(ora, rng, m, n, style):
+    """random sparse matrices with awkward columns: empty ones, single entries, dense runs, heavy tails"""
+    if style == "uniform":
+        cnt = rng.binomial(m, min(1.0, rng.uniform(0.002, 0.3)), n)
+    elif style == "heavy":
+        cnt = np.minimum((rng.lognormal(np.log(max(m * 0.02, 1.0)), 1.5, n)).astype(np.int64), m)
+    elif style == "mostly_empty":
+        cnt = np.where(rng.random(n) < 0.85, 0, rng.integers(1, max(2, m // 3), n))
+    else:   # "extremes": empty, one entry, full columns side by side
+        cnt = rng.choice([0, 1, 2, m // 2, m], size=n)
+    xs, is_, p = [], [], [0]
+    for c in range(n):
+        r = np.sort(rng.choice(m, size=int(min(cnt[c], m)), replace=False))
+        is_.append(r)
+        xs.append(rng.random(r.size) + 0.25)
+        p.append(p[-1] + r.size)
+    return ora.CSC(np.concatenate(xs) if xs else np.zeros(0), (np.concatenate(is_) if is_ else np.zeros(0)).astype(np.int32),
+                   np.array(p, dtype=np.int32), m, n)
+
+
+@pytest.mark.parametrize("case", range(96))
+def test_rhs_tiled_random_structures(sa, ora, case, monkeypatch):
+    """Randomised shapes against the plain kernel and the oracle: ranks on both sides of every layout boundary (16 / 17, 32 / 33,
+    64 / 65, 128), row counts around the tile sizes (408, 632, 984 rows), column counts around the wave-block sizes (64, 128,
+    512, 1024), empty / single-entry / full columns, whole range and forced tile-range splits.  Whole range: bit-equal to the
+    plain kernel (same products in the same order); split: equal to rounding."""
+    rng = np.random.default_rng(1000 + case)
+    k = int(rng.choice([1, 2, 3, 8, 15, 16, 17, 24, 31, 32, 33, 40, 50, 63, 64, 65, 96, 128]))
+    m = int(rng.choice([1, 7, 63, 407, 408, 409, 631, 632, 633, 983, 985, 1300, 2100]))
+    n = int(rng.choice([1, 5, 63, 64, 65, 127, 128, 129, 511, 513, 1025, 1500]))
+    style = ["uniform", "heavy", "mostly_empty", "extremes"][case % 4]
+    ranges = int(rng.choice([0, 0, 1, 2, 3]))
+    if ranges:
+        monkeypatch.setenv("SGL_TILED_RANGES", str(ranges))
+    A = _random_csc(ora, rng, m, n, style)
+    if A.nnz == 0:
+        A = _random_csc(ora, rng, m, n, "uniform")
+    At = A.t()
+    W, H = rng.random((m, k)), rng.random((n, k))
+    c = sa.Context(0)
+    try:
+        c.upload(to_dgc(sa, A), to_dgc(sa, At))
+        res = [(c.op_rhs(2, W), c.op_rhs(0, W), ora.rhs(A, W)), (c.op_rhs(3, H), c.op_rhs(1, H), ora.rhs(At, H))]
+    finally:
+        c.close()
+    for got, plain, want in res:
+        assert np.all(np.isfinite(got))
+        assert rel_fro(got, want) < 1e-13, (k, m, n, style, ranges)
+        if k <= 64 and ranges <= 1:
+            assert np.array_equal(got, plain), (k, m, n, style, ranges)
+        else:
+            assert rel_fro(got, plain) < 1e-13
