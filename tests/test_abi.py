@@ -90,3 +90,21 @@ def test_backend_r_rebinds_every_symbol_the_shim_registers():
         formals = [a.strip() for a in m.group(1).split(",")]
         passed = [a.strip() for a in m.group(2).split(",")]
         assert len(formals) == arity and passed == formals, (sym, arity, formals, passed)
+
+
+def test_reference_build_products_stay_out_of_history():
+    """oracle/_ref/ (the reference's `rng` class cut out of the reference tree at build time, and its build) is a build
+    product: git-ignored, never committed; only the recipe (make_ref.sh), the shim and the fixture it generated are."""
+    import subprocess
+    tracked = subprocess.run(["git", "-C", ROOT, "ls-files", "oracle/_ref"], capture_output=True, text=True)
+    if tracked.returncode != 0:
+        pytest.skip("not a git checkout")
+    assert tracked.stdout.strip() == ""
+    ign = open(os.path.join(ROOT, ".gitignore")).read()
+    assert "oracle/_ref/" in ign
+    assert not os.path.exists(os.path.join(ROOT, ".gpurunignore")) or "oracle/_ref" not in open(os.path.join(ROOT, ".gpurunignore")).read()
+    for f in ("oracle/make_ref.sh", "oracle/ref_rng_shim.cpp", "tests/golden/make_rng_ref.py", "tests/golden/rng_ref.npz"):
+        assert os.path.exists(os.path.join(ROOT, f)), f
+    # the shim holds no reference text: it includes the extracted class
+    shim = open(os.path.join(ROOT, "oracle", "ref_rng_shim.cpp")).read()
+    assert '#include "_ref/rng_class.inc"' in shim and "class rng" not in shim
