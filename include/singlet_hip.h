@@ -473,6 +473,9 @@ SGL_API int sgl_sweeps_get(sgl_ctx* ctx, int64_t* out4, int reset);
  * ranges R (blockIdx.y slabs), column blocks of 64.  out10 all zero when the
  * fit runs on the plain CSC kernel (k > 128). */
 SGL_API int sgl_layout_get(sgl_ctx* ctx, int64_t* out10);
+/* How many times the entry stream of each orientation (A, At) has been written on this context: a fit at an
+ * unchanged rank on an unchanged matrix reuses the stream (sgl_fit_init above) and leaves the counts as they are. */
+SGL_API int sgl_layout_builds(sgl_ctx* ctx, int64_t* out2);
 
 #ifdef __cplusplus
 }

@@ -133,6 +133,7 @@ SIGNATURES = {
     "sgl_timing_get": (C.c_int, [C.c_void_p, f64p, i64p, C.c_int]),
     "sgl_sweeps_get": (C.c_int, [C.c_void_p, i64p, C.c_int]),
     "sgl_layout_get": (C.c_int, [C.c_void_p, i64p]),
+    "sgl_layout_builds": (C.c_int, [C.c_void_p, i64p]),
 }
 
 _lib = None

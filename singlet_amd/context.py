@@ -382,6 +382,12 @@ class Context:
         keys = ("entries", "tiles", "tile_rows", "tile_ranges", "col_blocks")
         return {name: dict(zip(keys, (int(v) for v in out[5 * o:5 * o + 5]))) for o, name in enumerate(("A", "At"))}
 
+    def layout_builds(self):
+        """(A, At): times each entry stream has been written on this context (a re-init at an unchanged rank adds none)."""
+        out = np.zeros(2, dtype=np.int64)
+        check(self._L.sgl_layout_builds(self._h, ptr(out, i64p)))
+        return int(out[0]), int(out[1])
+
 
 class Multi:
     """sgl_multi: ONE process driving several devices, cells sharded, exchange over RCCL inside the

@@ -432,6 +432,7 @@ int sgl_tiled_build(sgl_ctx* c, const DevCSC& M, int k, DevTiled& S) {
     if (rc == SGL_OK && e != hipSuccess) { sgl_set_error("tiled build failed: %s", hipGetErrorString(e)); rc = SGL_EHIP; }
     if (rc != SGL_OK) { sgl_tiled_free(S); return rc; }
     S.built = true;
+    ++S.builds;
     return rc;
 }
 

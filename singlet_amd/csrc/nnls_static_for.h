@@ -32,22 +32,27 @@ __device__ __forceinline__ double sgl_div_normal(double x, double y) {
     return __builtin_fma(rem, r, q);
 }
 
-// One coordinate step of nnls (src/singlet.cpp:233-247) without the row update, branch-free, selects kept to
-// the minimum.  In: diff0 = b_i / a_ii (before the penalties), x_i, running tol, go (false: the column has
-// stopped -- its step is forced to zero, which leaves x, b and tol as they are).  Out: x_i, tol updated;
-// returns nd = -delta, the factor of the row update b += a[:, i] * nd.
-//   clamp (-diff > x_i): x_i -> 0, delta = -x_i, tol = 1 unless x_i was 0 (then nothing changes: delta = -0);
+// One coordinate step of nnls (src/singlet.cpp:233-247) without the row update, branch-free.  In: diff0 = b_i / a_ii
+// (before the penalties), x_i >= 0, running tol, go (false: the column has stopped -- its step is forced to zero, which
+// leaves x, b and tol as they are).  Out: x_i, tol updated; returns nd = -delta, the factor of the row update
+// b += a[:, i] * nd.
+//   clamp (-diff > x_i): x_i -> 0, delta = -x_i, tol = 1 unless x_i was 0 (then nothing changes);
 //   otherwise            x_i += diff, delta = diff, tol += |diff / (x_i + 1e-15)|  (diff == 0 adds exact zeros).
+// Both branches are ONE expression: nd = min(-diff, x_i) is x_i exactly when the reference clamps and -diff otherwise,
+// x_i - nd is 0 / x_i + diff, and |nd / (x_i - nd + 1e-15)| is the tol term of the second branch and an exact 0 in the
+// "clamped at zero already" case -- which leaves a single select, the tol = 1 of a coordinate that was clamped from a
+// positive value.  22 VALU instructions per step where the select-per-quantity form needed 38 (5 selects of 2 v_cndmask,
+// the negation); same values bit for bit (the sign of a zero step differs, which no later operation can see).
 __device__ __forceinline__ double sgl_nnls_step(double diff0, double& xi, double& tol, bool go, double L1, double L2) {
     double diff = diff0 - L1;                      // exact no-op when L1 == 0
     diff = __builtin_fma(L2, xi, diff);            // exact no-op when L2 == 0 (x >= 0)
-    diff = go ? diff : 0.0;
-    const bool clamp = -diff > xi;
-    const double xn = clamp ? 0.0 : xi + diff;
-    const double nd = clamp ? xi : -diff;
-    const double tadd = __builtin_fabs(sgl_div_normal(diff, xn + 1e-15));
-    const double t1 = (xi != 0.0) ? 1.0 : tol;
-    tol = clamp ? t1 : tol + tadd;
+    diff *= go ? 1.0 : 0.0;                        // one multiply instead of two v_cndmask (finite operands)
+    double nd;
+    asm("v_min_f64 %0, -%1, %2" : "=v"(nd) : "v"(diff), "v"(xi));
+    const double xn = xi - nd;
+    const double tadd = __builtin_fabs(sgl_div_normal(nd, xn + 1e-15));
+    const bool reset = (-diff > xi) & (xi != 0.0);
+    tol = reset ? 1.0 : tol + tadd;
     xi = xn;
     return nd;
 }

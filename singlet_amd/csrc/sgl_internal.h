@@ -69,6 +69,7 @@ struct DevTiled {
     // content is valid for (k, src_nnz); any change of the matrix frees everything (sgl_tiled_free).
     size_t cap_roff = 0, cap_x = 0, cap_cstart = 0, cap_cnt = 0, cap_part = 0, cap_xm = 0, cap_seg = 0;
     bool built = false;
+    int64_t builds = 0;         // times the stream content was (re)written on this context (sgl_layout_builds)
     int64_t src_nnz = -1;
     int32_t TR = 0, T = 0, CW = 0, k = 0, R = 1, tiles_per_range = 0;
     int64_t tail_wg0 = -1;      // tail split (R == 1): first workgroup (x) of the last, partly filled round of 256 (-1: none)

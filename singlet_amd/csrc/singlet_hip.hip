@@ -1609,6 +1609,14 @@ extern "C" int sgl_sweeps_get(sgl_ctx* c, int64_t* out4, int reset) {
     return SGL_OK;
 }
 
+extern "C" int sgl_layout_builds(sgl_ctx* c, int64_t* out2) {
+    CTX_GUARD(c);
+    if (!out2) { sgl_set_error("sgl_layout_builds: NULL buffer"); return SGL_EINVAL; }
+    out2[0] = c->TA.builds;
+    out2[1] = c->TAt.builds;
+    return SGL_OK;
+}
+
 extern "C" int sgl_layout_get(sgl_ctx* c, int64_t* out10) {
     CTX_GUARD(c);
     if (!out10) { sgl_set_error("sgl_layout_get: NULL buffer"); return SGL_EINVAL; }

@@ -80,24 +80,23 @@ def test_config5_at_its_full_size_on_one_gpu(sa):
     """BASELINE config 5's matrix (30 000 genes x 1 000 000 cells, 1.5e9 non-zeros) fits one MI355X with both
     orientations, both entry streams and their masked value arrays (~110 GB): masked fits at the ends of the rank
     range run, reduce the test error, and repeat bit for bit; a re-init at the same rank reuses the streams."""
-    import time
     c = sa.Context(0)
     try:
         c.synth(GENES, 1000000, 20)
         for k, iters in ((10, 3), (50, 2)):
             res = []
             for rep in range(2):
-                t0 = time.perf_counter()
                 c.fit_init(k, None)
-                t_init = time.perf_counter() - t0
+                builds = c.layout_builds()
                 r = c.ard_run(0.0, iters, 0.01, 0.0, SEED, INV, 1e9, 1)
                 W, d, _ = c.get_factors(h=False)
-                res.append((r["test_mse"].copy(), W.copy(), d.copy(), t_init))
-            (m0, W0, d0, _), (m1, W1, d1, t_reinit) = res
+                res.append((r["test_mse"].copy(), W.copy(), d.copy(), builds))
+            (m0, W0, d0, b_first), (m1, W1, d1, b_again) = res
             assert np.all(np.isfinite(m0)) and np.all(np.diff(m0) < 0) and 0.1 < m0[-1] < 0.5
             assert abs(W0.sum(axis=0) - 1.0).max() < 1e-9 and np.all(d0 > 0)
             assert np.array_equal(m0, m1) and np.array_equal(W0, W1) and np.array_equal(d0, d1)
-            assert t_reinit < 0.5, "re-init at an unchanged rank rebuilt the entry streams (%.2f s)" % t_reinit
+            # counted, not timed: hipMalloc / hipFree of the per-fit buffers cost 0.1 - 0.5 s at this size, box to box
+            assert b_again == b_first, "re-init at an unchanged rank rebuilt the entry streams %r -> %r" % (b_first, b_again)
     finally:
         c.close()
 
