@@ -473,9 +473,12 @@ SGL_API int sgl_sweeps_get(sgl_ctx* ctx, int64_t* out4, int reset);
  * ranges R (blockIdx.y slabs), column blocks of 64.  out10 all zero when the
  * fit runs on the plain CSC kernel (k > 128). */
 SGL_API int sgl_layout_get(sgl_ctx* ctx, int64_t* out10);
-/* How many times the entry stream of each orientation (A, At) has been written on this context: a fit at an
- * unchanged rank on an unchanged matrix reuses the stream (sgl_fit_init above) and leaves the counts as they are. */
-SGL_API int sgl_layout_builds(sgl_ctx* ctx, int64_t* out2);
+/* How many times derived data of the resident matrix has been (re)written on this context, out4 = entry stream of A, of
+ * At, mask lists of the cell side, of the gene side.  A fit at an unchanged rank reuses the streams (sgl_fit_init above);
+ * a masked fit (src/singlet.cpp:436-466, the test set rng(seed).draw(inv_density, ...)) whose (seed, inv_density) was
+ * among the last SGL_MASK_KEEP + 1 (default 3: R's n_replicates, R/ard_nmf.R:20) reuses the lists of drawn entries --
+ * the mask does not depend on the rank. */
+SGL_API int sgl_layout_builds(sgl_ctx* ctx, int64_t* out4);
 
 #ifdef __cplusplus
 }

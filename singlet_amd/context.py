@@ -383,10 +383,11 @@ class Context:
         return {name: dict(zip(keys, (int(v) for v in out[5 * o:5 * o + 5]))) for o, name in enumerate(("A", "At"))}
 
     def layout_builds(self):
-        """(A, At): times each entry stream has been written on this context (a re-init at an unchanged rank adds none)."""
-        out = np.zeros(2, dtype=np.int64)
+        """(stream of A, of At, mask lists of the cell side, of the gene side): times each has been written on this context
+        (a re-init at an unchanged rank adds no stream, a masked fit under a recently used seed no lists)."""
+        out = np.zeros(4, dtype=np.int64)
         check(self._L.sgl_layout_builds(self._h, ptr(out, i64p)))
-        return int(out[0]), int(out[1])
+        return tuple(int(v) for v in out)
 
 
 class Multi:

@@ -724,7 +724,7 @@ static int team_ard_iterate(sgl_team* T, double L1, double L2, uint64_t seed, ui
         if (!c->gene_nnz_global) { sgl_set_error("team: global gene counts missing"); return SGL_ESTATE; }
         const DevMaskList* ML = nullptr;   // this shard's part of every gene's mask as lists (built on the fit's first pass)
         if (k <= 128 && !getenv("SGL_MASK_NO_LIST")) {
-            SGLCHK(sgl_mask_list_build(c, c->ML[1], m, c->At.nrow, seed, inv_density, 1, 0, c->cell_offset));
+            SGLCHK(sgl_mask_list_select(c, 1, m, c->At.nrow, seed, inv_density, 1, 0, c->cell_offset));
             if (c->ML[1].mask_t == 1) ML = &c->ML[1];
         }
         SGLCHK(k_mask_gram_cols(c->stream, 0, m, c->At.nrow, c->col_nnz_At_global, c->H, nullptr, k, seed, inv_density, 1, 0,

@@ -118,6 +118,7 @@ struct NnlsScratch {
 // The cross-validation mask of one orientation as lists: idx[ptr[c] .. ptr[c + 1]) = the rows r (ascending) with
 // draw(cell, gene) true for column c -- built once per (seed, inv_density, shape, offsets) by two hashing passes and
 // read by mask_gram_list_kernel every iteration instead of hashing all rows x columns again (kernels_mask.hip).
+#define SGL_ML_KEEP 3
 struct DevMaskList {
     int64_t* ptr = nullptr;    // ncol + 1
     int32_t* idx = nullptr;
@@ -161,6 +162,8 @@ struct sgl_ctx {
     double* link_w = nullptr;
     int link_h_rows = 0, link_w_rows = 0;
     DevMaskList ML[2];         // masked path: the drawn rows of every column, per orientation (kernels_mask.hip); live with the entry streams
+    int64_t ml_builds[2] = {0, 0};        // times the lists of an orientation were hashed out on this context (sgl_layout_builds)
+    DevMaskList MLkeep[2][SGL_ML_KEEP];   // the lists of the masks used before this one, most recent first (sgl_mask_list_select)
     double* Gcols = nullptr;   // masked path: per-column Grams of one chunk of columns (gcols_chunk * k * k)
     int64_t gcols_chunk = 0;
     double* Wd = nullptr;      // mse_test: W' = W^T diag(d) as k x m
@@ -300,6 +303,12 @@ int k_mask_gram_cols(hipStream_t s, int64_t col0, int64_t ncols, int32_t nrow, c
 int sgl_mask_list_build(sgl_ctx* c, DevMaskList& L, int64_t ncol, int32_t nrow, uint64_t seed, uint64_t inv_density, int mask_t,
                         int64_t col_offset, int64_t row_offset);
 void sgl_mask_list_free(DevMaskList& L);
+// the lists of orientation `which` (0: cells, 1: genes) under this key in c->ML[which]: the current ones, ones kept from an
+// earlier fit, or built now -- the lists they replace are kept (R's rank search refits one matrix with the seeds
+// seed + 1 .. seed + n_replicates over and over, R/ard_nmf.R:95-160; the mask does not depend on the rank)
+int sgl_mask_list_select(sgl_ctx* c, int which, int64_t ncol, int32_t nrow, uint64_t seed, uint64_t inv_density, int mask_t,
+                         int64_t col_offset, int64_t row_offset);
+void sgl_mask_lists_free_all(sgl_ctx* c);
 int k_mask_gram_finalize(hipStream_t s, const double* G, const double* S, int k, int64_t ncols, double* out);
 int k_mse_test(sgl_ctx* c, const double* Wd, const double* H, int k, uint64_t seed, uint64_t inv_density,
                double* out_dev);

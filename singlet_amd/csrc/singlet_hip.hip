@@ -159,8 +159,7 @@ static void free_fit(sgl_ctx* c, bool keep_streams = false) {
     if (!keep_streams) {
         sgl_tiled_free(c->TA);
         sgl_tiled_free(c->TAt);
-        sgl_mask_list_free(c->ML[0]);
-        sgl_mask_list_free(c->ML[1]);
+        sgl_mask_lists_free_all(c);
     }
     c->use_tiled = false;
     c->k = 0;
@@ -946,7 +945,7 @@ int sgl_predict_mask_dev(sgl_ctx* c, const DevCSC& M, const int64_t* col_nnz, co
     if (k <= 128 && !getenv("SGL_MASK_NO_LIST")) {
         Phase ph(c, SGL_PH_MASK);
         DevMaskList& Lm = c->ML[mask_t ? 1 : 0];
-        SGLCHK(sgl_mask_list_build(c, Lm, M.ncol, M.nrow, seed, inv_density, mask_t, col_off, row_off));
+        SGLCHK(sgl_mask_list_select(c, mask_t ? 1 : 0, M.ncol, M.nrow, seed, inv_density, mask_t, col_off, row_off));
         if (Lm.mask_t == mask_t) L = &Lm;
     }
     for (int64_t c0 = 0; c0 < M.ncol; c0 += chunk) {
@@ -1609,11 +1608,13 @@ extern "C" int sgl_sweeps_get(sgl_ctx* c, int64_t* out4, int reset) {
     return SGL_OK;
 }
 
-extern "C" int sgl_layout_builds(sgl_ctx* c, int64_t* out2) {
+extern "C" int sgl_layout_builds(sgl_ctx* c, int64_t* out4) {
     CTX_GUARD(c);
-    if (!out2) { sgl_set_error("sgl_layout_builds: NULL buffer"); return SGL_EINVAL; }
-    out2[0] = c->TA.builds;
-    out2[1] = c->TAt.builds;
+    if (!out4) { sgl_set_error("sgl_layout_builds: NULL buffer"); return SGL_EINVAL; }
+    out4[0] = c->TA.builds;
+    out4[1] = c->TAt.builds;
+    out4[2] = c->ml_builds[0];
+    out4[3] = c->ml_builds[1];
     return SGL_OK;
 }
 

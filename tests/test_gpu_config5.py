@@ -76,6 +76,54 @@ def test_entry_streams_survive_fit_reinit(big):
     assert np.array_equal(f1[0], got[1][0]) and np.array_equal(f1[1], got[1][1]) and np.array_equal(f1[2], got[1][2])
 
 
+def test_mask_lists_of_recent_seeds_are_kept(sa, monkeypatch):
+    """A rank search refits one matrix with the seeds seed + 1 .. seed + n_replicates at rank after rank
+    (R/ard_nmf.R:95-160), and the mask is a function of (seed, inv_density, cell, gene) alone: the lists of the last three
+    masks stay resident and a fit under one of them hashes nothing.  The fits are the bits of a context that keeps none."""
+    def sweep(ctx):
+        out, builds = [], []
+        for k, seed in [(8, SEED + 1), (8, SEED + 2), (8, SEED + 3), (14, SEED + 1), (14, SEED + 2), (14, SEED + 3),
+                        (14, SEED + 4), (14, SEED + 2), (14, SEED + 1)]:
+            ctx.fit_init(k, None)
+            r = ctx.ard_run(0.0, 2, 0.01, 0.0, seed, INV, 1e9, 1)
+            W, d, _ = ctx.get_factors(h=False)
+            out.append((r["test_mse"].copy(), W.copy(), d.copy()))
+            builds.append(ctx.layout_builds()[2:])
+        return out, builds
+
+    def run():
+        c = sa.Context(0)
+        try:
+            c.synth(GENES, 20000, 20)
+            return sweep(c)
+        finally:
+            c.close()
+
+    kept, b_kept = run()
+    # seeds 1, 2, 3 are hashed once each, the second rank reuses them; seed 4 pushes out the oldest (seed 1 -- 2 was used
+    # after it); 2 is still there, 1 is hashed again
+    assert b_kept == [(1, 1), (2, 2), (3, 3), (3, 3), (3, 3), (3, 3), (4, 4), (4, 4), (5, 5)], b_kept
+    monkeypatch.setenv("SGL_MASK_KEEP", "0")
+    import subprocess, sys, pickle, os, textwrap
+    # (the switch is read once per process: the keep-nothing run is a child)
+    code = textwrap.dedent("""
+        import pickle, sys, numpy as np
+        sys.path.insert(0, %r)
+        import singlet_amd as sa
+        c = sa.Context(0); c.synth(%d, 20000, 20)
+        out = []
+        for k, seed in [(8, %d), (14, %d), (14, %d)]:
+            c.fit_init(k, None); r = c.ard_run(0.0, 2, 0.01, 0.0, seed, %d, 1e9, 1); W, d, _ = c.get_factors(h=False)
+            out.append((r["test_mse"].copy(), W.copy(), d.copy(), c.layout_builds()[2:]))
+        sys.stdout.buffer.write(pickle.dumps(out))
+    """) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), GENES, SEED + 1, SEED + 1, SEED + 2, INV)
+    raw = subprocess.run([sys.executable, "-c", code], check=True, capture_output=True, timeout=600).stdout
+    none = pickle.loads(raw[raw.index(b"\x80"):])
+    assert [n[3] for n in none] == [(1, 1), (1, 1), (2, 2)]          # only the running mask is there
+    for got, ref in ((kept[0], none[0]), (kept[3], none[1]), (kept[7], none[2])):
+        assert all(np.array_equal(a, b) for a, b in zip(got, ref[:3]))
+
+
 def test_config5_at_its_full_size_on_one_gpu(sa):
     """BASELINE config 5's matrix (30 000 genes x 1 000 000 cells, 1.5e9 non-zeros) fits one MI355X with both
     orientations, both entry streams and their masked value arrays (~110 GB): masked fits at the ends of the rank
@@ -96,7 +144,7 @@ def test_config5_at_its_full_size_on_one_gpu(sa):
             assert abs(W0.sum(axis=0) - 1.0).max() < 1e-9 and np.all(d0 > 0)
             assert np.array_equal(m0, m1) and np.array_equal(W0, W1) and np.array_equal(d0, d1)
             # counted, not timed: hipMalloc / hipFree of the per-fit buffers cost 0.1 - 0.5 s at this size, box to box
-            assert b_again == b_first, "re-init at an unchanged rank rebuilt the entry streams %r -> %r" % (b_first, b_again)
+            assert b_again[:2] == b_first[:2], "re-init at an unchanged rank rebuilt the entry streams %r -> %r" % (b_first, b_again)
     finally:
         c.close()
 
