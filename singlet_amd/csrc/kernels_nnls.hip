@@ -272,9 +272,10 @@ __global__ __launch_bounds__(256) void nnls_wave_kernel(const double* __restrict
                 // b_i / g_ii from the reciprocal (Markstein correction; see nnls_lane.h), then l.235-247
                 const double q0 = bi * rii;
                 const double diff0 = fma(fma(-q0, gii, bi), rii, q0);
-                double xn = xi;
-                const double nd = sgl_nnls_step(diff0, xn, tol, true, L1, L2);
-                if (nd != 0.0 || xn != xi) {  // wave-uniform
+                double xn = xi, dpen;
+                const double nd = sgl_nnls_nd(diff0, xi, true, L1, L2, dpen);
+                if (nd != 0.0) {  // wave-uniform; at rest: x, tol and b stay as they are
+                    sgl_nnls_apply(dpen, nd, xn, tol);
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
                         const int j = lane + 64 * r;
@@ -379,11 +380,15 @@ __global__ __launch_bounds__(64) void nnls_quad_kernel(const double* __restrict_
                     }
                     const double q0 = bi * rii;
                     const double diff0 = fma(fma(-q0, gii, bi), rii, q0);   // b_i / g_ii (Markstein, see nnls_lane.h)
-                    double xn = xi;
-                    const double nd = sgl_nnls_step(diff0, xn, tol, go, L1, L2);
-                    x[ir] = (l == il) ? xn : x[ir];
+                    double dpen;
+                    const double nd = sgl_nnls_nd(diff0, xi, go, L1, L2, dpen);
+                    if (__ballot(nd != 0.0) != 0ull) {   // at rest in all four columns: x, tol and b stay as they are
+                        double xn = xi;
+                        sgl_nnls_apply(dpen, nd, xn, tol);
+                        x[ir] = (l == il) ? xn : x[ir];
 #pragma unroll
-                    for (int r = 0; r < NR; ++r) b[r] = fma(g[r], nd, b[r]);
+                        for (int r = 0; r < NR; ++r) b[r] = fma(g[r], nd, b[r]);
+                    }
                 }
             });
             it += go ? 1 : 0;
@@ -510,11 +515,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGL_QG_WPE))
                     if (i + 1 < 16 * NR) { dn0 = dgc[2 * (i + 1)]; dn1 = dgc[2 * (i + 1) + 1]; }
                     const double q0 = bi * rii;
                     const double diff0 = fma(fma(-q0, gii, bi), rii, q0);   // b_i / g_ii (Markstein, see nnls_lane.h)
-                    double xn = xi;
-                    const double nd = sgl_nnls_step(diff0, xn, tol, go, L1, L2);
-                    x[ir] = (l == il) ? xn : x[ir];
-                    const bool moved = nd != 0.0;   // (x changes only with nd != 0; a stopped column has nd = 0)
+                    double dpen;
+                    const double nd = sgl_nnls_nd(diff0, xi, go, L1, L2, dpen);
+                    const bool moved = nd != 0.0;   // (x and tol change only with nd != 0; a stopped column has nd = 0)
                     if (__ballot(moved) != 0ull) {   // the coordinate moves in one of the four columns
+                        double xn = xi;
+                        sgl_nnls_apply(dpen, nd, xn, tol);
+                        x[ir] = (l == il) ? xn : x[ir];
                         if (moved && !have_i) {
 #pragma unroll
                             for (int r = 0; r < NR; ++r) g[r] = (l + 16 * r < k) ? gp[16 * r] : 0.0;

@@ -43,16 +43,27 @@ __device__ __forceinline__ double sgl_div_normal(double x, double y) {
 // "clamped at zero already" case -- which leaves a single select, the tol = 1 of a coordinate that was clamped from a
 // positive value.  22 VALU instructions per step where the select-per-quantity form needed 38 (5 selects of 2 v_cndmask,
 // the negation); same values bit for bit (the sign of a zero step differs, which no later operation can see).
-__device__ __forceinline__ double sgl_nnls_step(double diff0, double& xi, double& tol, bool go, double L1, double L2) {
-    double diff = diff0 - L1;                      // exact no-op when L1 == 0
+// The two halves of the step, for the kernels that test whether the coordinate moves at all before paying for the rest
+// (four columns per wave: a coordinate at rest in all four skips sgl_nnls_apply and the row update -- with nd = 0,
+// sgl_nnls_apply leaves x_i and tol as they are, bit for bit: x_i - 0, tol + |0 / (x_i + 1e-15)|, no reset).
+__device__ __forceinline__ double sgl_nnls_nd(double diff0, double xi, bool go, double L1, double L2, double& diff) {
+    diff = diff0 - L1;                             // exact no-op when L1 == 0
     diff = __builtin_fma(L2, xi, diff);            // exact no-op when L2 == 0 (x >= 0)
     diff *= go ? 1.0 : 0.0;                        // one multiply instead of two v_cndmask (finite operands)
     double nd;
     asm("v_min_f64 %0, -%1, %2" : "=v"(nd) : "v"(diff), "v"(xi));
+    return nd;
+}
+__device__ __forceinline__ void sgl_nnls_apply(double diff, double nd, double& xi, double& tol) {
     const double xn = xi - nd;
     const double tadd = __builtin_fabs(sgl_div_normal(nd, xn + 1e-15));
     const bool reset = (-diff > xi) & (xi != 0.0);
     tol = reset ? 1.0 : tol + tadd;
     xi = xn;
+}
+__device__ __forceinline__ double sgl_nnls_step(double diff0, double& xi, double& tol, bool go, double L1, double L2) {
+    double diff;
+    const double nd = sgl_nnls_nd(diff0, xi, go, L1, L2, diff);
+    sgl_nnls_apply(diff, nd, xi, tol);
     return nd;
 }
