@@ -631,6 +631,74 @@ __global__ __launch_bounds__(256) void mse_test_list_kernel(const double* __rest
     }
 }
 
+// The matrix value at every listed (gene, cell) of the cell-side lists -- 0 where the cell has no non-zero at the gene --
+// found ONCE per mask: the test error is traced several times per fit and the mask comes back fit after fit
+// (sgl_mask_list_select), and finding A(gene, cell) is most of what a trace costs in mse_test_list_kernel (per listed
+// gene a readlane, a ballot and two more readlanes, serial in the four genes of a step).
+__global__ __launch_bounds__(256) void mask_vals_kernel(const double* __restrict__ Ax, const int32_t* __restrict__ Ai,
+                                                        const int64_t* __restrict__ Ap, int64_t n,
+                                                        const int64_t* __restrict__ lptr, const int32_t* __restrict__ lidx,
+                                                        double* __restrict__ lval) {
+    const int lane = threadIdx.x & 63;
+    const int64_t gw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t cell = gw; cell < n; cell += nwaves) {
+        const int64_t q0 = Ap[cell], qend = Ap[cell + 1];
+        const int64_t p0 = lptr[cell];
+        const int nl = (int)(lptr[cell + 1] - p0);
+        // both ascend: lane t of a step looks its gene up by bisection in the cell's non-zeros (<= 11 + 1 probes of L2)
+        for (int t = lane; t < nl; t += 64) {
+            const int g = lidx[p0 + t];
+            int64_t lo = q0, hi = qend;   // first non-zero with row >= g
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) >> 1;
+                if (Ai[mid] < g) lo = mid + 1; else hi = mid;
+            }
+            lval[p0 + t] = (lo < qend && Ai[lo] == g) ? Ax[lo] : 0.0;
+        }
+    }
+}
+
+// mse_test_list_kernel with the matrix values listed (mask_vals_kernel): same predictions, same four partial sums in the
+// same order -- the same bits.
+template <int NJ>
+__global__ __launch_bounds__(256) void mse_test_vals_kernel(int64_t n, const int64_t* __restrict__ lptr, const int32_t* __restrict__ lidx,
+                                                            const double* __restrict__ lval, const double* __restrict__ Wd,
+                                                            const double* __restrict__ H, int k, double* __restrict__ losses) {
+    const int lane = threadIdx.x & 63, rowid = lane >> 4, l16 = lane & 15;
+    const int64_t gw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t cell = gw; cell < n; cell += nwaves) {
+        const int64_t p0 = lptr[cell];
+        const int nl = (int)(lptr[cell + 1] - p0);
+        double h[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) h[j] = (l16 + 16 * j < k) ? H[cell * k + l16 + 16 * j] : 0.0;
+        double s = 0.0;
+        for (int t = 0; t < nl; t += 4) {
+            const bool valid = t + rowid < nl;
+            const int g = valid ? lidx[p0 + t + rowid] : 0;
+            const double val = valid ? lval[p0 + t + rowid] : 0.0;
+            const double* wd = Wd + (int64_t)g * k + l16;
+            double prod = 0.0;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                if (l16 + 16 * j < k) prod = fma(wd[16 * j], h[j], prod);
+            prod += dpp_mov_f64(prod, 0, 0xf);
+            prod += dpp_mov_f64(prod, 1, 0xf);
+            prod += dpp_mov_f64(prod, 2, 0xf);
+            prod += dpp_mov_f64(prod, 3, 0xf);   // every lane of a 16-lane row holds its gene's prediction
+            const double e = prod - val;
+            s = valid ? fma(e, e, s) : s;
+        }
+        const double s0 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(s), 0), __builtin_amdgcn_readlane(__double2loint(s), 0));
+        const double s1 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(s), 16), __builtin_amdgcn_readlane(__double2loint(s), 16));
+        const double s2 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(s), 32), __builtin_amdgcn_readlane(__double2loint(s), 32));
+        const double s3 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(s), 48), __builtin_amdgcn_readlane(__double2loint(s), 48));
+        if (lane == 0) losses[cell] = (nl > 0) ? (((s0 + s1) + s2) + s3) / (double)nl : 0.0;
+    }
+}
+
 __global__ __launch_bounds__(256) void sum_partial_kernel(const double* __restrict__ v, int64_t n,
                                                           double* __restrict__ part) {
     double s = 0.0;
@@ -670,7 +738,45 @@ int k_mse_test(sgl_ctx* c, const double* Wd, const double* H, int k, uint64_t se
     const DevMaskList& L = c->ML[0];
     const bool lists = k <= 128 && L.mask_t == 0 && L.ptr != nullptr && L.idx != nullptr && L.seed == seed && L.inv == inv_density &&
                        L.ncol == n && L.nrow == c->A.nrow && L.col_off == c->cell_offset && L.row_off == 0 && !getenv("SGL_MSE_NO_LIST");
-    if (lists) {
+    // ... and the matrix values at the listed entries, found once per mask (8 B per drawn pair: 12 GB at config 5; not when
+    // that is more than a fifth of the free memory, SGL_MSE_NO_VALS=1: the window kernel looks them up in every trace)
+    DevMaskList& Lw = c->ML[0];
+    if (lists && !Lw.val_ok && !Lw.val_refused && !getenv("SGL_MSE_NO_VALS")) {
+        const size_t want = (size_t)Lw.total + 64;
+        if (Lw.cap_val < want) {
+            if (Lw.val) (void)hipFree(Lw.val);
+            Lw.val = nullptr; Lw.cap_val = 0;
+            size_t free_b = 0, total_b = 0;
+            HIPCHK(hipMemGetInfo(&free_b, &total_b));
+            const size_t cap = (size_t)((double)Lw.total * 1.02) + 1024;
+            if (8.0 * (double)cap > 0.2 * (double)free_b || hipMalloc(&Lw.val, sizeof(double) * cap) != hipSuccess) {
+                (void)hipGetLastError();
+                Lw.val = nullptr;
+                Lw.val_refused = true;
+            } else {
+                Lw.cap_val = cap;
+            }
+        }
+        if (Lw.val) {
+            mask_vals_kernel<<<dim3((unsigned)blocks), dim3(256), 0, c->stream>>>(c->A.x, c->A.i, c->A.p, n, Lw.ptr, Lw.idx, Lw.val);
+            HIPCHK(hipGetLastError());
+            Lw.val_ok = true;
+        }
+    }
+    if (lists && Lw.val_ok) {
+#define SGL_MSEV(NJ_) mse_test_vals_kernel<NJ_><<<dim3((unsigned)blocks), dim3(256), 0, c->stream>>>(n, L.ptr, L.idx, L.val, Wd, H, k, losses)
+        switch ((k + 15) / 16) {
+            case 1: SGL_MSEV(1); break;
+            case 2: SGL_MSEV(2); break;
+            case 3: SGL_MSEV(3); break;
+            case 4: SGL_MSEV(4); break;
+            case 5: SGL_MSEV(5); break;
+            case 6: SGL_MSEV(6); break;
+            case 7: SGL_MSEV(7); break;
+            default: SGL_MSEV(8); break;
+        }
+#undef SGL_MSEV
+    } else if (lists) {
 #define SGL_MSEL(NJ_) mse_test_list_kernel<NJ_><<<dim3((unsigned)blocks), dim3(256), 0, c->stream>>>(c->A.x, c->A.i, c->A.p, n, L.ptr, L.idx, Wd, H, k, losses)
         switch ((k + 15) / 16) {
             case 1: SGL_MSEL(1); break;

@@ -122,7 +122,9 @@ struct NnlsScratch {
 struct DevMaskList {
     int64_t* ptr = nullptr;    // ncol + 1
     int32_t* idx = nullptr;
-    size_t cap_ptr = 0, cap_idx = 0;
+    double* val = nullptr;     // cell side, on the first mse_test of a mask: the matrix value at every listed (gene, cell), 0 where A has none
+    bool val_ok = false, val_refused = false;
+    size_t cap_ptr = 0, cap_idx = 0, cap_val = 0;
     int64_t ncol = 0, total = 0;
     int32_t nrow = 0;
     uint64_t seed = 0, inv = 0;

@@ -591,6 +591,60 @@ def test_mse_test_op(sa, ora, k, use_lists, monkeypatch):
     assert abs(two - exp) <= 1e-11 * abs(exp), (two, exp)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [7, 50, 100])
+def test_mse_test_from_listed_values_equals_the_window_kernel(sa, ora, k, monkeypatch):
+    """Once a masked H-update has listed the mask, mse_test reads the matrix values at the listed entries from a list
+    made on its first call (mask_vals_kernel) instead of searching the cell's non-zeros in every trace: the bits of the
+    window kernel (SGL_MSE_NO_VALS=1), the oracle's value (src/singlet.cpp:536-568), also with a cell offset, empty
+    cells and a cell whose every gene is a non-zero."""
+    m, n, seed, inv = 333, 517, 99, 7
+    A = ora.synth_csc(m, n, 9)
+    # an empty cell and a full one
+    p = A.p.copy()
+    cnt = np.diff(p)
+    x2, i2, p2 = [], [], [0]
+    for c in range(n):
+        if c == 5:
+            pass
+        elif c == 11:
+            x2.append(1.0 + np.arange(m) % 5); i2.append(np.arange(m, dtype=np.int32))
+        else:
+            x2.append(A.x[p[c]:p[c + 1]]); i2.append(A.i[p[c]:p[c + 1]])
+        p2.append(p2[-1] + (0 if c == 5 else (m if c == 11 else cnt[c])))
+    A = ora.CSC(np.concatenate(x2).astype(np.float64), np.concatenate(i2).astype(np.int32), np.asarray(p2, dtype=np.int64), m, n)
+    rng = np.random.default_rng(k)
+    W = np.abs(rng.standard_normal((m, k)))
+    H = np.abs(rng.standard_normal((n, k))) * (rng.random((n, k)) < 0.8)
+    d = 0.5 + rng.random(k)
+    exp = ora.mse_test(A, W, d, H, seed, inv)
+
+    def shard(lo, hi):
+        sub = ora.CSC(A.x[A.p[lo]:A.p[hi]], A.i[A.p[lo]:A.p[hi]], A.p[lo:hi + 1] - A.p[lo], m, hi - lo)
+        c = sa.Context(0)
+        try:
+            c.upload(to_dgc(sa, sub), None, cell_offset=lo, ncells_total=n)
+            c.fit_init(k, W)
+            c.step_h_masked(0.0, 0.0, seed, inv)          # lists the mask of the cell side
+            assert c.layout_builds()[2] == 1
+            c.set_factors(W, d, H[lo:hi])
+            monkeypatch.setenv("SGL_MSE_NO_VALS", "1")
+            window = c.op_mse_test(seed, inv)
+            monkeypatch.delenv("SGL_MSE_NO_VALS")
+            first = c.op_mse_test(seed, inv)               # makes the value list
+            again = c.op_mse_test(seed, inv)               # reads it
+            return window, first, again
+        finally:
+            c.close()
+
+    w1, f1, a1 = shard(0, n)
+    assert f1 == w1 and a1 == w1
+    assert abs(f1 - exp) <= 1e-11 * abs(exp), (f1, exp)
+    parts = [shard(0, 200), shard(200, n)]
+    assert all(f == w and a == w for w, f, a in parts)
+    assert abs(sum(q[1] for q in parts) - exp) <= 1e-11 * abs(exp)
+
+
 def _random_csc(ora, rng, m, n, style):
     """random sparse matrices with awkward columns: empty ones, single entries, dense runs, heavy tails"""
     if style == "uniform":
