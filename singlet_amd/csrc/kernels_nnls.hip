@@ -314,6 +314,24 @@ __device__ __forceinline__ double quad_bcast(double v) {
     return __hiloint2double(hi, lo);
 }
 
+// b_i and x_i of a coordinate for the 16 lanes of every row in one statement.  (The builtin form above initialises the
+// `old` operand -- a v_mov per dword -- although a row_newbcast has no invalid source lane; this is the bare
+// v_mov_b32_dpp.  hipcc pads no hazards around inline asm: the s_nop covers the two wait states between a VALU write of
+// a source -- the row update of the coordinate before -- and its DPP read.)
+template <int J>
+__device__ __forceinline__ void nnls_row_bcast2(double bsrc, double xsrc, double& bi, double& xi) {
+    const int blo = __double2loint(bsrc), bhi = __double2hiint(bsrc), xlo = __double2loint(xsrc), xhi = __double2hiint(xsrc);
+    int r0, r1, r2, r3;
+    asm("s_nop 1\n\t"
+        "v_mov_b32_dpp %0, %4 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %1, %5 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %2, %6 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %3, %7 row_newbcast:%8 row_mask:0xf bank_mask:0xf"
+        : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3) : "v"(blo), "v"(bhi), "v"(xlo), "v"(xhi), "n"(J));
+    bi = __hiloint2double(r1, r0);
+    xi = __hiloint2double(r3, r2);
+}
+
 template <int NR>
 __global__ __launch_bounds__(64) void nnls_quad_kernel(const double* __restrict__ G, int64_t gstride,
                                                        const double* __restrict__ B, double* __restrict__ X,
@@ -468,9 +486,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGL_QG_WPE))
         unsigned act[NW], cur[NW];
 #pragma unroll
         for (int w = 0; w < NW; ++w) act[w] = ~0u;
-        double gn[NR];
+        // Two row buffers by the parity of the coordinate (no copies), every load of a row unconditional under ONE exec
+        // mask: the lanes past the rank (only in piece NR - 1: an instance serves 16 (NR - 1) < k <= 16 NR) read the row's
+        // last entry instead -- their b is never looked at.  (Written as `j < k ? gp[16 r] : 0.0` per piece, hipcc
+        // wrapped each of the 7 loads in its own s_and_saveexec / branch and zeroed the register first, and the row went
+        // through 2 - 3 register copies per coordinate: ~110 instructions per step, now ~60.)
+        double g2[2][NR];
 #pragma unroll
-        for (int r = 0; r < NR; ++r) gn[r] = 0.0;
+        for (int r = 0; r < NR; ++r) g2[0][r] = g2[1][r] = 0.0;
+        const int last_j = (l + 16 * (NR - 1) < k) ? l + 16 * (NR - 1) : k - 1;
+        auto load_row = [&](double (&dst)[NR], const double* __restrict__ p, const double* __restrict__ pl) {
+#pragma unroll
+            for (int r = 0; r < NR - 1; ++r) dst[r] = p[16 * r];
+            dst[NR - 1] = pl[0];
+        };
         while (true) {
             const bool go = cvalid && it < 100 && (tol / kd) > 1e-8;
             if (__ballot(go) == 0ull) break;
@@ -478,39 +507,32 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGL_QG_WPE))
             if (go) tol = 0.0;
 #pragma unroll
             for (int w = 0; w < NW; ++w) cur[w] = 0u;
-            // a running row pointer (its addresses cannot be hoisted out of the sweep loop: written as Gc[(i + 1) k + ...]
+            // running row pointers (their addresses cannot be hoisted out of the sweep loop: written as Gc[(i + 1) k + ...]
             // hipcc kept the addresses of all 16 NR rows in registers, 344 VGPRs at NR = 7)
-            const double* __restrict__ gp = Gc + l;   // row i of the running coordinate
+            const double* __restrict__ gp = Gc + l;          // row i of the running coordinate, pieces 0 .. NR - 2
+            const double* __restrict__ gpl = Gc + last_j;    // ... its last piece
             double dn0 = dgc[0], dn1 = dgc[1];        // (G_ii, 1 / G_ii) of the coordinate to come
             bool have = go && (act[0] & 1u) != 0u;    // row 0 fetched ahead? (per column)
-            if (have) {
-#pragma unroll
-                for (int r = 0; r < NR; ++r) gn[r] = (l + 16 * r < k) ? gp[16 * r] : 0.0;
-            }
+            if (have) load_row(g2[0], gp, gpl);
             static_for<16 * NR>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
                 constexpr int ir = i >> 4, il = i & 15;
+                constexpr int pb = i & 1;
                 bool run_i = i < k;
                 if (i <= 16 * (NR - 1)) { asm volatile("" : "+s"(one)); run_i = one != 0; }   // opaque, always true (see nnls_lane.h)
                 if (run_i) {
-                    double g[NR];
-#pragma unroll
-                    for (int r = 0; r < NR; ++r) g[r] = gn[r];
                     const bool have_i = have;
                     have = false;
                     if (i + 1 < 16 * NR) {   // row i + 1, in flight during this coordinate -- if its coordinate moved last sweep
                         const bool more = (i + 1 <= 16 * (NR - 1)) || (i + 1 < k);
                         constexpr int i1 = i + 1;
                         have = more && go && (act[i1 >> 5] & (1u << (i1 & 31))) != 0u;
-                        if (have) {
-#pragma unroll
-                            for (int r = 0; r < NR; ++r) gn[r] = (l + 16 * r < k) ? gp[k + 16 * r] : 0.0;
-                        }
+                        if (have) load_row(g2[pb ^ 1], gp + k, gpl + k);
                     }
                     // fence: one row ahead, no more
                     __builtin_amdgcn_sched_barrier(0);
-                    const double bi = quad_bcast<il>(b[ir]);
-                    const double xi = quad_bcast<il>(x[ir]);
+                    double bi, xi;
+                    nnls_row_bcast2<il>(b[ir], x[ir], bi, xi);
                     const double gii = dn0, rii = dn1;
                     if (i + 1 < 16 * NR) { dn0 = dgc[2 * (i + 1)]; dn1 = dgc[2 * (i + 1) + 1]; }
                     const double q0 = bi * rii;
@@ -522,15 +544,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGL_QG_WPE))
                         double xn = xi;
                         sgl_nnls_apply(dpen, nd, xn, tol);
                         x[ir] = (l == il) ? xn : x[ir];
-                        if (moved && !have_i) {
+                        if (moved && !have_i) load_row(g2[pb], gp, gpl);
 #pragma unroll
-                            for (int r = 0; r < NR; ++r) g[r] = (l + 16 * r < k) ? gp[16 * r] : 0.0;
-                        }
-#pragma unroll
-                        for (int r = 0; r < NR; ++r) b[r] = fma(g[r], nd, b[r]);
+                        for (int r = 0; r < NR; ++r) b[r] = fma(g2[pb][r], nd, b[r]);
                         cur[i >> 5] |= moved ? (1u << (i & 31)) : 0u;
                     }
                     gp += k;
+                    gpl += k;
                     __builtin_amdgcn_sched_barrier(0);
                 }
             });
