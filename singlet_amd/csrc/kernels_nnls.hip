@@ -298,24 +298,8 @@ __global__ __launch_bounds__(256) void nnls_wave_kernel(const double* __restrict
     }
 }
 
-// ---------------------------------------------------------------------------
-// Per-column Gram (masked path), k <= 64: FOUR columns per wave, one 16-lane DPP row each ("quad").  In
-// nnls_wave_kernel the ~60 instructions of a coordinate step that are uniform over the wave (two divisions,
-// clamp logic, tol) are issued once per column; here one issue serves four columns, and a lane's share of the
-// Gram row update is ceil(k / 16) FMAs instead of one.  The column's Gram is staged ONCE as a packed lower
-// triangle in LDS (k (k + 1) / 2 doubles: 10 KB at k = 50, four per wave), so global memory sees it once
-// instead of once per sweep; b_i, x_i and 1 / g_ii reach the row's lanes by DPP row_newbcast (builtin: the
-// compiler pads the VALU-write -> DPP-read hazard), g_ii and the Gram row come from LDS.  Arithmetic and order
-// are those of nnls_lane.h (the folded form of src/singlet.cpp:229-250), results bit-identical.
-template <int J>
-__device__ __forceinline__ double quad_bcast(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + J, 0xf, 0xf, false);   // row_newbcast:J
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + J, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-
-// b_i and x_i of a coordinate for the 16 lanes of every row in one statement.  (The builtin form above initialises the
-// `old` operand -- a v_mov per dword -- although a row_newbcast has no invalid source lane; this is the bare
+// b_i and x_i (and 1 / g_ii) of a coordinate for the 16 lanes of every row in one statement.  (__builtin_amdgcn_update_dpp
+// initialises its `old` operand -- a v_mov per dword -- although a row_newbcast has no invalid source lane; this is the bare
 // v_mov_b32_dpp.  hipcc pads no hazards around inline asm: the s_nop covers the two wait states between a VALU write of
 // a source -- the row update of the coordinate before -- and its DPP read.)
 template <int J>
@@ -332,6 +316,34 @@ __device__ __forceinline__ void nnls_row_bcast2(double bsrc, double xsrc, double
     xi = __hiloint2double(r3, r2);
 }
 
+template <int J>
+__device__ __forceinline__ void nnls_row_bcast3(double bsrc, double xsrc, double rsrc, double& bi, double& xi, double& ri) {
+    const int blo = __double2loint(bsrc), bhi = __double2hiint(bsrc), xlo = __double2loint(xsrc), xhi = __double2hiint(xsrc);
+    const int rlo = __double2loint(rsrc), rhi = __double2hiint(rsrc);
+    int r0, r1, r2, r3, r4, r5;
+    asm("s_nop 1\n\t"
+        "v_mov_b32_dpp %0, %6 row_newbcast:%12 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %1, %7 row_newbcast:%12 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %2, %8 row_newbcast:%12 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %3, %9 row_newbcast:%12 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %4, %10 row_newbcast:%12 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %5, %11 row_newbcast:%12 row_mask:0xf bank_mask:0xf"
+        : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5)
+        : "v"(blo), "v"(bhi), "v"(xlo), "v"(xhi), "v"(rlo), "v"(rhi), "n"(J));
+    bi = __hiloint2double(r1, r0);
+    xi = __hiloint2double(r3, r2);
+    ri = __hiloint2double(r5, r4);
+}
+
+// ---------------------------------------------------------------------------
+// Per-column Gram (masked path), k <= 64: FOUR columns per wave, one 16-lane DPP row each ("quad").  In
+// nnls_wave_kernel the ~60 instructions of a coordinate step that are uniform over the wave (two divisions,
+// clamp logic, tol) are issued once per column; here one issue serves four columns, and a lane's share of the
+// Gram row update is ceil(k / 16) FMAs instead of one.  The column's Gram is staged ONCE as a packed lower
+// triangle in LDS (k (k + 1) / 2 doubles: 10 KB at k = 50, four per wave), so global memory sees it once
+// instead of once per sweep; b_i, x_i and 1 / g_ii reach the row's lanes by DPP row_newbcast (nnls_row_bcast3), g_ii and
+// the Gram row come from LDS.  Arithmetic and order are those of nnls_lane.h (the folded form of
+// src/singlet.cpp:229-250), results bit-identical.
 template <int NR>
 __global__ __launch_bounds__(64) void nnls_quad_kernel(const double* __restrict__ G, int64_t gstride,
                                                        const double* __restrict__ B, double* __restrict__ X,
@@ -385,9 +397,8 @@ __global__ __launch_bounds__(64) void nnls_quad_kernel(const double* __restrict_
                 if (i <= 16 * (NR - 1)) { asm volatile("" : "+s"(one)); run_i = one != 0; }
                 if (run_i) {
                     constexpr int ti = i * (i + 1) / 2;
-                    const double bi = quad_bcast<il>(b[ir]);
-                    const double xi = quad_bcast<il>(x[ir]);
-                    const double rii = quad_bcast<il>(rg[ir]);
+                    double bi, xi, rii;
+                    nnls_row_bcast3<il>(b[ir], x[ir], rg[ir], bi, xi, rii);
                     const double gii = tri[ti + i];
                     double g[NR];
 #pragma unroll
@@ -443,6 +454,7 @@ __global__ __launch_bounds__(64) void nnls_quad_kernel(const double* __restrict_
 #ifndef SGL_QG_WPE
 #define SGL_QG_WPE 4
 #endif
+
 template <int NR>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGL_QG_WPE))) void nnls_quad_global_kernel(const double* __restrict__ G, int64_t gstride,
                                                               const double* __restrict__ B, double* __restrict__ X,
@@ -614,7 +626,15 @@ int k_nnls_wave(hipStream_t s, const double* G, int64_t gstride, const double* B
     // per-column Grams: four columns per wave while four waves' triangles fit a CU's LDS (k <= 50).  Measured at
     // 30 000 x 100 000 (nnls_h, ms): k = 10: 1.1 vs 4.4 for nnls_wave_kernel, k = 30: 5.8 vs 14.0, k = 50: 21.5 vs
     // 27.1; at k = 64 (two waves per CU) 48.4 vs 38.5, so larger ranks stay on the wave kernel.  (env: A/B tests)
-    if (gstride != 0 && 4 * 4 * sizeof(double) * (size_t)(((k * (k + 1) / 2) + 1) & ~1) <= 160 * 1024 && !getenv("SGL_NNLS_NO_QUAD")) {
+    // Round 4: once the global-memory solve below had lost its copies and per-load branches it overtakes this one where the
+    // triangles leave one wave per SIMD: nnls_h per masked iteration at 30 000 x 200 000 (LDS -> global): k = 32: 6.5 -> 7.6,
+    // 36: 8.6 -> 9.0, 40: 10.1 -> 9.7, 44: 12.7 -> 10.9, 48: 16.9 -> 11.6; on the 30 000 columns of the W side the LDS solve
+    // stays ahead up to k = 44.  (SGL_NNLS_QUAD_GLOBAL_FROM: the first rank that takes the global solve -- A/B tests)
+    const char* qmin = getenv("SGL_NNLS_QUAD_GLOBAL_MIN_COLS");   // (tests lower it to reach the long-launch choices with small problems)
+    const int64_t long_launch = (qmin && atoll(qmin) > 0) ? atoll(qmin) : 65536;
+    const char* qfrom = getenv("SGL_NNLS_QUAD_GLOBAL_FROM");
+    const int global_from = (qfrom && atoi(qfrom) > 0) ? atoi(qfrom) : (ncols >= long_launch ? 40 : 47);
+    if (gstride != 0 && k < global_from && 4 * 4 * sizeof(double) * (size_t)(((k * (k + 1) / 2) + 1) & ~1) <= 160 * 1024 && !getenv("SGL_NNLS_NO_QUAD")) {
         switch ((k + 15) / 16) {
             case 1: return launch_nnls_quad<1>(s, G, gstride, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
             case 2: return launch_nnls_quad<2>(s, G, gstride, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
@@ -630,13 +650,13 @@ int k_nnls_wave(hipStream_t s, const double* G, int64_t gstride, const double* B
     // the wave slots).  With chunks that fill the chip (sgl_mask_workspace) k = 113 ... 128 gains too when the launch has
     // columns enough (nnls_h k = 120: 198 -> 134 ms, 128: 216 -> 146; the 30 000 genes of the W side: 19.5 -> 24.0, so
     // short launches keep the wave kernel there).  SGL_NNLS_QUAD_GLOBAL_112=1: the old limit for every launch.
-    const char* qmin = getenv("SGL_NNLS_QUAD_GLOBAL_MIN_COLS");   // (tests lower it to reach the k > 112 instance with small problems)
-    const int64_t long_launch = (qmin && atoll(qmin) > 0) ? atoll(qmin) : 65536;
     const int quad_global_max_k = (ncols >= long_launch && !getenv("SGL_NNLS_QUAD_GLOBAL_112")) ? 128 : 112;
-    // (k > 48: the instances run coordinates 0 .. 16 (NR - 1) unconditionally and prefetch their rows -- a smaller rank,
-    // reachable only with the LDS quad kernel switched off by SGL_NNLS_NO_QUAD, would read past the column's k x k Gram)
-    if (gstride != 0 && k > 48 && k <= quad_global_max_k && !getenv("SGL_NNLS_NO_QUAD_GLOBAL")) {
+    // (instance NR serves 16 (NR - 1) < k <= 16 NR: it runs coordinates 0 .. 16 (NR - 1) unconditionally and prefetches their rows)
+    if (gstride != 0 && k <= quad_global_max_k && !getenv("SGL_NNLS_NO_QUAD_GLOBAL")) {
         switch ((k + 15) / 16) {
+            case 1: return launch_nnls_quad_global<1>(s, G, gstride, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
+            case 2: return launch_nnls_quad_global<2>(s, G, gstride, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
+            case 3: return launch_nnls_quad_global<3>(s, G, gstride, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
             case 4: return launch_nnls_quad_global<4>(s, G, gstride, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
             case 5: return launch_nnls_quad_global<5>(s, G, gstride, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
             case 6: return launch_nnls_quad_global<6>(s, G, gstride, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);

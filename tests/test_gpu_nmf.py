@@ -124,6 +124,26 @@ def test_c_ard_nmf_parity_quad_solve_above_112(sa, ora, k, monkeypatch):
     assert np.allclose(got["test_mse"], ref["test_mse"], rtol=1e-9, atol=0)
 
 
+@pytest.mark.parametrize("k", [3, 16, 17, 31, 40, 44, 47, 48])
+def test_c_ard_nmf_global_quad_solve_equals_the_lds_one(sa, ora, k, monkeypatch):
+    """The masked solve takes four columns per wave on the column's Gram in global memory from k = 40 on long launches (47 on
+    short ones) and on its LDS triangle below: same arithmetic in the same order, so the fits are the same bits whichever
+    runs (SGL_NNLS_QUAD_GLOBAL_FROM moves the limit), and the oracle's to 1e-9."""
+    m, n = 220, 260
+    A = ora.synth_csc(m, n, 20)
+    At = A.t()
+    w0 = ora.synth_winit(k, m)
+    ref = ora.c_ard_nmf(A, At, 0.0, 3, 0.01, 0.0, 0, w0, 77, 20, 1e-3, 1)
+    got = {}
+    for name, frm in (("lds", "1000"), ("global", "1")):
+        monkeypatch.setenv("SGL_NNLS_QUAD_GLOBAL_FROM", frm)
+        got[name] = sa.c_ard_nmf(to_dgc(sa, A), to_dgc(sa, At), 0.0, 3, False, 0.01, 0.0, 0, w0.T, 77, 20, 1e-3, 1)
+    for key in ("w", "h", "d", "test_mse", "tol"):
+        assert np.array_equal(got["lds"][key], got["global"][key]), key
+    _check(got["global"], ref)
+    assert np.allclose(got["global"]["test_mse"], ref["test_mse"], rtol=1e-9, atol=0)
+
+
 def test_c_ard_nmf_overfit_break(sa, ora):
     """A tiny overfit threshold makes the reference break out of the loop early; same here."""
     A = ora.synth_csc(200, 240, 20)
