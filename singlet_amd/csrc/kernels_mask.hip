@@ -118,7 +118,7 @@ __device__ __forceinline__ void static_for_rem(F_&& f) { static_for_rem_impl(f, 
 // tiles per epilogue batch (8 KB of LDS each); at least what the remainder partials need (REM * NB * 2 KB)
 constexpr int mg_tb(int ntiles, int rem, int nb) {
     // small tile sets run several workgroups per CU: keep their LDS small (17 KB of row queues + 8 KB per tile of the batch)
-    const int want = ntiles <= 6 ? 2 : (ntiles <= 15 ? 4 : 8), need = (rem * nb + 3) / 4;
+    const int want = ntiles <= 6 ? 2 : (ntiles <= 15 ? 4 : 8), need = ((rem < 4 ? rem : 4) * nb + 3) / 4;   // (the list kernel's remainder quads go through one at a time)
     return want > need ? want : need;
 }
 #define MG_TB(NTILES_, REM_, NB_) mg_tb(NTILES_, REM_, NB_)
@@ -389,8 +389,24 @@ int k_mask_gram_cols(hipStream_t s, int64_t col0, int64_t ncols, int32_t nrow, c
         if (lists) SGLCHK((launch_mask_gram_list<__VA_ARGS__>(g, b, s, col0, ncols, col_nnz, L, F, G, k, Gcols, raw)));            \
         else SGLCHK((launch_mask_gram_mfma<__VA_ARGS__>(g, b, s, col0, ncols, nrow, col_nnz, F, G, k, seed, sgl_div_make(inv_density), mask_t, col_offset, row_offset, Gcols, raw))); \
     } while (0)
-        // k = 16 NT + r with r <= 4: the remainder rows on the VALU (REM = 2 / 4) instead of NT + 1 more tiles
+        // k = 16 NT + r with 4 < r <= 8 at NT = 3 .. 5, from the lists: the remainder rows as two quads of quarter-MFMAs instead
+        // of NT + 1 more tiles.  A v_mfma_f64_4x4x4_4b costs ~22 cycles here, not a quarter of the 16x16x4's 64; measured
+        // (mask phase per iteration at 30 000 x 200 000, ms): k = 56 48.3 -> 43.0, 69 70.0 -> 63.1, 72 70.2 -> 63.0, 88 97.7 ->
+        // 90.6; it does not pay with three quads (k = 60 47.2 -> 47.3, 76 70.7 -> 72.9, 90 96.0 -> 95.1) or below NT = 3
+        // (k = 24 18.5 -> 22.8, 40 29.9 -> 29.8, 44 34.1 -> 35.9): those keep the tile count below, and so does the hashing kernel
         const int nt_full = k / 16, rem = k % 16;
+        if (lists && rem > 4 && rem <= 8 && nt_full >= 3 && nt_full <= 5 && !getenv("SGL_MASK_GRAM_NO_REM") && !getenv("SGL_MASK_GRAM_NO_REM8")) {
+#define SGL_MGL(NT_, REM_) SGLCHK((launch_mask_gram_list<NT_, 1, 0, REM_>(g, b, s, col0, ncols, col_nnz, L, F, G, k, Gcols, raw)))
+            switch (nt_full) {
+                case 3: SGL_MGL(3, 8); break;
+                case 4: SGL_MGL(4, 8); break;
+                default: SGL_MGL(5, 8); break;
+            }
+#undef SGL_MGL
+            HIPCHK(hipGetLastError());
+            return SGL_OK;
+        }
+        // k = 16 NT + r with r <= 4: the remainder rows as quarter-MFMAs (lists) / on the VALU (hashing kernel), REM = 2 / 4
         if (rem >= 1 && rem <= 4 && nt_full >= 1 && nt_full <= 6 && !getenv("SGL_MASK_GRAM_NO_REM")) {
             const int key = nt_full * 10 + (rem <= 2 ? 2 : 4);
             switch (key) {

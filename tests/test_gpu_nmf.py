@@ -93,6 +93,8 @@ def test_rcpp_predict(sa, ora, shape):
 
 
 @pytest.mark.parametrize("k,trace,maxit", [(6, 1, 4), (8, 2, 5), (5, 3, 4), (17, 2, 3), (20, 1, 3), (30, 2, 3), (36, 2, 2), (49, 2, 2), (50, 2, 2), (52, 2, 2), (66, 2, 2), (70, 2, 2), (83, 2, 2), (90, 1, 2), (100, 2, 2), (116, 2, 2),
+                                            # 4 < k % 16 <= 8 at NT = 3 .. 5: remainder rows as two quads of quarter-MFMAs (mask_gram_list_kernel<NT, 1, 0, 8>)
+                                            (53, 2, 2), (55, 2, 2), (56, 2, 2), (69, 2, 2), (72, 2, 2), (87, 2, 2), (88, 2, 2),
                                             # above 128: Gram downdates on the VALU in pair ranges, wave NNLS (any-rank path)
                                             (140, 2, 2), (260, 1, 1)])
 def test_c_ard_nmf_parity(sa, ora, k, trace, maxit):

@@ -83,11 +83,12 @@ def _mask_gram_oracle(ora, F, G, ncols, seed, inv_density, mask_t, col_off, row_
     return out
 
 
-@pytest.mark.parametrize("k", [1, 2, 5, 10, 16, 17, 18, 20, 30, 33, 36, 48, 50, 52, 64, 66, 70, 80, 84, 96, 98, 100, 104, 112, 128, 130])
+@pytest.mark.parametrize("k", [1, 2, 5, 10, 16, 17, 18, 20, 21, 24, 25, 28, 30, 33, 36, 37, 40, 41, 44, 48, 50, 52, 53, 56, 57, 60, 64, 66, 69, 70, 72,
+                               73, 76, 80, 84, 85, 88, 89, 92, 96, 98, 100, 104, 112, 128, 130])
 @pytest.mark.parametrize("use_lists", [False, True])
 def test_mask_gram_downdate(ctx, ora, k, use_lists):
     """Per-column Gram downdates of predict_mask, by the hashing kernel and from the mask lists (every tile-set
-    instance: full blocks, VALU remainder rows, a partial last block, two-part tile sets; k = 130: the VALU kernel,
+    instance: full blocks, remainder rows (one to three quads), a partial last block, two-part tile sets; k = 130: the VALU kernel,
     which ignores the lists), both orientations with offsets, raw sums; several hundred drawn rows per column
     (the pipelined loop of the list kernel) down to none."""
     rng = np.random.default_rng(500 + k)
@@ -106,7 +107,7 @@ def test_mask_gram_downdate(ctx, ora, k, use_lists):
 def test_mask_gram_lists_short_columns(ctx, ora, nrow):
     """Few rows: empty lists, one partial group, fewer groups than waves, the unpipelined tail only."""
     rng = np.random.default_rng(900 + nrow)
-    for k in (7, 50, 100):
+    for k in (7, 50, 100, 22, 43, 70, 90):
         F = rng.random((nrow, k)) + 0.1
         G = ora.aat(rng.random((2 * k, k)))
         for inv in (1, 2, 9):

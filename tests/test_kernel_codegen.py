@@ -227,7 +227,7 @@ def test_list_downdate_kernels_own_their_agprs(mask_asm):
     for name, nt, nparts, part, rem, body in kernels:
         nt, nparts, part, rem = int(nt), int(nparts), int(part), int(rem)
         ntiles = (nt * (nt + 1) // 2 - part + nparts - 1) // nparts
-        nreg = 8 * ntiles + (2 * (nt + 1) if rem else 0)
+        nreg = 8 * ntiles + 2 * (nt + 1) * ((rem + 3) // 4) if rem else 8 * ntiles   # tiles + remainder quads x column blocks
         in_asm = False
         for line in body.splitlines():
             if "#ASMSTART" in line:
