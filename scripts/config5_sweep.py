@@ -26,12 +26,6 @@ ctx.ard_run(0.0, 1, 0.01, 0.0, 1, 20, 1e9, 1)   # warm-up (module load, workspac
 rows, plain = [], {}
 t_all = time.perf_counter()
 for k in range(10, 101, 10):
-    ctx.fit_init(k, None)
-    ctx.nmf_run(0.0, 1, 0.01, 0.01, 0.0, 0.0)
-    ctx.fit_init(k, None)
-    t0 = time.perf_counter()
-    ctx.nmf_run(0.0, 3, 0.01, 0.01, 0.0, 0.0)
-    plain[k] = (time.perf_counter() - t0) / 3
     for rep in (1, 2, 3):
         t0 = time.perf_counter()
         ctx.fit_init(k, None, synth_seed=0x5EED + rep)          # a different initial w per replicate
@@ -41,6 +35,18 @@ for k in range(10, 101, 10):
                      "traces": len(r["test_mse"]), "test_mse": float(r["test_mse"][-1])})
         print(rows[-1], file=sys.stderr, flush=True)
 total = time.perf_counter() - t_all
+# seconds per plain (c_nmf) iteration at every rank, for the table in DESIGN.md: AFTER the grid and outside its wall time --
+# cross_validate_nmf runs masked fits only (rounds 1 - 3 timed these iterations inside the grid loop: ~3 s of their figures)
+t_plain = time.perf_counter()
+for k in range(10, 101, 10):
+    ctx.fit_init(k, None)
+    ctx.nmf_run(0.0, 1, 0.01, 0.01, 0.0, 0.0)
+    ctx.fit_init(k, None)
+    t0 = time.perf_counter()
+    ctx.nmf_run(0.0, 3, 0.01, 0.01, 0.0, 0.0)
+    plain[k] = (time.perf_counter() - t0) / 3
+t_plain = time.perf_counter() - t_plain
 print(json.dumps({"workload": "synthetic %d genes x %d cells, 5%% nnz, inv_density 20, cv_tol 1e-4, maxit %d, trace_test_mse %d, "
-                              "one resident context, fit set-up (entry streams) included in wall_s" % (genes, cells, maxit, trace),
-                  "generate_s": gen_s, "grid_wall_s": total, "sec_per_plain_iter": plain, "fits": rows}))
+                              "one resident context, fit set-up (entry streams, mask lists) included in wall_s" % (genes, cells, maxit, trace),
+                  "generate_s": gen_s, "grid_wall_s": total, "grid_is": "the 30 masked fits, nothing else (the plain-iteration timing below ran after them)",
+                  "plain_timing_wall_s": t_plain, "sec_per_plain_iter": plain, "fits": rows}))
