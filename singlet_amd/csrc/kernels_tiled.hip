@@ -356,8 +356,10 @@ int sgl_tiled_build(sgl_ctx* c, const DevCSC& M, int k, DevTiled& S) {
     const int r_bal = skewed ? (int)std::min<double>(256.0, ceil(top_share * 256.0 / 0.35)) : 1;
     if (r_bal > r_fill) {
         double best = -1.0;
-        // (a fill factor beyond the tile count leaves the range whole, as it always did: such a matrix is tiny)
+        // (a fill factor beyond the tile count: every tile its own range -- round 3 left the range whole there, "such a matrix is
+        // tiny", and the gene side of pbmc3k -- 14 column groups, 5 tiles, half of the non-zeros in the first group -- ran 1.07 ms)
         const int rmin = std::max(r_fill, (int)std::min<int64_t>(r_bal, std::max(1, S.T)));
+        if (rmin > S.T) R = std::max(1, S.T);
         for (int r = rmin; r <= std::min<int64_t>(S.T, rmin + rmin / 4 + 4); ++r) {
             const int tpr = (S.T + r - 1) / r;
             const int reff = (S.T + tpr - 1) / tpr;  // ranges actually non-empty
@@ -365,9 +367,12 @@ int sgl_tiled_build(sgl_ctx* c, const DevCSC& M, int k, DevTiled& S) {
             const double eff = wgs / (ceil(wgs / 256.0) * 256.0);
             if (eff > best + 1e-9) { best = eff; R = reff; }
         }
-    } else if (r_fill > 1 && S.T > 1 && E >= (4ll << 20) && !getenv("SGL_TILED_OLD_SPLIT")) {
-        // (below ~4 M entries a pass takes microseconds either way: the range stays whole and every b_j is summed in
-        // exactly the reference's order -- a split adds the ranges' partial sums, equal up to rounding)
+    } else if (r_fill > 1 && S.T > 1 && !getenv("SGL_TILED_OLD_SPLIT")) {
+        // (matrices of every size: for most of round 4 the range stayed whole below 4 M entries -- "a pass takes microseconds
+        // either way" -- and pbmc3k, 2.3 M non-zeros in 3 column groups of the quad layout, ran its 22 tiles on THREE CUs:
+        // 0.83 / 1.07 ms per pass where config 2, with 22 times the non-zeros, takes 0.21.  A split adds the ranges' partial
+        // sums: equal to the whole range up to rounding, and SGL_TILED_RANGES=1 keeps the reference's order for the tests that
+        // compare bits.)
         // Too few column groups to fill the chip: cut the tile range into R pieces (sizes floor / ceil of T / R).  Round 4:
         // R by a cost model instead of "the count of workgroups nearest a multiple of 256" -- that rule took R = T at
         // BASELINE config 2 in the quad layout (49 column groups x 32 tiles: 1568 workgroups of ONE tile each, every
