@@ -275,9 +275,20 @@ int sgl_tiled_build(sgl_ctx* c, const DevCSC& M, int k, DevTiled& S) {
     TR = TR / 8 * 8;
     if (TR > 984) TR = 984;  // groups per pair (+ <= 7 chunk-padding groups) must fit a byte
     if (TR < 8 || k > 64) { sgl_set_error("tiled accumulate: k=%d unsupported", k); return SGL_EINVAL; }
+    S.nwb = ((int64_t)M.ncol + S.CW - 1) / S.CW;
+    // A small matrix cannot fill the chip with LDS-sized tiles even when every tile is a range of its own (pbmc3k: 3 column
+    // groups x 22 tiles on the cell side, 14 x 5 on the gene side): shorter tiles -- at least 128 rows, so that a column still
+    // brings a few entries per tile -- until column groups x tiles reach the 256 CUs.  (SGL_TILED_FULL_TILES=1: tests of the
+    // chunk loop's extremes -- a column dense over a whole LDS-sized tile.)
+    {
+        const int64_t groups = (S.nwb + TILED_NW - 1) / TILED_NW, T0 = ((int64_t)M.nrow + TR - 1) / TR;
+        if (groups * T0 < 256 && !getenv("SGL_TILED_FULL_TILES")) {
+            const int64_t want = std::min<int64_t>((256 + groups - 1) / groups, ((int64_t)M.nrow + 127) / 128);
+            if (want > T0) TR = std::min<int>(TR, (int)(((((int64_t)M.nrow + want - 1) / want) + 7) / 8 * 8));
+        }
+    }
     S.TR = TR;
     S.T = (int)((M.nrow + TR - 1) / TR);
-    S.nwb = ((int64_t)M.ncol + S.CW - 1) / S.CW;
     S.ncol = M.ncol;
     S.nrow = M.nrow;
     S.src_nnz = M.nnz;

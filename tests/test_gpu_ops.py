@@ -176,6 +176,7 @@ def test_rhs_tiled_quad_layout_equals_the_pair_layout(sa, ora, k, monkeypatch):
     the quad layout (default) against the pair layout (SGL_TILED_NO_QUAD=1) and the plain kernel, bit for bit, and its
     stream is the one the layout query reports (128 columns per block, 632-row tiles)."""
     monkeypatch.setenv("SGL_TILED_RANGES", "1")   # bit for bit: the tile range whole (by default a matrix this small has it cut over the CUs)
+    monkeypatch.setenv("SGL_TILED_FULL_TILES", "1")   # ... and LDS-sized tiles (it would get shorter ones)
     A = ora.synth_csc(2500, 3000, 10)
     At = A.t()
     rng = np.random.default_rng(100 + k)
@@ -262,6 +263,7 @@ def test_rhs_tiled_pair_bookkeeping_extremes(ctx, ora, sa, shape, layout, monkey
     if layout == "pair":
         monkeypatch.setenv("SGL_TILED_NO_QUAD", "1")
     monkeypatch.setenv("SGL_TILED_RANGES", "1")   # bit for bit: the tile range whole
+    monkeypatch.setenv("SGL_TILED_FULL_TILES", "1")   # counts near the byte's limit need LDS-sized tiles
     rng = np.random.default_rng({"very_sparse": 1, "dense_blocks": 2, "one_pair_only": 3}[shape])
     m, n, k = 2300, 200, 10                     # k = 10: tiles of 984 rows (the cap; 632 in the quad layout)
     D = np.zeros((m, n))
@@ -308,6 +310,7 @@ def test_rhs_tiled_columns_sorted_by_count(sa, ora, k, monkeypatch):
     with skewed columns the padding shrinks, and since the order INSIDE a column is untouched the sums are bit for
     bit those of the matrix-order stream (SGL_TILED_SORT=0) and of the plain kernel."""
     monkeypatch.setenv("SGL_TILED_RANGES", "1")   # bit for bit: the tile range whole
+    monkeypatch.setenv("SGL_TILED_FULL_TILES", "1")   # the padding figures below are those of LDS-sized tiles
     A = _skewed_csc(ora, 1500, 700, 3)
     At = A.t()
     rng = np.random.default_rng(k)
@@ -333,9 +336,27 @@ def test_rhs_tiled_columns_sorted_by_count(sa, ora, k, monkeypatch):
 
 
 @pytest.mark.parametrize("k", [10, 50])
-def test_entry_stream_padding_on_pbmc3k(sa, ora, k):
+def test_entry_stream_padding_on_pbmc3k(sa, ora, k, monkeypatch):
     """The reference's own data (data/pbmc3k.RData: 13714 genes x 2700 cells, 3 ... 2700 non-zeros per gene): stored
-    entries per non-zero of both orientations.  In matrix order the gene side pads 1.76 - 1.81 x (round-2 verdict)."""
+    entries per non-zero of both orientations.  In matrix order the gene side pads 1.76 - 1.81 x (round-2 verdict).  With
+    LDS-sized tiles (SGL_TILED_FULL_TILES=1) the sorted stream stores at most 1.20 entries per non-zero; as the fit runs
+    it -- a matrix this small gets shorter tiles, so that column groups x tiles reach the 256 CUs -- the padding is the price
+    of the parallelism and stays below 1.9."""
+    import os
+    pads = {}
+    for full in ("1", None):
+        if full:
+            monkeypatch.setenv("SGL_TILED_FULL_TILES", full)
+        else:
+            monkeypatch.delenv("SGL_TILED_FULL_TILES")
+        pads[full] = _pbmc3k_layout(sa, ora, k)
+    (lay, nnz), (lay_short, _) = pads["1"], pads[None]
+    assert lay["A"]["entries"] / nnz <= 1.20 and lay["At"]["entries"] / nnz <= 1.20, (lay, nnz)
+    assert lay_short["A"]["tiles"] > lay["A"]["tiles"] and lay_short["At"]["tiles"] > lay["At"]["tiles"]
+    assert lay_short["A"]["entries"] / nnz <= 1.9 and lay_short["At"]["entries"] / nnz <= 1.9, (lay_short, nnz)
+
+
+def _pbmc3k_layout(sa, ora, k):
     import os
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pbmc3k_counts.npz"))
     p, dim = g["p"], g["dim"]
@@ -350,8 +371,7 @@ def test_entry_stream_padding_on_pbmc3k(sa, ora, k):
         lay = c.layout_get()
     finally:
         c.close()
-    nnz = int(p[-1])
-    assert lay["A"]["entries"] / nnz <= 1.20 and lay["At"]["entries"] / nnz <= 1.20, (lay, nnz)
+    return lay, int(p[-1])
 
 
 def test_skewed_generator_is_a_valid_consistent_matrix(sa, ora):
@@ -689,6 +709,8 @@ def test_rhs_tiled_random_structures(sa, ora, case, monkeypatch):
     ranges = int(rng.choice([0, 1, 1, 2, 3]))   # 0: the library's own choice (these matrices are small: usually a split)
     if ranges:
         monkeypatch.setenv("SGL_TILED_RANGES", str(ranges))
+    if case % 3 == 0:
+        monkeypatch.setenv("SGL_TILED_FULL_TILES", "1")   # LDS-sized tiles (row counts around the tile sizes); otherwise the short tiles of a small matrix
     A = _random_csc(ora, rng, m, n, style)
     if A.nnz == 0:
         A = _random_csc(ora, rng, m, n, "uniform")
