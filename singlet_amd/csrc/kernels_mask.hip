@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void mask_gram_mfma_kernel(int64_t col0, int64
         f[NB - 1] = ((NB - 1) * 16 + r16 < k) ? src[16 * (NB - 1)] : 0.0;
     };
     auto mfma_group = [&](const double (&f)[NB]) {
-        if (REM > 0) {   // the remainder rows on the VALU
+        if constexpr (REM > 0) {   // the remainder rows on the VALU
             static_for_rem<REM>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
                 const double v = mg_bcast<i>(f[NT]);

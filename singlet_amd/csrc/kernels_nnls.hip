@@ -535,7 +535,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGL_QG_WPE))
                 if (run_i) {
                     const bool have_i = have;
                     have = false;
-                    if (i + 1 < 16 * NR) {   // row i + 1, in flight during this coordinate -- if its coordinate moved last sweep
+                    if constexpr (i + 1 < 16 * NR) {   // row i + 1, in flight during this coordinate -- if its coordinate moved last sweep
                         const bool more = (i + 1 <= 16 * (NR - 1)) || (i + 1 < k);
                         constexpr int i1 = i + 1;
                         have = more && go && (act[i1 >> 5] & (1u << (i1 & 31))) != 0u;

@@ -539,7 +539,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     // stride the stream's offsets were built for, ldf / ldb = strides (doubles) between rows of F /
     // columns of the output, slab = doubles between the outputs of two tile ranges (blockIdx.y)
     constexpr int NSL = (MODE == 4 || MODE == 7) ? 4 : 2;
-    constexpr bool RING8 = MODE != 2;            // half-set / quad-set ring slots, eight deep
     constexpr bool PAIRRING = MODE == 3 || MODE == 6;
     asm volatile("" ::: "v255");
     extern __shared__ __attribute__((aligned(16))) char smem[];
