@@ -121,7 +121,17 @@ __global__ __launch_bounds__(1024) void nnls_pack_scan_kernel(uint32_t* __restri
     const int per = (total + 1023) / 1024;
     const int a = threadIdx.x * per, b = (a + per < total) ? a + per : total;
     unsigned s = 0;
-    for (int e = a; e < b; ++e) s += hist[e];
+    {   // (eight independent loads per step: one at a time the thread's ~60 strided reads were 90 us of pure latency per solve)
+        int e = a;
+        for (; e + 8 <= b; e += 8) {
+            unsigned v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = hist[e + q];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s += v[q];
+        }
+        for (; e < b; ++e) s += hist[e];
+    }
     part[threadIdx.x] = s;
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {
@@ -131,7 +141,17 @@ __global__ __launch_bounds__(1024) void nnls_pack_scan_kernel(uint32_t* __restri
         __syncthreads();
     }
     unsigned run = part[threadIdx.x] - s;
-    for (int e = a; e < b; ++e) { const unsigned c = hist[e]; hist[e] = run; run += c; }
+    {
+        int e = a;
+        for (; e + 8 <= b; e += 8) {
+            unsigned v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = hist[e + q];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { hist[e + q] = run; run += v[q]; }
+        }
+        for (; e < b; ++e) { const unsigned c = hist[e]; hist[e] = run; run += c; }
+    }
     if (threadIdx.x == 1023) *n_out = part[1023];
 }
 __global__ __launch_bounds__(256) void nnls_pack_scatter_kernel(const uint8_t* __restrict__ key, int64_t n, int nblocks,
