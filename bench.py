@@ -246,7 +246,12 @@ def report(args, run):
     bytes_h = nnz_local * (vb + 4) + 4 * (n_loc + 1) + k * n_loc * 8 + k * m * 8
     bytes_w = nnz_local * (vb + 4) + 4 * (m + 1) + k * n_loc * 8 + k * m * 8
     bytes_iter = 2 * nnz_total * (vb + 4) + 4 * (n + m + 2) + 2 * k * n * 8 + 3 * k * m * 8
-    ph_ms = {p: (v[0] / args.steps) for p, v in phases.items()}
+    # every rank's hipEvent phases (rank order); the headline phases are the MAX over the ranks -- an iteration ends when
+    # the slowest rank has delivered its part of the exchange -- and `per_rank` keeps each rank's own figures, so that a
+    # straggler or a slow collective shows in the first multi-GPU record
+    phases_all = run.get("phases_all") or [phases]
+    per_rank_ms = [{p: (v[0] / args.steps) for p, v in ph.items()} for ph in phases_all]
+    ph_ms = {p: max(r[p] for r in per_rank_ms) for p in per_rank_ms[0]}
     rhs_h_ms, rhs_w_ms = ph_ms["rhs_h"], ph_ms["rhs_w"]
     dom = "rhs_h" if rhs_h_ms >= rhs_w_ms else "rhs_w"
     dom_ms = max(rhs_h_ms, rhs_w_ms)
@@ -307,9 +312,20 @@ def report(args, run):
                      "whole_iteration": {"algorithmic_bytes": bytes_iter, "achieved": bytes_iter / (ms_step * 1e-3) / 1e9 / world,
                                          "frac": bytes_iter / (ms_step * 1e-3) / 1e9 / world / HBM_PEAK_GBS}},
         "phases_ms_per_step": ph_ms,
+        "phases_are": "max over the %d rank(s) of each phase's hipEvent time per iteration" % len(per_rank_ms),
         "comm": dict(comm, per_iteration=COMM_PER_ITERATION[comm["mode"]]),
         "tol_last": run["tols"][-1], "generate_s": run["gen_s"],
     }
+    if len(per_rank_ms) > 1 or run.get("rank_info"):
+        info = run.get("rank_info") or [{} for _ in per_rank_ms]
+        out["per_rank"] = [dict(info[r], rank=r, phases_ms_per_step=per_rank_ms[r], sum_of_phases_ms=sum(per_rank_ms[r].values()),
+                                comm_ms=per_rank_ms[r].get("comm", 0.0)) for r in range(len(per_rank_ms))]
+        # compute = everything but the exchange; a rank's comm phase holds its wait for the slowest rank plus the transfer
+        sums = [r["sum_of_phases_ms"] - r["comm_ms"] for r in out["per_rank"]]
+        out["rank_imbalance"] = {"slowest_rank_by_compute": int(max(range(len(sums)), key=lambda q: sums[q])),
+                                 "max_over_min_compute": max(sums) / max(min(sums), 1e-12),
+                                 "note": "comm_ms = wait for the slowest rank + transfer: the straggler shows the SMALLEST comm_ms",
+                                 "comm_ms_max": max(r["comm_ms"] for r in out["per_rank"]), "comm_ms_min": min(r["comm_ms"] for r in out["per_rank"])}
     if run.get("loopback"):
         out["loopback"] = True
         out["config"]["parallelism"] = "cells/%d, all ranks on ONE device (loopback rehearsal, not a scaling point)" % world
@@ -374,18 +390,23 @@ def run_single_process(args, pl):
         if not pl["loopback"] and (not info["is_rccl"] or info["nranks"] != world):
             raise SystemExit("bench.py: the library's communicator spans %d ranks (rccl=%s), asked for %d"
                              % (info["nranks"], info["is_rccl"], world))
-        c0.sweeps_get(reset=True)
-        c0.timing_enable(True)
-        c0.timing_get(reset=True)
-        t0 = time.perf_counter()          # all streams idle: the last warm-up iterate() read every rank's tol
+        for c in ranks:
+            c.sweeps_get(reset=True)      # reads the rank's counters behind a stream synchronise: EVERY rank's stream is idle
+            c.timing_enable(True)         # before t0, whatever --warmup was (0 included: fit_init's asynchronous tail)
+            c.timing_get(reset=True)
+        t0 = time.perf_counter()
         tols = [step() for _ in range(args.steps)]
-        elapsed = time.perf_counter() - t0
-        phases = c0.timing_get(reset=True)
-        c0.timing_enable(False)
+        elapsed = time.perf_counter() - t0    # iterate() returns when every rank's tol has been read: all streams idle again
+        phases_all = [c.timing_get(reset=True) for c in ranks]
+        for c in ranks:
+            c.timing_enable(False)
+        phases = phases_all[0]
         m = dims[0][0]
         mb = (m + world - 1) // world if world > 1 else m
         run = {"world": world, "elapsed": elapsed, "tols": tols, "dims": dims[0], "nnz_total": int(sum(d[2] for d in dims)),
-               "phases": phases, "sweeps": c0.sweeps_get(reset=True), "layout": c0.layout_get(), "gen_s": gen_s,
+               "phases": phases, "phases_all": phases_all,
+               "rank_info": [{"device": int(pl["devices"][r]), "cells": int(dims[r][1]), "nnz": int(dims[r][2])} for r in range(world)],
+               "sweeps": c0.sweeps_get(reset=True), "layout": c0.layout_get(), "gen_s": gen_s,
                "w_cols_rank0": min(mb, m), "loopback": pl["loopback"],
                "comm": {"mode": "loopback" if pl["loopback"] else "native-single-process", "note": None,
                         "rccl_nranks": info["nranks"] if info["is_rccl"] else None, "rccl_path": info["path"] or None,
@@ -551,14 +572,19 @@ def main():
     layout = ctx.layout_get()
 
     nnz_total = nnz_local
+    phases_all, rank_info = [phases], [{"device": int(local_rank), "cells": int(n_loc), "nnz": int(nnz_local)}]
     if dist is not None:
         elapsed = reduce_host([elapsed], dist.ReduceOp.MAX)[0]
         nnz_total = int(reduce_host([float(nnz_local)], dist.ReduceOp.SUM)[0])
+        got = [None] * world
+        dist.all_gather_object(got, (phases, rank_info[0]))
+        phases_all, rank_info = [g[0] for g in got], [g[1] for g in got]
 
     if rank == 0:
         mb = (m + world - 1) // world if (world > 1 and mode == "native") else m
         out = report(args, {"world": world, "elapsed": elapsed, "tols": tols, "dims": (m, n_loc, nnz_local), "nnz_total": nnz_total,
-                            "phases": phases, "sweeps": sweeps, "layout": layout, "gen_s": gen_s, "w_cols_rank0": min(mb, m),
+                            "phases": phases, "phases_all": phases_all, "rank_info": rank_info if world > 1 else None,
+                            "sweeps": sweeps, "layout": layout, "gen_s": gen_s, "w_cols_rank0": min(mb, m),
                             "comm": {"mode": mode, "note": comm_note, "rccl_nranks": comm_info["nranks"] if comm_info["is_rccl"] else None,
                                      "rccl_path": comm_info["path"] or None,
                                      "host_coordination": None if dist is None else dist.get_backend(),

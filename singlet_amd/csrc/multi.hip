@@ -31,7 +31,10 @@
 #include <string.h>
 #include <stdlib.h>
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
+#include <memory>
 #include <functional>
 #include <mutex>
 #include <string>
@@ -46,6 +49,7 @@ struct RcclApi {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;   // optional: a build without it can only destroy
     ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*ReduceScatter)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
@@ -80,6 +84,7 @@ static RcclApi* rccl_api() {
             api.CommInitRank = (decltype(api.CommInitRank))bind("ncclCommInitRank");
             api.CommInitAll = (decltype(api.CommInitAll))bind("ncclCommInitAll");
             api.CommDestroy = (decltype(api.CommDestroy))bind("ncclCommDestroy");
+            api.CommAbort = (decltype(api.CommAbort))dlsym(api.handle, "ncclCommAbort");
             api.CommCount = (decltype(api.CommCount))bind("ncclCommCount");
             api.AllReduce = (decltype(api.AllReduce))bind("ncclAllReduce");
             api.ReduceScatter = (decltype(api.ReduceScatter))bind("ncclReduceScatter");
@@ -126,7 +131,12 @@ struct TeamPool {
     // host barrier of the workers (loopback exchange only); `failed` releases everybody when a rank has given up
     int bar_count = 0;
     uint64_t bar_gen = 0;
-    bool failed = false;
+    std::atomic<bool> failed{false};
+    // RCCL drive: exchange steps enqueued by any worker during the running call.  A rank that fails while a peer has a
+    // collective in flight (or is about to enqueue one) would leave that peer blocked for ever in its next host wait --
+    // the kernels of a collective only return when every rank has joined -- so the failing worker aborts the team's
+    // communicators (team_abort): `enq` and `failed` are read / written in the order that closes the window (team_exchange).
+    std::atomic<int> enq{0};
 };
 
 struct sgl_team {
@@ -135,6 +145,10 @@ struct sgl_team {
     std::vector<sgl_ctx*> local;   // the ranks this process drives
     std::vector<int> rank;         // team rank of local[i]
     std::vector<ncclComm_t> comm;  // per local rank; empty in loopback mode
+    // comm[i] is used by rank i's worker thread only -- except when a failure makes another thread abort it: the owner holds
+    // comm_mu[i] while it enqueues on it (microseconds: RCCL's launch does not wait for the peers), the aborting thread takes it
+    std::vector<std::unique_ptr<std::timed_mutex>> comm_mu;
+    std::atomic<bool> broken{false};   // communicators aborted after a failure: every later call on the team is refused
     bool loopback = false;
     std::vector<hipEvent_t> ev;    // loopback: stream ordering
     hipEvent_t done = nullptr;
@@ -156,6 +170,7 @@ void sgl_team_detach(sgl_ctx* c) {
             T->local.erase(T->local.begin() + i);
             T->rank.erase(T->rank.begin() + i);
             if (i < T->comm.size()) T->comm.erase(T->comm.begin() + i);
+            if (i < T->comm_mu.size()) T->comm_mu.erase(T->comm_mu.begin() + i);
             break;
         }
     c->team = nullptr;
@@ -164,6 +179,35 @@ void sgl_team_detach(sgl_ctx* c) {
         if (T->done) (void)hipEventDestroy(T->done);
         delete T;
     }
+}
+
+// A rank has failed (or a call has timed out) while collectives may be in flight: abort every local communicator, which
+// makes the kernels of the pending collectives return on all devices, so that the peers' host waits (stream
+// synchronisation, implicit synchronisation inside hipMalloc / hipFree ...) come back and their next exchange step is
+// refused (`broken`).  Once per team; the team cannot be used afterwards, only destroyed.
+static void team_abort(sgl_team* T) {
+    bool expected = false;
+    if (!T->broken.compare_exchange_strong(expected, true)) return;
+    if (T->loopback || T->comm.empty()) return;
+    RcclApi* R = rccl_api();
+    if (!R) return;
+    for (size_t i = 0; i < T->comm.size(); ++i) {
+        std::unique_lock<std::timed_mutex> lk;
+        if (i < T->comm_mu.size() && T->comm_mu[i]) {
+            lk = std::unique_lock<std::timed_mutex>(*T->comm_mu[i], std::defer_lock);
+            (void)lk.try_lock_for(std::chrono::seconds(2));   // an owner stuck inside an enqueue must not stop the abort
+        }
+        if (T->comm[i]) {
+            if (R->CommAbort) (void)R->CommAbort(T->comm[i]);
+            else (void)R->CommDestroy(T->comm[i]);
+            T->comm[i] = nullptr;
+        }
+    }
+}
+
+static int team_refused(const sgl_team* T) {
+    if (T->broken.load()) { sgl_set_error("team: the communicators were aborted after a failure on one rank; destroy the team"); return SGL_ECOMM; }
+    return SGL_OK;
 }
 
 // ------------------------------------------------------------ loopback kernels --
@@ -232,9 +276,15 @@ static void pool_worker(sgl_team* T, int i) {
             P->rc[i] = rc;
             if (rc != SGL_OK) {
                 P->err[i] = sgl_last_error();
-                P->failed = true;          // releases ranks waiting in team_barrier
+                P->failed = true;          // releases ranks waiting in team_barrier; no worker enqueues an exchange step any more
                 P->cv_bar.notify_all();
             }
+        }
+        // RCCL drive: a peer that has enqueued (or was just about to enqueue) an exchange step of this call waits on the
+        // device for this rank, which will never join: abort the communicators so that its host wait returns
+        if (rc != SGL_OK && !T->loopback && P->enq.load() > 0) team_abort(T);
+        {
+            std::lock_guard<std::mutex> lk(P->mu);
             if (--P->pending == 0) P->cv_done.notify_one();
         }
     }
@@ -277,6 +327,7 @@ template <typename F>
 static int team_parallel(sgl_team* T, F&& fn) {
     const int n = (int)T->local.size();
     TeamPool* P = T->pool;
+    SGLCHK(team_refused(T));
     if (!P) {
         for (int i = 0; i < n; ++i) {
             HIPCHK(hipSetDevice(T->local[i]->device));
@@ -284,17 +335,38 @@ static int team_parallel(sgl_team* T, F&& fn) {
         }
         return SGL_OK;
     }
+    bool timed_out = false;
     {
         std::unique_lock<std::mutex> lk(P->mu);
         P->job = [&fn](int i) -> int { return fn(i); };
         P->failed = false;
+        P->enq = 0;
         P->bar_count = 0;
         std::fill(P->rc.begin(), P->rc.end(), (int)SGL_OK);
         P->pending = n;
         ++P->gen;
         P->cv_go.notify_all();
+        // Watchdog: a library call on a team is seconds at most (an iteration is milliseconds, the set-up of a fit seconds).
+        // When the workers are not back after SGL_TEAM_TIMEOUT_S (default 600 s, 0 = wait for ever) something is blocked for
+        // good -- a rank that never joined a collective -- and the call gives up instead of hanging its host: the ranks
+        // waiting at the host barrier are released, the communicators aborted (their kernels return), and the call reports
+        // SGL_ECOMM once the workers are back.
+        const char* te = getenv("SGL_TEAM_TIMEOUT_S");
+        const double tmo = te ? atof(te) : 600.0;
+        if (tmo > 0 && !P->cv_done.wait_for(lk, std::chrono::duration<double>(tmo), [&] { return P->pending == 0; })) {
+            timed_out = true;
+            P->failed = true;
+            P->cv_bar.notify_all();
+            lk.unlock();
+            team_abort(T);
+            lk.lock();
+        }
         P->cv_done.wait(lk, [&] { return P->pending == 0; });
         P->job = nullptr;
+    }
+    if (timed_out) {
+        sgl_set_error("team: the call did not come back within SGL_TEAM_TIMEOUT_S; ranks released, communicators aborted");
+        return SGL_ECOMM;
     }
     for (int i = 0; i < n; ++i)
         if (P->rc[i] != SGL_OK) {
@@ -423,6 +495,7 @@ static int xfer_issue(sgl_team* T, int i0, int i1, const Xfer& x) {
 }
 static int team_exchange(sgl_team* T, int who, std::initializer_list<Xfer> ops) {
     const int nl = (int)T->local.size();
+    SGLCHK(team_refused(T));
     if (who < 0) {
         std::vector<PhaseEvent> pe(nl);
         for (int i = 0; i < nl; ++i) {
@@ -443,6 +516,11 @@ static int team_exchange(sgl_team* T, int who, std::initializer_list<Xfer> ops) 
     }
     sgl_ctx* c = T->local[who];
     HIPCHK(hipSetDevice(c->device));
+    {   // test hook (tests/test_gpu_native_team.py): SGL_TEAM_TEST_STALL="rank:seconds" -- that rank's worker sleeps in front of
+        // every exchange step, as a rank blocked on the host would; read once per process
+        static const struct Stall { int rank = -1; double sec = 0; Stall() { if (const char* e = getenv("SGL_TEAM_TEST_STALL")) (void)sscanf(e, "%d:%lf", &rank, &sec); } } stall;
+        if (stall.rank == T->rank[who] && stall.sec > 0) std::this_thread::sleep_for(std::chrono::duration<double>(stall.sec));
+    }
     PhaseEvent pe;
     SGLCHK(sgl_phase_begin(c, SGL_PH_COMM, &pe));
     if (T->loopback) {
@@ -453,6 +531,16 @@ static int team_exchange(sgl_team* T, int who, std::initializer_list<Xfer> ops) 
         }
         SGLCHK(team_barrier(T));
     } else {
+        // enq first, failed second (the failing worker writes failed first, reads enq second): either this rank sees the
+        // failure and enqueues nothing, or the failing rank sees the pending step and aborts the communicators
+        TeamPool* P = T->pool;
+        if (P) {
+            P->enq.fetch_add(1);
+            if (P->failed.load()) { sgl_set_error("team: another rank failed"); return SGL_ECOMM; }
+        }
+        std::unique_lock<std::timed_mutex> lk;
+        if ((size_t)who < T->comm_mu.size() && T->comm_mu[who]) lk = std::unique_lock<std::timed_mutex>(*T->comm_mu[who]);
+        SGLCHK(team_refused(T));
         SGLCHK(group_begin(T));
         int rc = SGL_OK;
         for (const Xfer& x : ops)
@@ -506,6 +594,7 @@ static int team_gene_counts(sgl_team* T) {
 #define TEAM_GUARD(T)                                                                                 \
     do {                                                                                              \
         if ((T) == nullptr || (T)->local.empty()) { sgl_set_error("null or empty team"); return SGL_EINVAL; } \
+        SGLCHK(team_refused(T));                                                                      \
     } while (0)
 
 // W is replicated, so tol = cor(w, w_prev) must come out bit-identical on every local rank: checked on every
@@ -1018,6 +1107,7 @@ extern "C" int sgl_multi_create(int ndev, const int* devices, sgl_multi** out) {
         if (!R) rc = SGL_ECOMM;
         else {
             M->comm.assign(ndev, nullptr);
+            for (int i = 0; i < ndev; ++i) M->comm_mu.emplace_back(new std::timed_mutex());
             ncclResult_t r = R->CommInitAll(M->comm.data(), ndev, dev.data());
             if (r != ncclSuccess) { sgl_set_error("ncclCommInitAll failed: %s", R->GetErrorString(r)); M->comm.clear(); rc = SGL_ECOMM; }
         }

@@ -69,3 +69,48 @@ def test_too_few_devices_exits_non_zero_with_a_message():
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode != 0
     assert "device" in r.stderr and "{" not in r.stdout
+
+
+def _fake_run(world, slow_rank=None):
+    names = ("gram", "rhs_h", "nnls_h", "rhs_w", "nnls_w", "scale", "comm", "mask")
+    base = {"gram": 0.9, "rhs_h": 12.4, "nnls_h": 9.1, "rhs_w": 12.0, "nnls_w": 3.0, "scale": 1.4, "comm": 2.0, "mask": 0.0}
+    phases_all = []
+    for r in range(world):
+        ph = {n: (base[n] * (1.5 if (r == slow_rank and n in ("rhs_h", "rhs_w")) else 1.0), 10) for n in names}
+        if slow_rank is not None and r != slow_rank:
+            ph["comm"] = (base["comm"] + 12.0, 20)      # the others wait for the straggler inside the collective
+        phases_all.append(ph)
+    lay = {"entries": 1000, "tiles": 3, "tile_rows": 408, "tile_ranges": 1, "col_blocks": 8}
+    return {"world": world, "elapsed": 0.5, "tols": [0.1] * 10, "dims": (300, 1000 // world, 15000 // world), "nnz_total": 15000,
+            "phases": phases_all[0], "phases_all": phases_all,
+            "rank_info": [{"device": r, "cells": 1000 // world, "nnz": 15000 // world} for r in range(world)],
+            "sweeps": {"h_sweeps": 100, "w_sweeps": 10, "h_wave_sweeps": 10, "w_wave_sweeps": 4}, "layout": {"A": lay, "At": lay},
+            "gen_s": 0.1, "w_cols_rank0": 300 // world,
+            "comm": {"mode": "native-single-process", "note": None, "rccl_nranks": world, "rccl_path": "librccl.so.1",
+                     "host_coordination": "none", "devices": list(range(world)), "tol_bit_identical_across_ranks": True}}
+
+
+def test_report_carries_every_ranks_phases_and_the_comm_phase():
+    """The first N > 1 record must diagnose itself: headline phases = max over the ranks, `per_rank` = each rank's own
+    hipEvent phases incl. `comm`, and the slowest rank is named."""
+    import json
+    args = bench.parse(["--gpus", "4", "--steps", "10", "--genes", "300", "--cells", "1000", "--k", "5", "--no-cpu-baseline"])
+    out = bench.report(args, _fake_run(4, slow_rank=2))
+    json.dumps(out)
+    assert len(out["per_rank"]) == 4 and [r["rank"] for r in out["per_rank"]] == [0, 1, 2, 3]
+    assert out["per_rank"][2]["phases_ms_per_step"]["rhs_h"] == pytest.approx(1.86)
+    assert out["phases_ms_per_step"]["rhs_h"] == pytest.approx(1.86)          # the max over ranks, not rank 0's 1.24
+    assert out["phases_ms_per_step"]["comm"] == pytest.approx(1.4)            # a waiting rank's collective
+    assert out["per_rank"][2]["comm_ms"] == pytest.approx(0.2)                # the straggler itself does not wait
+    assert out["rank_imbalance"]["comm_ms_max"] == pytest.approx(1.4) and out["rank_imbalance"]["comm_ms_min"] == pytest.approx(0.2)
+    assert out["roofline"]["ms_per_pass"] == pytest.approx(1.86)
+    # one rank: no per-rank block unless the run brings rank_info
+    one = _fake_run(1)
+    one["rank_info"] = None
+    assert "per_rank" not in bench.report(args, one)
+
+
+def test_report_names_the_straggler_by_its_compute_time():
+    args = bench.parse(["--gpus", "4", "--steps", "10", "--genes", "300", "--cells", "1000", "--k", "5", "--no-cpu-baseline"])
+    out = bench.report(args, _fake_run(4, slow_rank=2))
+    assert out["rank_imbalance"]["slowest_rank_by_compute"] == 2 and out["rank_imbalance"]["max_over_min_compute"] > 1.2

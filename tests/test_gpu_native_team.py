@@ -244,3 +244,44 @@ def test_bench_launcher_free_forms_print_one_json_line(argv, mode, n):
     if mode == "native-single-process":
         assert d["comm"]["rccl_nranks"] == 1
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(d["roofline"])
+
+
+def test_team_call_times_out_instead_of_hanging():
+    """A rank whose worker is blocked on the host (test hook SGL_TEAM_TEST_STALL) keeps its peers waiting for its part of the
+    exchange.  The watchdog of the team call (SGL_TEAM_TIMEOUT_S) must release them and report SGL_ECOMM instead of hanging
+    the host, and the team must refuse further calls (its communicators count as aborted).  Own process: both switches
+    are read once."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, time
+sys.path.insert(0, %r)
+import numpy as np
+import singlet_amd as sa
+from oracle import oracle as ora
+A = ora.synth_csc(150, 400, 10)
+dA = sa.dgCMatrix(A.x, A.i, A.p, (A.nrow, A.ncol))
+M = sa.Multi([0, 0, 0])
+M.upload(dA)
+t0 = time.time()
+try:
+    M.fit_init(6, ora.synth_winit(6, 150))     # its gene-count all-reduce is the first exchange step
+    print("NO-ERROR")
+except sa.SingletHipError as e:
+    print("ERR1", round(time.time() - t0, 1), str(e))
+try:
+    M.iterate(0.01, 0.01, 0.0, 0.0)
+    print("NO-ERROR-2")
+except sa.SingletHipError as e:
+    print("ERR2", str(e))
+M.close()
+print("CLOSED")
+''' % root
+    env = dict(os.environ, SGL_TEAM_TEST_STALL="1:6", SGL_TEAM_TIMEOUT_S="1.5")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    out = r.stdout
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "ERR1" in out and "did not come back" in out, out
+    assert "ERR2" in out and "aborted" in out, out
+    assert "CLOSED" in out and "NO-ERROR" not in out, out
