@@ -456,8 +456,9 @@ SGL_API int sgl_op_mse_test(sgl_ctx* ctx, uint64_t seed, uint64_t inv_density, d
 #define SGL_PH_NNLS_W 4
 #define SGL_PH_SCALE 5     /* row sums, scale, cor, copies */
 #define SGL_PH_COMM 6      /* all-reduce callback */
-#define SGL_PH_MASK 7      /* masked-path extras: Gram downdates, mse_test */
-#define SGL_PH_COUNT 8
+#define SGL_PH_MASK 7      /* masked path: the per-column Gram downdates of predict_mask (src/singlet.cpp:458-463), mask lists */
+#define SGL_PH_MSE 8       /* masked path: mse_test (src/singlet.cpp:536-568), one call per trace row */
+#define SGL_PH_COUNT 9
 /* Enable/disable per-phase timing (costs two event records per kernel group). */
 SGL_API int sgl_timing_enable(sgl_ctx* ctx, int on);
 /* ms[SGL_PH_COUNT] accumulated since the last reset, calls[SGL_PH_COUNT] launches. */
@@ -479,6 +480,11 @@ SGL_API int sgl_layout_get(sgl_ctx* ctx, int64_t* out10);
  * among the last SGL_MASK_KEEP + 1 (default 3: R's n_replicates, R/ard_nmf.R:20) reuses the lists of drawn entries --
  * the mask does not depend on the rank. */
 SGL_API int sgl_layout_builds(sgl_ctx* ctx, int64_t* out4);
+/* Drawn (cell, gene) pairs of the mask the current fit runs under -- the entries predict_mask leaves out and mse_test scores
+ * (src/singlet.cpp:445-448: rng(seed).draw(inv_density, ...) true), as this shard's lists hold them: out2 = pairs listed
+ * per cell (H-update), per gene (W-update); 0 where the lists are not built (no masked pass yet, or the hashing kernels run).
+ * One masked iteration forms out2[0] + out2[1] rank-one downdates w_r w_r^T: the work unit of the measurement in bench.py. */
+SGL_API int sgl_mask_pairs(sgl_ctx* ctx, int64_t* out2);
 
 #ifdef __cplusplus
 }

@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SGL_LIB_PATH", os.path.join(_HERE, "libsinglet_hip.so"))  # override: kernel ablation builds only
 
-SGL_PH_NAMES = ("gram", "rhs_h", "nnls_h", "rhs_w", "nnls_w", "scale", "comm", "mask")
+SGL_PH_NAMES = ("gram", "rhs_h", "nnls_h", "rhs_w", "nnls_w", "scale", "comm", "mask", "mse")
 SGL_PH_COUNT = len(SGL_PH_NAMES)
 
 f64p = C.POINTER(C.c_double)
@@ -134,6 +134,7 @@ SIGNATURES = {
     "sgl_sweeps_get": (C.c_int, [C.c_void_p, i64p, C.c_int]),
     "sgl_layout_get": (C.c_int, [C.c_void_p, i64p]),
     "sgl_layout_builds": (C.c_int, [C.c_void_p, i64p]),
+    "sgl_mask_pairs": (C.c_int, [C.c_void_p, i64p]),
 }
 
 _lib = None
@@ -147,8 +148,14 @@ def load():
             raise SingletHipError(-2, "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                                       "or `make -C singlet_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
         L = C.CDLL(LIB_PATH)
+        override = "SGL_LIB_PATH" in os.environ   # an A/B build of an older tree may lack the newest symbols: bind what it has
         for name, (res, args) in SIGNATURES.items():
-            fn = getattr(L, name)  # AttributeError if the library does not export it
+            try:
+                fn = getattr(L, name)  # AttributeError if the library does not export it
+            except AttributeError:
+                if override:
+                    continue
+                raise
             fn.restype = res
             fn.argtypes = args
         _lib = L

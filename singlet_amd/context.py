@@ -382,6 +382,12 @@ class Context:
         keys = ("entries", "tiles", "tile_rows", "tile_ranges", "col_blocks")
         return {name: dict(zip(keys, (int(v) for v in out[5 * o:5 * o + 5]))) for o, name in enumerate(("A", "At"))}
 
+    def mask_pairs(self):
+        """(pairs listed per cell, per gene) of the mask the current fit runs under (sgl_mask_pairs; 0 where no lists are built)."""
+        out = np.zeros(2, dtype=np.int64)
+        check(self._L.sgl_mask_pairs(self._h, ptr(out, i64p)))
+        return int(out[0]), int(out[1])
+
     def layout_builds(self):
         """(stream of A, of At, mask lists of the cell side, of the gene side): times each has been written on this context
         (a re-init at an unchanged rank adds no stream, a masked fit under a recently used seed no lists)."""

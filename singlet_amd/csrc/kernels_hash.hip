@@ -241,6 +241,25 @@ __global__ __launch_bounds__(256) void validate_csc_kernel(const int32_t* __rest
     if (bad) atomicOr(flag, bad);
 }
 
+// flag |= 4 when a value is NaN or +-Inf.  The reference would carry such a value into every factor (each b is a sum over
+// the column, src/singlet.cpp:341-343); the shared-Gram solve here assumes finite right-hand sides (nnls_static_for.h:
+// the branch-free step), so non-finite input is refused at the door instead.  Call after k_validate_csc (which clears the flag).
+__global__ __launch_bounds__(256) void all_finite_kernel(const double* __restrict__ x, int64_t n, int* __restrict__ flag) {
+    int bad = 0;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const double v = x[e];
+        if (!(__builtin_fabs(v) < __builtin_inf())) bad = 4;
+    }
+    if (bad) atomicOr(flag, bad);
+}
+
+int k_all_finite(hipStream_t s, const double* x, int64_t n, int* flag_dev) {
+    if (n <= 0) return SGL_OK;
+    all_finite_kernel<<<dim3((unsigned)std::min<int64_t>((n + 255) / 256, 8192)), dim3(256), 0, s>>>(x, n, flag_dev);
+    HIPCHK(hipGetLastError());
+    return SGL_OK;
+}
+
 int k_validate_csc(hipStream_t s, const int32_t* idx, const int64_t* p, int64_t ncol, int32_t nrow, int* flag_dev) {
     if (ncol <= 0) return SGL_OK;
     HIPCHK(hipMemsetAsync(flag_dev, 0, sizeof(int), s));

@@ -269,6 +269,7 @@ __global__ __launch_bounds__(256) void nnls_wave_kernel(const double* __restrict
         if (col_nnz != nullptr && col_nnz[col] == 0) continue;
         const double* Gc = G + col * gstride;
         double b[R], x[R], gd[R], rg[R];
+        bool irr = false;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int j = lane + 64 * r;
@@ -276,7 +277,9 @@ __global__ __launch_bounds__(256) void nnls_wave_kernel(const double* __restrict
             x[r] = (j < k) ? X[col * k + j] : 0.0;
             gd[r] = (j < k) ? Gc[(int64_t)j * k + j] : 1.0;
             rg[r] = 1.0 / gd[r];   // correctly rounded reciprocal of this column's diagonal, once per column
+            irr = irr || !__builtin_isnormal(rg[r]);
         }
+        const bool any_irr = __ballot(irr) != 0ull;   // a zero (or otherwise irregular) diagonal entry: the reference's own division there
         double tol = 1.0;
         int it = 0;
         for (; it < 100 && (tol / kd) > 1e-8; ++it) {
@@ -290,10 +293,9 @@ __global__ __launch_bounds__(256) void nnls_wave_kernel(const double* __restrict
                 }
                 const double bi = rl64(bsel, il), xi = rl64(xsel, il), gii = rl64(gsel, il), rii = rl64(rsel, il);
                 // b_i / g_ii from the reciprocal (Markstein correction; see nnls_lane.h), then l.235-247
-                const double q0 = bi * rii;
-                const double diff0 = fma(fma(-q0, gii, bi), rii, q0);
+                const double diff0 = sgl_nnls_quotient(bi, gii, rii, any_irr);
                 double xn = xi, dpen;
-                const double nd = sgl_nnls_nd(diff0, xi, true, L1, L2, dpen);
+                const double nd = sgl_nnls_nd_strict(diff0, xi, true, L1, L2, dpen);
                 if (nd != 0.0) {  // wave-uniform; at rest: x, tol and b stay as they are
                     sgl_nnls_apply(dpen, nd, xn, tol);
 #pragma unroll
@@ -391,6 +393,7 @@ __global__ __launch_bounds__(64) void nnls_quad_kernel(const double* __restrict_
             }
         }
         double b[NR], x[NR], rg[NR];
+        bool irr = false;
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             const int j = l + 16 * r;
@@ -398,7 +401,9 @@ __global__ __launch_bounds__(64) void nnls_quad_kernel(const double* __restrict_
             b[r] = v ? B[col * k + j] : 0.0;
             x[r] = v ? X[col * k + j] : 0.0;
             rg[r] = v ? 1.0 / Gc[(int64_t)j * k + j] : 1.0;   // correctly rounded reciprocal of the diagonal
+            irr = irr || !__builtin_isnormal(rg[r]);
         }
+        const bool any_irr = __ballot(irr) != 0ull;   // a zero (or otherwise irregular) diagonal entry in one of the four columns
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
         double tol = 1.0;
@@ -427,10 +432,9 @@ __global__ __launch_bounds__(64) void nnls_quad_kernel(const double* __restrict_
                         else if (r > ir) g[r] = tri[trij[r] + i];                // j > i: a[j, i]
                         else g[r] = tri[(l <= il) ? (ti + l + 16 * r) : (trij[r] + i)];
                     }
-                    const double q0 = bi * rii;
-                    const double diff0 = fma(fma(-q0, gii, bi), rii, q0);   // b_i / g_ii (Markstein, see nnls_lane.h)
+                    const double diff0 = sgl_nnls_quotient(bi, gii, rii, any_irr);   // b_i / g_ii (Markstein, see nnls_lane.h)
                     double dpen;
-                    const double nd = sgl_nnls_nd(diff0, xi, go, L1, L2, dpen);
+                    const double nd = sgl_nnls_nd_strict(diff0, xi, go, L1, L2, dpen);
                     if (__ballot(nd != 0.0) != 0ull) {   // at rest in all four columns: x, tol and b stay as they are
                         double xn = xi;
                         sgl_nnls_apply(dpen, nd, xn, tol);
@@ -492,6 +496,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGL_QG_WPE))
         // (G_jj, 1 / G_jj) of the four columns: in LDS, not in 4 NR registers per lane -- a coordinate needs its pair once,
         // as one 16-byte read at a constant offset a coordinate ahead, where four DPP broadcasts served it before
         double b[NR], x[NR];
+        bool irr = false;
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             const int j = l + 16 * r;
@@ -499,9 +504,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGL_QG_WPE))
             b[r] = v ? B[col * k + j] : 0.0;
             x[r] = v ? X[col * k + j] : 0.0;
             const double gdj = v ? Gc[(int64_t)j * k + j] : 1.0;
+            const double rdj = 1.0 / gdj;   // correctly rounded reciprocal of the diagonal
             dgl[(grp * 16 * NR + j) * 2] = gdj;
-            dgl[(grp * 16 * NR + j) * 2 + 1] = 1.0 / gdj;   // correctly rounded reciprocal of the diagonal
+            dgl[(grp * 16 * NR + j) * 2 + 1] = rdj;
+            irr = irr || !__builtin_isnormal(rdj);
         }
+        const bool any_irr = __ballot(irr) != 0ull;   // a zero (or otherwise irregular) diagonal entry in one of the four columns
         __builtin_amdgcn_wave_barrier();
         const double* const dgc = dgl + (size_t)grp * 16 * NR * 2;   // this column's pairs
         double tol = 1.0;
@@ -567,10 +575,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGL_QG_WPE))
                     nnls_row_bcast2<il>(b[ir], x[ir], bi, xi);
                     const double gii = dn0, rii = dn1;
                     if (i + 1 < 16 * NR) { dn0 = dgc[2 * (i + 1)]; dn1 = dgc[2 * (i + 1) + 1]; }
-                    const double q0 = bi * rii;
-                    const double diff0 = fma(fma(-q0, gii, bi), rii, q0);   // b_i / g_ii (Markstein, see nnls_lane.h)
+                    const double diff0 = sgl_nnls_quotient(bi, gii, rii, any_irr);   // b_i / g_ii (Markstein, see nnls_lane.h)
                     double dpen;
-                    const double nd = sgl_nnls_nd(diff0, xi, go, L1, L2, dpen);
+                    const double nd = sgl_nnls_nd_strict(diff0, xi, go, L1, L2, dpen);
                     const bool moved = nd != 0.0;   // (x and tol change only with nd != 0; a stopped column has nd = 0)
                     if (__ballot(moved) != 0ull) {   // the coordinate moves in one of the four columns
                         double xn = xi;

@@ -61,6 +61,33 @@ __device__ __forceinline__ void sgl_nnls_apply(double diff, double nd, double& x
     tol = reset ? 1.0 : tol + tadd;
     xi = xn;
 }
+// The same first half for the solves against PER-COLUMN Grams (predict_mask, src/singlet.cpp:458-463), where a diagonal entry
+// a_ii - asub_ii can be exactly zero -- a factor whose row of the other factor matrix is all zero, or lies entirely inside
+// the column's drawn rows -- and the reference's `b(i) / a(i, i)` is +-inf or NaN (l.233): non-finite steps must come out as
+// the reference's do.  With nd = clamp ? x_i : -diff (instead of v_min_f64, which returns the OTHER operand for a NaN):
+//   diff NaN   l.237 false, l.243 true: x_i += NaN, b -= a.col(i) * NaN, tol NaN     = nd NaN:  x_i - nd, b += a.col(i) * nd, tol + |nd / ..|
+//   diff +inf  the same branch: x_i = inf, b -= a.col(i) * inf, tol += |inf / inf|   = nd -inf: the same expressions
+//   diff -inf  l.237 true: the clamp of a finite step (x_i -> 0, tol = 1; nothing if x_i == 0)     = nd x_i
+// and a stopped column is gated by a select (0 * inf would be NaN).  Finite steps: the same bits as sgl_nnls_nd.
+__device__ __forceinline__ double sgl_nnls_nd_strict(double diff0, double xi, bool go, double L1, double L2, double& diff) {
+    diff = diff0 - L1;
+    diff = __builtin_fma(L2, xi, diff);
+    diff = go ? diff : 0.0;
+    return (-diff > xi) ? xi : -diff;
+}
+// b_i / g_ii for a per-column Gram: the Markstein form (correctly rounded quotient from the correctly rounded reciprocal r_ii,
+// see nnls_lane.h) wherever r_ii is a normal number; elsewhere (g_ii zero, denormal, huge, non-finite) the IEEE division the
+// reference performs.  `any_irregular` is wave-uniform and false for all but degenerate columns: one scalar branch per coordinate.
+__device__ __forceinline__ double sgl_nnls_quotient(double bi, double gii, double rii, bool any_irregular) {
+    const double q0 = bi * rii;
+    double diff0 = __builtin_fma(__builtin_fma(-q0, gii, bi), rii, q0);
+    if (any_irregular) {
+        const double q = bi / gii;
+        diff0 = __builtin_isnormal(rii) ? diff0 : q;
+    }
+    return diff0;
+}
+
 __device__ __forceinline__ double sgl_nnls_step(double diff0, double& xi, double& tol, bool go, double L1, double L2) {
     double diff;
     const double nd = sgl_nnls_nd(diff0, xi, go, L1, L2, diff);

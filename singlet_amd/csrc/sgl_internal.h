@@ -240,6 +240,7 @@ int k_exclusive_scan(sgl_ctx* c, const int64_t* in, int64_t* out, int64_t n);  /
 int k_scan_total(hipStream_t s, const int64_t* in, int64_t* out, int64_t n);
 int k_col_counts(hipStream_t s, const int64_t* p, int64_t ncol, int64_t* counts);
 int k_validate_csc(hipStream_t s, const int32_t* idx, const int64_t* p, int64_t ncol, int32_t nrow, int* flag_dev);
+int k_all_finite(hipStream_t s, const double* x, int64_t n, int* flag_dev);   // flag |= 4 on NaN / Inf (after k_validate_csc)
 int k_widen_p(hipStream_t s, const int32_t* p32, int64_t n1, int64_t* p64);
 int k_build_segments(hipStream_t s, const DevCSC& M);
 

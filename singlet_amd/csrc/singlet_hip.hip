@@ -288,13 +288,15 @@ static int upload_one(sgl_ctx* c, DevCSC& M, const double* x, const int32_t* i, 
     // the kernels index factor rows by these values: refuse anything that is not a valid dgCMatrix
     int flag = 0;
     if (rc == SGL_OK) rc = k_validate_csc(c->stream, M.i, M.p, ncol, nrow, reinterpret_cast<int*>(p32));
+    if (rc == SGL_OK) rc = k_all_finite(c->stream, M.x, nnz, reinterpret_cast<int*>(p32));
     if (rc == SGL_OK && hipMemcpyAsync(&flag, p32, sizeof(int), hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = SGL_EHIP;
     if (hipStreamSynchronize(c->stream) != hipSuccess && rc == SGL_OK) rc = SGL_EHIP;
     dev_free(p32);
     if (rc == SGL_EHIP) { sgl_set_error("upload: a HIP call failed: %s", hipGetErrorString(hipGetLastError())); return rc; }
     if (rc == SGL_OK && flag != 0) {
-        sgl_set_error("not a valid dgCMatrix: %s%s", (flag & 1) ? "row index outside [0, nrow) " : "",
-                      (flag & 2) ? "row indices not strictly ascending within a column" : "");
+        sgl_set_error("not a valid dgCMatrix: %s%s%s", (flag & 1) ? "row index outside [0, nrow) " : "",
+                      (flag & 2) ? "row indices not strictly ascending within a column " : "",
+                      (flag & 4) ? "non-finite value (NA / NaN / Inf) in the x slot" : "");
         return SGL_EINVAL;
     }
     return rc;
@@ -340,13 +342,15 @@ static int upload_chunks(sgl_ctx* c, DevCSC& M, int32_t n_chunks, const double* 
     SGLCHK(dev_alloc(&dflag, 1));
     int flag = 0;
     int rc = k_validate_csc(c->stream, M.i, M.p, ncol, nrow, dflag);
+    if (rc == SGL_OK) rc = k_all_finite(c->stream, M.x, nnz, dflag);
     if (rc == SGL_OK && hipMemcpyAsync(&flag, dflag, sizeof(int), hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = SGL_EHIP;
     if (hipStreamSynchronize(c->stream) != hipSuccess && rc == SGL_OK) rc = SGL_EHIP;   // also: p64 leaves scope
     dev_free(dflag);
     if (rc == SGL_EHIP) { sgl_set_error("chunk upload: a HIP call failed: %s", hipGetErrorString(hipGetLastError())); return rc; }
     if (rc == SGL_OK && flag != 0) {
-        sgl_set_error("not a valid dgCMatrix list: %s%s", (flag & 1) ? "row index outside [0, nrow) " : "",
-                      (flag & 2) ? "row indices not strictly ascending within a column" : "");
+        sgl_set_error("not a valid dgCMatrix list: %s%s%s", (flag & 1) ? "row index outside [0, nrow) " : "",
+                      (flag & 2) ? "row indices not strictly ascending within a column " : "",
+                      (flag & 4) ? "non-finite value (NA / NaN / Inf) in an x slot" : "");
         return SGL_EINVAL;
     }
     return rc;
@@ -440,6 +444,19 @@ extern "C" int sgl_upload_dense(sgl_ctx* c, const double* A, int32_t nrow, int32
     const size_t tot = (size_t)nrow * (size_t)ncol;
     SGLCHK(dev_alloc(&c->Adense, tot));
     HIPCHK(hipMemcpyAsync(c->Adense, A, sizeof(double) * tot, hipMemcpyHostToDevice, c->stream));
+    {   // non-finite entries are refused like in the sparse uploads (k_all_finite)
+        int* dflag = nullptr;
+        SGLCHK(dev_alloc(&dflag, 1));
+        int flag = 0;
+        hipError_t e = hipMemsetAsync(dflag, 0, sizeof(int), c->stream);
+        int rc = e == hipSuccess ? k_all_finite(c->stream, c->Adense, (int64_t)tot, dflag) : SGL_EHIP;
+        if (rc == SGL_OK && (hipMemcpyAsync(&flag, dflag, sizeof(int), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                             hipStreamSynchronize(c->stream) != hipSuccess)) rc = SGL_EHIP;
+        dev_free(dflag);
+        if (rc == SGL_EHIP) sgl_set_error("sgl_upload_dense: HIP call failed");
+        SGLCHK(rc);
+        if (flag != 0) { sgl_set_error("sgl_upload_dense: non-finite value (NA / NaN / Inf) in the matrix"); return SGL_EINVAL; }
+    }
     DevCSC& M = c->A;
     M.nrow = nrow; M.ncol = ncol;
     int64_t* counts = nullptr;
@@ -680,6 +697,11 @@ extern "C" int sgl_fit_init(sgl_ctx* c, int32_t k, const double* w_init, uint64_
     CTX_GUARD(c);
     if (!c->A.p || !c->At.p) { sgl_set_error("sgl_fit_init: no matrix resident"); return SGL_ESTATE; }
     if (k <= 0 || k > SGL_MAX_K) { sgl_set_error("rank k=%d unsupported (1..%d)", k, SGL_MAX_K); return SGL_EINVAL; }
+    if (w_init) {   // the solves assume finite operands (nnls_static_for.h); the matrix is checked at upload
+        const size_t nw = (size_t)k * (size_t)c->A.nrow;
+        for (size_t q = 0; q < nw; ++q)
+            if (!std::isfinite(w_init[q])) { sgl_set_error("sgl_fit_init: w_init holds a non-finite value at %zu", q); return SGL_EINVAL; }
+    }
     HIPCHK(hipStreamSynchronize(c->stream));
     free_fit(c, true);
     const int rc = fit_init_impl(c, k, w_init, synth_seed);
@@ -963,7 +985,7 @@ int sgl_mse_test_enqueue(sgl_ctx* c, uint64_t seed, uint64_t inv_density) {
     const int k = c->k;
     const int64_t m = c->A.nrow;
     SGLCHK(sgl_mask_workspace(c));
-    Phase ph(c, SGL_PH_MASK);
+    Phase ph(c, SGL_PH_MSE);
     SGLCHK(k_wd(c->stream, c->W, c->d, k, m, c->Wd));
     return k_mse_test(c, c->Wd, c->H, k, seed, inv_density, c->scalars + 1);
 }
@@ -1615,6 +1637,13 @@ extern "C" int sgl_layout_builds(sgl_ctx* c, int64_t* out4) {
     out4[1] = c->TAt.builds;
     out4[2] = c->ml_builds[0];
     out4[3] = c->ml_builds[1];
+    return SGL_OK;
+}
+
+extern "C" int sgl_mask_pairs(sgl_ctx* c, int64_t* out2) {
+    CTX_GUARD(c);
+    if (!out2) { sgl_set_error("sgl_mask_pairs: NULL buffer"); return SGL_EINVAL; }
+    for (int o = 0; o < 2; ++o) out2[o] = (c->ML[o].mask_t >= 0 && !c->ML[o].refused) ? c->ML[o].total : 0;
     return SGL_OK;
 }
 
