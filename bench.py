@@ -31,12 +31,22 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+FP64_MFMA_PEAK_TFLOPS = 78.6  # v_mfma_f64_*: 32 FLOP / clk / SIMD x 1024 SIMDs x 2.4 GHz = the FP64 vector peak (AMD's MI355X figure;
+                              # MI355X_MICROARCH.md tabulates the f32-input MFMA the same way: "runs at the vector rate")
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_MEASURED_GBS = 6290.0    # same table: float4 copy, 79 %
 
 
 def parse(argv=None):
     ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", choices=("als", "ard"), default="als",
+                    help="als = the headline: plain ALS iterations of c_nmf on config 3; ard = BASELINE config 5 on one GPU: the "
+                         "(rank, replicate) grid of masked fits behind ard_nmf / cross_validate_nmf on one resident matrix, with "
+                         "the Gram downdate's FP64-MFMA roofline and the CPU oracle's c_ard_nmf timed beside it")
+    ap.add_argument("--ranks", default="10,20,30,40,50,60,70,80,90,100", help="--workload ard: the ranks of the grid")
+    ap.add_argument("--replicates", type=int, default=3, help="--workload ard: restarts per rank (R's n_replicates)")
+    ap.add_argument("--maxit", type=int, default=10, help="--workload ard: iterations per masked fit")
+    ap.add_argument("--trace", type=int, default=5, help="--workload ard: trace_test_mse (mse_test every this many iterations)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
@@ -49,7 +59,8 @@ def parse(argv=None):
                     help="iid = BASELINE's synthetic matrix (the headline); skewed = the same generator with log-normal weights "
                          "per cell (sigma 0.5) and per gene (sigma 1.5): heavy-tailed row and column counts (secondary record)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-cells", type=int, default=200000, help="cells of the CPU baseline sample (0 = all)")
+    ap.add_argument("--cpu-sample-cells", type=int, default=None,
+                    help="cells of the CPU baseline sample (0 = all); default 200 000 (als) / 10 000 (ard)")
     ap.add_argument("--comm", choices=("auto", "native", "hook", "none"), default="auto",
                     help="exchange between the ranks: native = RCCL inside the library (sgl_comm_init_rank), hook = "
                          "torch.distributed all-reduce through sgl_set_allreduce, auto = none for one rank, native otherwise")
@@ -63,7 +74,10 @@ def parse(argv=None):
     ap.add_argument("--force-allreduce", action="store_true",
                     help="with one rank: still create the RCCL process group and route the two per-iteration sums through "
                          "the all-reduce hook (plumbing check of the hook path on a 1-GPU box)")
-    return ap.parse_args(argv)
+    a = ap.parse_args(argv)
+    if a.cpu_sample_cells is None:
+        a.cpu_sample_cells = 200000 if a.workload == "als" else 10000
+    return a
 
 
 def plan(args, env):
@@ -418,8 +432,147 @@ def run_single_process(args, pl):
     emit(json.dumps(out))
 
 
+def cpu_baseline_ard(args, ranks):
+    """The oracle's c_ard_nmf (oracle/singlet_oracle.c: predict_mask / mse_test / the loop of src/singlet.cpp:1090-1152 restated)
+    MEASURED on this host's cores on a cell slice of the same synthetic matrix: per rank one 2-iteration masked fit (one trace
+    row) on the first S cells and one on the first S / 2 -- both the per-cell work (hashing, right-hand sides, every cell's and
+    every gene's Gram downdate) and the part that does not grow with the cells (the genes' NNLS solves) are then known:
+    t(cells) = a * cells + b per masked iteration, evaluated at the full cell count."""
+    import numpy as np
+    from oracle import oracle as ora
+    ns = args.cells if args.cpu_sample_cells <= 0 else min(args.cpu_sample_cells, args.cells)
+    nh = max(ns // 2, 1)
+    t0 = time.perf_counter()
+    full = ora.synth_csc(args.genes, ns, args.inv_density)
+    full_t = full.t()
+    half = ora.CSC(full.x[:full.p[nh]], full.i[:full.p[nh]], full.p[:nh + 1], args.genes, nh)
+    half_t = half.t()
+    gen_s = time.perf_counter() - t0
+    rows, total = [], 0.0
+    fits = args.replicates * args.maxit
+    ora.c_ard_nmf(half, half_t, 0.0, 1, args.L1, 0.0, 0, ora.synth_winit(ranks[0], args.genes), 1001, args.inv_density, 1e9, 1)   # thread pool, page faults
+    for k in ranks:
+        w0 = ora.synth_winit(k, args.genes)
+
+        def timed(A, At):
+            t = time.perf_counter()
+            ora.c_ard_nmf(A, At, 0.0, 2, args.L1, 0.0, 0, w0, 1001, args.inv_density, 1e9, 2)
+            return (time.perf_counter() - t) / 2.0
+        ts = timed(full, full_t)
+        if ns < args.cells and nh < ns:
+            th = timed(half, half_t)
+            a = (ts - th) / (ns - nh)
+            if a <= 0.0:            # timer noise on a tiny sample: everything scales
+                a = ts / ns
+            b = min(max(ts - a * ns, 0.0), ts)
+        else:
+            a, b = ts / ns, 0.0
+        est = a * args.cells + b
+        rows.append({"k": k, "sample_sec_per_masked_iter": ts, "est_full_sec_per_masked_iter": est, "not_scaled_sec": b})
+        total += fits * est
+    cores = int(ora.lib().ora_max_threads())
+    return {"value": total, "unit": "s", "cores": cores, "kind": "port", "cpu_model": _cpu_model(),
+            "build": "gcc -O2 -fopenmp -ffp-contract=off", "per_rank": rows,
+            "sample": "oracle/singlet_oracle.c c_ard_nmf (restatement of src/singlet.cpp:1090-1152 with predict_mask :436-466 and "
+                      "mse_test :536-568), %d threads on %s; per rank a 2-iteration masked fit with one trace row on the first %d and "
+                      "the first %d of %d cells x %d genes, seconds per masked iteration extrapolated linearly in the cells with "
+                      "the part that does not grow (the genes' solves) kept; value = sum over the grid's %d fits x %d iterations; "
+                      "generation + transposes %.1f s not timed" % (cores, _cpu_model(), ns, nh, args.cells, args.genes,
+                                                                     len(ranks) * args.replicates, args.maxit, gen_s)}
+
+
+def run_ard(args):
+    """BASELINE config 5 on ONE GPU: the (rank, replicate) grid of 10-iteration masked fits that cross_validate_nmf / the rank
+    search of ard_nmf run (R/cross_validate_nmf.R:69-104, R/ard_nmf.R:95-160), on one resident matrix: sgl_fit_init +
+    sgl_ard_run per (k, replicate), fit set-up (entry streams per rank, mask lists per seed) inside the timed region.
+    value = wall seconds of the grid.  roofline = the per-column Gram downdates of predict_mask (src/singlet.cpp:458-463) against
+    the FP64 matrix pipe: one masked iteration sums w_r w_r^T over every drawn (cell, gene) pair, once per cell and once per
+    gene -- pairs x k (k + 1) flop on the symmetric half -- and the hipEvent time of the phase that holds exactly those kernels
+    (SGL_PH_MASK) divides it; taken from the last replicate of each rank, whose mask lists exist already."""
+    import singlet_amd as sa
+    ranks = [int(v) for v in str(args.ranks).split(",") if v.strip()]
+    if not ranks or min(ranks) < 1:
+        raise SystemExit("bench.py: --ranks %r" % args.ranks)
+    ctx = sa.Context(0)
+    t0 = time.perf_counter()
+    ctx.synth(args.genes, args.cells, args.inv_density)
+    gen_s = time.perf_counter() - t0
+    m, n, nnz = ctx.dims()
+    ctx.fit_init(ranks[0], None)
+    ctx.ard_run(0.0, 1, args.L1, 0.0, 1, args.inv_density, 1e9, 1)      # warm-up: module load, workspaces (its mask is not the grid's)
+    ctx.timing_enable(True)
+    fits, per_rank = [], []
+    t_all = time.perf_counter()
+    for k in ranks:
+        rr = []
+        for rep in range(1, args.replicates + 1):
+            ctx.timing_get(reset=True)
+            t0 = time.perf_counter()
+            ctx.fit_init(k, None, synth_seed=0x5EED + rep)              # a different initial w per replicate
+            r = ctx.ard_run(1e-4, args.maxit, args.L1, 0.0, 1000 + rep, args.inv_density, 1e-4, args.trace)
+            dt = time.perf_counter() - t0
+            ph = ctx.timing_get(reset=True)
+            pairs = ctx.mask_pairs()
+            it = max(int(r["n_iter"]), 1)
+            row = {"k": k, "rep": rep, "wall_s": dt, "iters": int(r["n_iter"]), "traces": len(r["test_mse"]),
+                   "sec_per_masked_iter": dt / it, "test_mse": float(r["test_mse"][-1]),
+                   "phases_ms": {p: v[0] for p, v in ph.items() if v[0] > 0}, "mask_pairs": {"per_cell": pairs[0], "per_gene": pairs[1]}}
+            rr.append(row)
+            fits.append(row)
+            print({q: row[q] for q in ("k", "rep", "wall_s", "iters", "sec_per_masked_iter")}, file=sys.stderr, flush=True)
+        last = rr[-1]
+        npairs = last["mask_pairs"]["per_cell"] + last["mask_pairs"]["per_gene"]
+        mask_s = last["phases_ms"].get("mask", 0.0) * 1e-3
+        flops = float(npairs) * k * (k + 1) * max(last["iters"], 1)
+        tf = flops / mask_s / 1e12 if (mask_s > 0 and npairs > 0) else None
+        per_rank.append({"k": k, "sec_per_masked_iter": sum(q["sec_per_masked_iter"] for q in rr) / len(rr),
+                         "fit_wall_s": [q["wall_s"] for q in rr], "iters": [q["iters"] for q in rr],
+                         "phases_ms_per_iter_last_replicate": {p: v / max(last["iters"], 1) for p, v in last["phases_ms"].items()},
+                         "downdate": {"pairs_per_iteration": npairs, "flop_per_iteration": float(npairs) * k * (k + 1),
+                                      "ms_per_iteration": 1e3 * mask_s / max(last["iters"], 1), "achieved_tflops": tf,
+                                      "frac_of_fp64_mfma_peak": (tf / FP64_MFMA_PEAK_TFLOPS) if tf else None}})
+    total = time.perf_counter() - t_all
+    ctx.timing_enable(False)
+    with_tf = [q for q in per_rank if q["downdate"]["achieved_tflops"]]
+    dom = max(with_tf, key=lambda q: q["downdate"]["ms_per_iteration"]) if with_tf else None
+    nfits = len(fits)
+    out = {
+        "metric": "rank-sweep wall seconds (ard_nmf + cross_validate_nmf grid k in {%s}, %d restarts, %d cells x %d genes, %d-iteration "
+                  "masked fits)" % (",".join(str(k) for k in ranks), args.replicates, n, m, args.maxit),
+        "value": total, "unit": "s", "n_gpus": 1, "steps": nfits, "warmup": 1, "ms_per_step": 1e3 * total / max(nfits, 1),
+        "higher_is_better": False, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "config 5 on one GPU: synthetic CSC %d genes x %d cells, 1/%d non-zero (nnz %d); grid of %d masked fits "
+                               "(c_ard_nmf: cv_tol 1e-4, maxit %d, trace_test_mse %d, test density 1/%d, L1 %g), one resident context; a step = one fit, "
+                               "set-up (entry streams per rank, mask lists per seed) included"
+                               % (m, n, args.inv_density, nnz, nfits, args.maxit, args.trace, args.inv_density, args.L1),
+                   "genes": m, "cells": n, "ranks": ranks, "replicates": args.replicates, "nnz": nnz, "parallelism": "one GPU (replica sweep over N GPUs: SINGLET_REPLICA_GPUS)"},
+        "roofline": None if dom is None else {
+            "bound": "mfma", "kernel": "mask_gram_list_kernel: per-column Gram downdates of predict_mask, rank %d (the rank with the longest downdate phase)" % dom["k"],
+            "achieved": dom["downdate"]["achieved_tflops"], "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": dom["downdate"]["frac_of_fp64_mfma_peak"], "traffic": None,
+            "algorithmic_flop_per_iteration": dom["downdate"]["flop_per_iteration"], "ms_per_iteration": dom["downdate"]["ms_per_iteration"],
+            "algorithmic_flop_is": "drawn (cell, gene) pairs listed per cell + per gene, x k (k + 1): the symmetric half of every rank-one downdate, 2 flop per FMA",
+            "time_is": "hipEvent time of the SGL_PH_MASK phase (the downdate kernels of both half-iterations) in the last replicate's fit, per iteration",
+            "note": "FP64 MFMA and FP64 VALU share one rate on this part and do not overlap (DESIGN.md, Masked path): the fraction also prices the tile padding of k not a multiple of 16"},
+        "per_rank": per_rank, "fits": fits, "generate_s": gen_s,
+        "grid_is": "the masked fits only, in rank order; mask lists of the %d seeds are built in the first rank's fits and kept" % args.replicates,
+    }
+    if not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline_ard(args, ranks)
+            out["speedup_vs_cpu_baseline"] = out["cpu_baseline"]["value"] / out["value"]
+        except Exception as e:  # noqa: BLE001 - the baseline is reported, never required
+            out["cpu_baseline"] = {"error": repr(e)}
+    ctx.close()
+    emit(json.dumps(out))
+
+
 def main():
     args = parse()
+    if args.workload == "ard":
+        if args.gpus != 1 or "WORLD_SIZE" in os.environ and int(os.environ.get("WORLD_SIZE") or 1) > 1:
+            raise SystemExit("bench.py: --workload ard is a one-GPU record (the grid's fits are independent: the replica sweep, not a team)")
+        return run_ard(args)
     pl = plan(args, os.environ)
     if pl["form"] == "single-process":
         return run_single_process(args, pl)

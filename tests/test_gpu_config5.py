@@ -272,3 +272,34 @@ def test_r_driver_list_and_dense_branches_equal_the_one_matrix_result(sa, ora):
     assert [r["k"] for r in m1["cv_data"]] == [r["k"] for r in ml["cv_data"]] == [r["k"] for r in md["cv_data"]]
     assert np.array_equal(m1["w"], ml["w"]) and np.array_equal(m1["h"], ml["h"]) and np.array_equal(m1["d"], ml["d"])
     assert rel_fro(md["w"], m1["w"]) < 1e-9 and rel_fro(md["h"], m1["h"]) < 1e-9 and rel_fro(md["d"], m1["d"]) < 1e-9
+
+
+def test_bench_ard_workload_prints_roofline_and_cpu_baseline():
+    """`bench.py --workload ard` is how config 5 is measured (round 5): the grid's wall seconds, per rank the Gram downdate's
+    FP64-MFMA TFLOP/s from its hipEvent phase and the drawn-pair count, and the oracle's c_ard_nmf timed on a cell slice --
+    run here end to end on a small shape and held to the bench contract's keys."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "ard", "--genes", "3000", "--cells", "20000", "--ranks", "6,20,50",
+                        "--replicates", "2", "--maxit", "3", "--trace", "2", "--cpu-sample-cells", "1500"],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline", "per_rank"):
+        assert key in d, key
+    assert d["unit"] == "s" and d["higher_is_better"] is False and d["steps"] == 6 and d["value"] > 0
+    rf = d["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 78.6 and 0 < rf["frac"] < 1 and rf["traffic"] is None
+    assert [q["k"] for q in d["per_rank"]] == [6, 20, 50]
+    for q in d["per_rank"]:
+        dd = q["downdate"]
+        # every (cell, gene) pair is drawn with probability 1 / 20, listed once per cell and once per gene
+        assert abs(dd["pairs_per_iteration"] / (2 * 3000 * 20000 / 20.0) - 1.0) < 0.02
+        assert dd["achieved_tflops"] > 0 and dd["ms_per_iteration"] > 0
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and len(cb["per_rank"]) == 3 and "c_ard_nmf" in cb["sample"]

@@ -13,19 +13,33 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "singlet_amd", "csrc", "kernels_tiled.hip")
+CSRC = os.path.join(ROOT, "singlet_amd", "csrc")
+SRC = os.path.join(CSRC, "kernels_tiled.hip")
 HIPCC = "/opt/rocm/bin/hipcc"
+
+
+def _device_asm(src, tmpdir):
+    """Device assembly of a translation unit of the library.  The build keeps it as a by-product of the compilation that made
+    the shipped object (singlet_amd/csrc/asm/<unit>.s, Makefile: -save-temps): use that when it is at least as new as every
+    source it depends on -- it then describes exactly the code in libsinglet_hip.so -- else compile the unit here."""
+    unit = os.path.splitext(os.path.basename(src))[0]
+    kept = os.path.join(CSRC, "asm", unit + ".s")
+    deps = [src] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))] + [os.path.join(ROOT, "include", "singlet_hip.h")]
+    gen = os.path.join(CSRC, "gen_acc_tiled.py")
+    if os.path.exists(kept) and all(os.path.getmtime(kept) >= os.path.getmtime(d) for d in deps + [gen]):
+        return open(kept).read()
+    out = os.path.join(str(tmpdir), unit + ".s")
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-S",
+                    "--cuda-device-only", "-o", out, src], check=True, capture_output=True, timeout=900)
+    return open(out).read()
 
 
 @pytest.fixture(scope="module")
 def tiled_asm(tmp_path_factory):
     if not os.path.exists(HIPCC):
         pytest.skip("hipcc not installed")
-    out = str(tmp_path_factory.mktemp("asm") / "kernels_tiled.s")
     subprocess.run(["make", "-C", os.path.dirname(SRC), "acc_tiled_gen.inc"], check=True, capture_output=True, timeout=120)
-    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-S",
-                    "--cuda-device-only", "-o", out, SRC], check=True, capture_output=True, timeout=600)
-    text = open(out).read()
+    text = _device_asm(SRC, tmp_path_factory.mktemp("asm"))
     inst = {}
     for nsl in (2, 3, 4, 6, 7):   # acc_tiled_kernel<MODE>: pairs with prepared sets, pairs on the ring layout, quads (k <= 32); 6 / 7: 3 / 4 with the schedule table
         m = re.search(r"^(_Z16acc_tiled_kernelILi%dEE\w*):[^\n]*\n(.*?)s_endpgm" % nsl, text, re.S | re.M)
@@ -211,10 +225,7 @@ MASK_SRC = os.path.join(ROOT, "singlet_amd", "csrc", "kernels_mask.hip")
 def mask_asm(tmp_path_factory):
     if not os.path.exists(HIPCC):
         pytest.skip("hipcc not installed")
-    out = str(tmp_path_factory.mktemp("asm") / "kernels_mask.s")
-    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-S",
-                    "--cuda-device-only", "-o", out, MASK_SRC], check=True, capture_output=True, timeout=900)
-    return open(out).read()
+    return _device_asm(MASK_SRC, tmp_path_factory.mktemp("asm"))
 
 
 def test_list_downdate_kernels_own_their_agprs(mask_asm):
@@ -266,10 +277,7 @@ def test_half_lane_nnls_x_in_agprs(tmp_path_factory):
     descriptor must cover the named registers."""
     if not os.path.exists(HIPCC):
         pytest.skip("hipcc not installed")
-    out = str(tmp_path_factory.mktemp("asm") / "kernels_nnls_half.s")
-    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-S",
-                    "--cuda-device-only", "-o", out, HALF_SRC], check=True, capture_output=True, timeout=900)
-    text = open(out).read()
+    text = _device_asm(HALF_SRC, tmp_path_factory.mktemp("asm"))
     kernels = re.findall(r"^(_Z16nnls_half_kernelILi(\d+)E\w*):[^\n]*\n(.*?)^\.Lfunc_end", text, re.S | re.M)
     assert len(kernels) == 8
     for name, kh, body in kernels:
