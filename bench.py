@@ -477,8 +477,10 @@ def cpu_baseline_ard(args, ranks):
                       "mse_test :536-568), %d threads on %s; per rank a 2-iteration masked fit with one trace row on the first %d and "
                       "the first %d of %d cells x %d genes, seconds per masked iteration extrapolated linearly in the cells with "
                       "the part that does not grow (the genes' solves) kept; value = sum over the grid's %d fits x %d iterations; "
-                      "generation + transposes %.1f s not timed" % (cores, _cpu_model(), ns, nh, args.cells, args.genes,
-                                                                     len(ranks) * args.replicates, args.maxit, gen_s)}
+                      "generation + transposes %.1f s not timed.  A port: its Gram downdate AAt(wsub) is a plain rank-one "
+                      "loop where the reference calls Eigen's blocked rankUpdate -- the reference itself is likely several times "
+                      "faster than this figure" % (cores, _cpu_model(), ns, nh, args.cells, args.genes,
+                                                   len(ranks) * args.replicates, args.maxit, gen_s)}
 
 
 def run_ard(args):

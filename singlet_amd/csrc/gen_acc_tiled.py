@@ -385,9 +385,10 @@ class GenTab(GenQuad):
     pair = True: two columns per LDS instruction (half-set ring slots, doubled lane rows: GenPairRing's loads);
     pair = False: four (GenQuad's)."""
 
-    def __init__(self, pair):
+    def __init__(self, pair, pf=0):
         super().__init__()
         self.pair = pair
+        self.pf = pf   # > 0: at every wrap of the ring, touch the stream `pf` laps beyond the lap being loaded (below)
 
     def refill(self, i):
         if self.pair:
@@ -428,6 +429,18 @@ class GenTab(GenQuad):
         A(f"s_load_dwordx16 s[{TAB1}:{TAB1 + 15}], s[{S_TP}:{S_TP + 1}], 0x0")
         A(f"s_add_u32 s{S_TP}, s{S_TP}, 64")
         A(f"s_addc_u32 s{S_TP + 1}, s{S_TP + 1}, 0")
+        if self.pf:
+            # Stream prefetch into L2 (round 5).  The ring keeps one lap (8 slots) of the stream in flight per wave: a slot's data
+            # must make the whole trip from HBM inside one lap of the loop (~3 us), and every load that takes longer stalls the
+            # wave at its counted vmcnt.  Once per lap two more loads touch every 128-byte line of the lap `pf` laps beyond the
+            # one being loaded (lane stride = lap bytes / 64; %[pfl] = lane * stride + pf * lap bytes of the row-offset stream,
+            # the value stream is twice that): the ring's own loads of that lap then hit L2.  Destination v63 is a dummy:
+            # nothing reads it, and both loads are older than ring slot 0's refill, so the vmcnt wait of body(NS - 1) -- a lap
+            # later -- has seen them land before v63 is written again.
+            A("s_mov_b32 m0, 0")   # index mode is on and M0 still points the last group's destinations at its accumulators
+            A("v_lshlrev_b32 v63, 1, %[pfl]")
+            A(f"global_load_dword v63, v63, s[{S_XP}:{S_XP + 1}]")
+            A(f"global_load_dword v63, %[pfl], s[{S_RP}:{S_RP + 1}]")
 
     def body(self, d, L_body, L_last):
         """a half-set that is NOT the chunk's last one: both octets fetch ahead; s[S_NS] counts the fetching half-sets still to
@@ -439,7 +452,10 @@ class GenTab(GenQuad):
         self.addrs(d, 1)
         self.octet(d, 0, True)
         A("s_mov_b32 m0, 0")
-        A(f"s_waitcnt vmcnt({2 * (self.NS - 2)})")
+        # slot d + 1 has landed: of the 2 (NS - 1) ring loads in flight its two are the oldest; with the two prefetch loads of
+        # the last wrap in flight as well (issued between the refills of slot NS - 1 and slot 0) two more may stay
+        # outstanding, except at d = NS - 1, where they are older than the slot waited for
+        A(f"s_waitcnt vmcnt({2 * (self.NS - 2) + (2 if (self.pf and d != self.NS - 1) else 0)})")
         self.addrs(dn, 0)
         self.octet(d, 1, True)
         self.refill(d)
@@ -560,13 +576,18 @@ def main():
     g.A(f"s_mov_b64 %[xp], s[{S_XP}:{S_XP + 1}]")
     out.append(f"#define ACC_TILED2R_RING_FILL_ASM \\\n{g.text()}")
     # ---- schedule-table bookkeeping (default): pairs and quads
+    # laps of L2 prefetch ahead of the ring.  Default 0: measured at config 3 (round 5, one box, two runs each, rhs_h / rhs_w ms per
+    # pass) 0 laps 10.25 / 10.21 and 10.28 / 10.24, 2 laps 10.47 / 10.47 and 10.56 / 10.48, 4 laps 10.65 / 10.66 and 10.73 / 10.65;
+    # config 2 0.220 -> 0.262: the waves are not waiting for the stream, and the two extra loads per lap cost what loads cost.
+    pf = int(os.environ.get("SGL_GEN_PF", "0"))
     for tag, pair in (("2T", True), ("4T", False)):
         out.append("")
-        g = GenTab(pair)
+        g = GenTab(pair, pf)
         g.chunk()
         out.append(f"#define ACC_TILED{tag}_CHUNK_ASM \\\n{g.text()}")
-    tclob = [f'"s{r}"' for r in range(TAB0, S_Q + 8)] + ['"memory"', '"scc"']
+    tclob = [f'"s{r}"' for r in range(TAB0, S_Q + 8)] + ['"memory"', '"scc"'] + (['"v63"'] if pf else [])
     out.append("#define ACC_TILEDT_CLOBBERS " + ", ".join(tclob))
+    out.append(f"#define ACC_TILED_PF_LAPS {pf}")
     sys.stdout.write("\n".join(out) + "\n")
 
 

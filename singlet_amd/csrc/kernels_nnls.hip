@@ -616,6 +616,133 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGL_QG_WPE))
     }
 }
 
+// ---------------------------------------------------------------------------
+// SHARED Gram, FEW columns (round 5): four columns per wave against the one Gram of predict (src/singlet.cpp:333-347).
+// The lane-per-column kernel is built for throughput -- 64 columns per wave, ~4150 instructions per sweep at k = 50 -- and a
+// solve of a few thousand columns (a rank's gene block on an 8-GPU team: 3750 genes; the cells of pbmc3k: 2700) runs it on a
+// few dozen waves, each alone on its SIMD: the solve then lasts as long as ONE wave's sweeps, 24 x 11 us.  Here a column has
+// the 16 lanes of a DPP row (lane l holds coordinates l, l + 16, ...): a sweep is ~40 instructions per coordinate for four
+// columns instead of ~83 for 64, i.e. SIXTEEN times the waves at less than half the sweep length, and a wave waits for the
+// slowest of 4 columns instead of 64.  The Gram is staged once per workgroup as a full square (row stride 16 NR: row i of this
+// lane's coordinates at immediate offsets, no triangle indexing -- nnls_quad_kernel with a zero column stride lost to that),
+// (G_ii, 1 / G_ii) as pairs read by one uniform 16-byte read.  Arithmetic, order and stop test are the lane kernel's (b_i / G_ii
+// by the Markstein form from the correctly rounded reciprocal, sgl_nnls_nd / sgl_nnls_apply, fma(G_ji, nd, b_j)): the same bits.
+// Pays while the lane kernel would be latency-bound: up to ~8000 columns (sgl_nnls_shared).
+template <int NR>
+__global__ __launch_bounds__(256) void nnls_quad_shared_kernel(const double* __restrict__ G, const double* __restrict__ B, double* __restrict__ X,
+                                                               const int64_t* __restrict__ col_nnz, int k, int64_t ncols, double L1, double L2,
+                                                               unsigned long long* __restrict__ sweep_counter) {
+    constexpr int GS = 16 * NR;
+    extern __shared__ __attribute__((aligned(16))) char qs_lds_raw[];
+    double* Gl = reinterpret_cast<double*>(qs_lds_raw);   // Gl[i * GS + j] = G[j, i] (= G[i, j]), 0 beyond the rank
+    double* Dl = Gl + (size_t)k * GS;                      // (G_jj, 1 / G_jj)
+    for (int e = threadIdx.x; e < k * GS; e += blockDim.x) {
+        const int i = e / GS, j = e - i * GS;
+        Gl[e] = (j < k) ? G[j + (size_t)k * i] : 0.0;
+    }
+    for (int j = threadIdx.x; j < GS; j += blockDim.x) {
+        const double g = (j < k) ? G[j + (size_t)k * j] : 1.0;
+        Dl[2 * j] = g;
+        Dl[2 * j + 1] = 1.0 / g;   // correctly rounded reciprocal of the diagonal
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, grp = lane >> 4, l = lane & 15;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const double kd = (double)k;
+    const double* __restrict__ gl = Gl + l;
+    long long total_sweeps = 0, ran_total = 0;
+    const int64_t nquads = (ncols + 3) >> 2;
+    for (int64_t quad = wave; quad < nquads; quad += nwaves) {
+        const int64_t col = quad * 4 + grp;
+        const bool cvalid = col < ncols && (col_nnz == nullptr || col_nnz[col] != 0);
+        double b[NR], x[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int j = l + 16 * r;
+            const bool v = cvalid && j < k;
+            b[r] = v ? B[col * k + j] : 0.0;
+            x[r] = v ? X[col * k + j] : 0.0;
+        }
+        double tol = 1.0;
+        int it = 0, ran = 0, one = 1;
+        while (true) {
+            const bool go = cvalid && it < 100 && (tol / kd) > 1e-8;
+            if (__ballot(go) == 0ull) break;
+            ++ran;
+            if (go) tol = 0.0;
+            double dn0 = Dl[0], dn1 = Dl[1];
+            static_for<16 * NR>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                constexpr int ir = i >> 4, il = i & 15;
+                bool run_i = i < k;
+                if (i <= 16 * (NR - 1)) { asm volatile("" : "+s"(one)); run_i = one != 0; }   // opaque, always true (see nnls_lane.h)
+                if (run_i) {
+                    double g[NR];
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) g[r] = gl[i * GS + 16 * r];
+                    double bi, xi;
+                    nnls_row_bcast2<il>(b[ir], x[ir], bi, xi);
+                    const double gii = dn0, rii = dn1;
+                    if (i + 1 < 16 * NR) { dn0 = Dl[2 * (i + 1)]; dn1 = Dl[2 * (i + 1) + 1]; }
+                    const double q0 = bi * rii;
+                    const double diff0 = fma(fma(-q0, gii, bi), rii, q0);   // b_i / G_ii (Markstein, see nnls_lane.h)
+                    double dpen;
+                    const double nd = sgl_nnls_nd(diff0, xi, go, L1, L2, dpen);
+                    if (__ballot(nd != 0.0) != 0ull) {   // at rest in all four columns: x, tol and b stay as they are
+                        double xn = xi;
+                        sgl_nnls_apply(dpen, nd, xn, tol);
+                        x[ir] = (l == il) ? xn : x[ir];
+#pragma unroll
+                        for (int r = 0; r < NR; ++r) b[r] = fma(g[r], nd, b[r]);
+                    }
+                }
+            });
+            it += go ? 1 : 0;
+        }
+        if (cvalid) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int j = l + 16 * r;
+                if (j < k) X[col * k + j] = x[r];
+            }
+            if (l == 0) total_sweeps += it;
+        }
+        ran_total += ran;
+    }
+    if (sweep_counter != nullptr) {
+        for (int off = 32; off > 0; off >>= 1) total_sweeps += __shfl_down(total_sweeps, off, 64);
+        if (lane == 0 && (total_sweeps != 0 || ran_total != 0)) {
+            atomicAdd(sweep_counter, (unsigned long long)total_sweeps);
+            atomicAdd(sweep_counter + 2, (unsigned long long)ran_total);
+        }
+    }
+}
+
+template <int NR>
+static int launch_nnls_quad_shared(hipStream_t s, const double* G, const double* B, double* X, const int64_t* col_nnz, int k, int64_t ncols,
+                                   double L1, double L2, unsigned long long* sweep_counter) {
+    const size_t lds = sizeof(double) * ((size_t)k * 16 * NR + 2 * 16 * NR);
+    const int64_t nquads = (ncols + 3) / 4;
+    const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>((nquads + 3) / 4, 256 * 8));
+    nnls_quad_shared_kernel<NR><<<dim3((unsigned)blocks), dim3(256), lds, s>>>(G, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
+    HIPCHK(hipGetLastError());
+    return SGL_OK;
+}
+
+// G: the k x k Gram (column-major, + 1e-15 on the diagonal), shared by all columns; B is read only.  k <= 64.
+int k_nnls_quad_shared(hipStream_t s, const double* G, const double* B, double* X, const int64_t* col_nnz, int k, int64_t ncols,
+                       double L1, double L2, unsigned long long* sweep_counter) {
+    if (ncols <= 0) return SGL_OK;
+    switch ((k + 15) / 16) {
+        case 1: return launch_nnls_quad_shared<1>(s, G, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
+        case 2: return launch_nnls_quad_shared<2>(s, G, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
+        case 3: return launch_nnls_quad_shared<3>(s, G, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
+        case 4: return launch_nnls_quad_shared<4>(s, G, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
+        default: sgl_set_error("k_nnls_quad_shared: k=%d above 64", k); return SGL_EINVAL;
+    }
+}
+
 template <int NR>
 static int launch_nnls_quad_global(hipStream_t s, const double* G, int64_t gstride, const double* B, double* X, const int64_t* col_nnz,
                                    int k, int64_t ncols, double L1, double L2, unsigned long long* sweep_counter) {

@@ -52,7 +52,7 @@
 #define TILED_CW 64          // columns per wave
 #define TILED_NP 32          // column pairs per wave
 #define TILED_LDS_BYTES (160 * 1024 - 512)  // the whole 160 KiB of a CU minus the read-past-the-row slack
-#define TILED_SLACK 1024     // stream entries readable past the end (ring prefetch)
+#define TILED_SLACK 4096     // stream entries readable past the end (ring prefetch: 256 - 512 entries, + the L2 prefetch laps beyond it)
 
 // ---------------------------------------------------------------- build -----
 // groups per (wb, t, pair) and entries per chunk
@@ -578,6 +578,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     // entries, lanes 32-47 and 48-63 the B half's (slots 32 ..): the [A A B B] layout the row broadcasts read
     const unsigned slot = PAIRRING ? (unsigned)((lane >> 5) * 32 + (lane & 15)) : (unsigned)lane;
     const unsigned voff4 = slot * 4, voff8 = slot * 8;
+    // L2 prefetch of the stream (gen_acc_tiled.py, GenTab.wrap): lane offset into the row-offset stream that spreads the 64
+    // lanes over one lap of it (8 ring slots: 1 KB in the pair layout, 2 KB in the quad layout), ACC_TILED_PF_LAPS laps ahead
+    constexpr unsigned LAP_R = (NSL == 4 ? 256u : 128u) * 8u;
+    const unsigned pfl = (unsigned)lane * (LAP_R / 64u) + (unsigned)ACC_TILED_PF_LAPS * LAP_R;
 
     asm volatile(ACC_TILED_ZERO_ASM ::: "memory");
 
@@ -728,12 +732,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 if constexpr (MODE == 6)
                     asm volatile(ACC_TILED2T_CHUNK_ASM
                                  : [rp] "+s"(rp), [xp] "+s"(xp), [phase] "+s"(phase)
-                                 : [ns] "s"(2 * nsets), [tp] "s"(tp), [lane16] "v"(lane16), [voff4] "v"(voff4), [voff8] "v"(voff8)
+                                 : [ns] "s"(2 * nsets), [tp] "s"(tp), [lane16] "v"(lane16), [voff4] "v"(voff4), [voff8] "v"(voff8), [pfl] "v"(pfl)
                                  : ACC_TILEDT_CLOBBERS);
                 else
                     asm volatile(ACC_TILED4T_CHUNK_ASM
                                  : [rp] "+s"(rp), [xp] "+s"(xp), [phase] "+s"(phase)
-                                 : [ns] "s"(nsets), [tp] "s"(tp), [lane16] "v"(lane16), [voff4] "v"(voff4), [voff8] "v"(voff8)
+                                 : [ns] "s"(nsets), [tp] "s"(tp), [lane16] "v"(lane16), [voff4] "v"(voff4), [voff8] "v"(voff8), [pfl] "v"(pfl)
                                  : ACC_TILEDT_CLOBBERS);
             } else if constexpr (MODE == 4)
                 asm volatile(ACC_TILED4_CHUNK_ASM
@@ -883,10 +887,15 @@ int k_acc_tiled_all(hipStream_t s, const DevTiled& S, const double* F, double* B
     return SGL_OK;
 }
 
-// part size the entry streams are built for at rank k (0: no tiled path): even, at most 64
+// part size the entry streams are built for at rank k (0: no tiled path): even, at most 64.  A pass costs the same whatever its
+// part size within a layout (one address add, one ds_read_b128, two FMAs per entry tuple), and the quad layout of parts up to 32
+// serves FOUR columns per tuple where the pair layout serves two: ranks 65 - 96 run as THREE quad passes (1.5 x the cost of a
+// k = 64 pass) instead of two pair passes (2 x); 97 - 128 as two pair passes (four quad passes would cost the same).
+// One pass over half-height tiles with four factors per lane was priced and loses: 15 % more LDS time than the two passes
+// (scripts/r5/r5_pad_model.py).  SGL_TILED_NO_QUAD3=1: two pair passes (A/B, tests).
 int tiled_part_size(int k) {
     if (k <= 64) return k;
     if (k > 128) return 0;
-    const int parts = (k + 63) / 64;
+    const int parts = (k <= 96 && !getenv("SGL_TILED_NO_QUAD3") && !getenv("SGL_TILED_NO_QUAD")) ? 3 : (k + 63) / 64;
     return ((k + parts - 1) / parts + 1) & ~1;
 }

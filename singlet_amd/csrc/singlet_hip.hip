@@ -750,6 +750,14 @@ static int gene_counts(sgl_ctx* c, const int64_t** out) {
 int sgl_nnls_shared(sgl_ctx* c, const double* G, double* B, double* X, const int64_t* col_nnz, int64_t ncols,
                        double L1, double L2, unsigned long long* counter, bool h_side) {
     const int k = c->k;
+    // A solve of a few thousand columns leaves the lane-per-column kernel on a few dozen waves, bound by the length of ONE wave's
+    // sweeps; four columns per wave (kernels_nnls.hip, nnls_quad_shared_kernel) is shorter there: a rank's gene block on a team,
+    // small matrices.  Same bits either way.  (SGL_NNLS_QUAD_SHARED_MAX_COLS: the column count up to which it runs; 0 = never)
+    {
+        const char* e = getenv("SGL_NNLS_QUAD_SHARED_MAX_COLS");   // read per call (two per iteration): the tests switch it
+        const long long qs_max = e ? atoll(e) : 8192ll;
+        if (k >= 12 && k <= 64 && ncols <= qs_max) return k_nnls_quad_shared(c->stream, G, B, X, col_nnz, k, ncols, L1, L2, counter);
+    }
     if (k <= SGL_LANE_NNLS_MAX_K) {
         const int KP = lane_kp(k);
         SGLCHK(k_pad_gram(c->stream, G, k, KP, nnls_gram_stride(KP), c->Gpad));
@@ -1553,7 +1561,9 @@ extern "C" int sgl_op_nnls(sgl_ctx* c, const double* G, const double* B, double*
     HIPCHK(hipMemsetAsync(c->sweep_counters + 4, 0, 4 * sizeof(unsigned long long), c->stream));
     int rc;
     NnlsScratch scr;  // re-pack passes only pay off (and are only used) for many columns
-    if (k <= SGL_LANE_NNLS_MAX_K) {
+    if (k <= 64 && getenv("SGL_OP_NNLS_QUAD_SHARED")) {   // tests: the four-columns-per-wave solve of short launches (sgl_nnls_shared)
+        rc = k_nnls_quad_shared(c->stream, dG.p, dB.p, dX.p, nullptr, k, ncols, L1, L2, c->sweep_counters + 4);
+    } else if (k <= SGL_LANE_NNLS_MAX_K) {
         const int KP = lane_kp(k);
         rc = dGp.alloc((size_t)SGL_LANE_NNLS_MAX_K * (SGL_LANE_NNLS_MAX_K + 16) + 64);
         if (rc == SGL_OK) rc = k_pad_gram(c->stream, dG.p, k, KP, nnls_gram_stride(KP), dGp.p);

@@ -729,3 +729,30 @@ def test_rhs_tiled_random_structures(sa, ora, case, monkeypatch):
             assert np.array_equal(got, plain), (k, m, n, style, ranges)
         else:
             assert rel_fro(got, plain) < 1e-13
+
+
+@pytest.mark.parametrize("k", [1, 7, 12, 16, 17, 30, 32, 33, 48, 49, 50, 63, 64])
+def test_nnls_four_columns_per_wave_on_a_shared_gram_matches_the_lane_kernel(ctx, ora, k, monkeypatch):
+    """Short launches against a shared Gram (a rank's gene block on a team, small matrices) run four columns per wave with the
+    Gram staged in LDS (nnls_quad_shared_kernel, round 5) instead of a lane per column: same operations in the same order --
+    bit-identical solutions and equal sweep totals, ragged column counts (partial quads, partial workgroups), and the oracle's
+    solution to 1e-9."""
+    rng = np.random.default_rng(700 + k)
+    F = rng.random((3 * k + 5, k))
+    G = F.T @ F + 1e-15 * np.eye(k)
+    for ncols in (1, 3, 4, 1000 + 37, 3750):
+        B = rng.normal(size=(ncols, k)) * 3 + 1.0
+        B *= np.exp(rng.normal(size=(ncols, 1)) * 2)
+        X0 = np.abs(rng.normal(size=(ncols, k))) * (rng.random((ncols, k)) < 0.5) * 1e-3
+        monkeypatch.delenv("SGL_OP_NNLS_QUAD_SHARED", raising=False)
+        Xl, sl = ctx.op_nnls(G, B, X0, 0.02, 0.01)
+        monkeypatch.setenv("SGL_OP_NNLS_QUAD_SHARED", "1")
+        Xq, sq = ctx.op_nnls(G, B, X0, 0.02, 0.01)
+        assert np.array_equal(Xl, Xq) and sl == sq, (k, ncols)
+    tot = 0
+    for c in range(40):     # the oracle solves one column per call
+        xo, _, it = ora.nnls(G, B[c], X0[c], 0.02, 0.01)
+        tot += it
+        assert np.linalg.norm(Xq[c] - xo) <= 1e-9 * max(np.linalg.norm(xo), 1e-300) and np.array_equal(Xq[c] == 0, xo == 0)
+    Xs, ss = ctx.op_nnls(G, B[:40], X0[:40], 0.02, 0.01)
+    assert ss == tot and np.array_equal(Xs, Xq[:40])

@@ -25,8 +25,11 @@ def _device_asm(src, tmpdir):
     unit = os.path.splitext(os.path.basename(src))[0]
     kept = os.path.join(CSRC, "asm", unit + ".s")
     deps = [src] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))] + [os.path.join(ROOT, "include", "singlet_hip.h")]
-    gen = os.path.join(CSRC, "gen_acc_tiled.py")
-    if os.path.exists(kept) and all(os.path.getmtime(kept) >= os.path.getmtime(d) for d in deps + [gen]):
+    if unit == "kernels_tiled":
+        deps.append(os.path.join(CSRC, "gen_acc_tiled.py"))
+    else:
+        deps = [d for d in deps if not d.endswith("acc_tiled_gen.inc")]
+    if os.path.exists(kept) and all(os.path.getmtime(kept) >= os.path.getmtime(d) for d in deps):
         return open(kept).read()
     out = os.path.join(str(tmpdir), unit + ".s")
     subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-S",
