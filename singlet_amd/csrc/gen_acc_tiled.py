@@ -409,10 +409,15 @@ class GenTab(GenQuad):
         A = self.A
         x = self.QEX[d]
         abl = os.environ.get("SGL_GEN_ABLATE", "")   # timing ablations only (results are wrong): nofma, noread, noadd
+        # LDS waits: one per W entry tuples (SGL_GEN_WAIT, default 4 = one per group).  Before tuple j the wave has 8 reads in
+        # flight (8 - j of this octet, j of the next); the next W tuples need the W oldest: lgkmcnt(8 - W) -- without reads
+        # ahead (a chunk's last octet) 8 - j - W.
+        W_ = int(os.environ.get("SGL_GEN_WAIT", "4"))
         for g in range(2):
             self.group_head_tab(d, o, g)
-            A(f"s_waitcnt lgkmcnt({4 if reads else 4 - 4 * g})")
             for j in range(4 * g, 4 * g + 4):
+                if j % W_ == 0:
+                    A(f"s_waitcnt lgkmcnt({8 - W_ if reads else 8 - j - W_})")
                 bc = f"row_newbcast:{8 * o + j} row_mask:0xf bank_mask:0xf"
                 if "nofma" not in abl:
                     A(f"v_fmac_f64_dpp {r2(ACC)}, {r2(x)}, {r2(W[j])} {bc}")

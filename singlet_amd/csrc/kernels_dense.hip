@@ -206,11 +206,40 @@ __global__ void partial_sum_stage2_kernel(const double* __restrict__ tmp, int ns
     if (diag_k > 0 && e % diag_k == e / diag_k) s += diag_add;
     out[e] = s;
 }
+// Short vectors (the k row sums: n x segments <= 1024) in ONE launch, the same two stages inside one workgroup -- thread
+// (segment s, entry e) sums its segment's blocks in order, then thread e the segments in order: the bits of the two-kernel
+// form, one launch instead of two (round 5: at the 125 000-cell shard of an 8-GPU team the small launches of an iteration add up
+// to a third of a millisecond).  add_all: + 1e-15 on every entry (scale's d, src/singlet.cpp:221) instead of a separate kernel.
+__global__ __launch_bounds__(1024) void partial_sum_small_kernel(const double* __restrict__ part, int nblocks, int n, int nseg, double add_all,
+                                                                 double* __restrict__ out) {
+    __shared__ double tmp[1024];
+    const int t = threadIdx.x;
+    const int sgm = t / n, e = t - sgm * n;
+    if (sgm < nseg) {
+        const int b0 = sgm * SGL_RED_SEG;
+        const int b1 = (b0 + SGL_RED_SEG < nblocks) ? b0 + SGL_RED_SEG : nblocks;
+        double s = 0.0;
+        for (int b = b0; b < b1; ++b) s += part[(size_t)b * n + e];
+        tmp[t] = s;
+    }
+    __syncthreads();
+    if (t < n) {
+        double s = 0.0;
+        for (int q = 0; q < nseg; ++q) s += tmp[q * n + t];
+        out[t] = s + add_all;
+    }
+}
 // part: nblocks x n partials at the start of c->ws; the segment sums go behind them (the caller reserved
 // sgl_partial_ws(nblocks, n) doubles)
 static size_t sgl_partial_ws(int nblocks, int n) { return (size_t)nblocks * n + (size_t)((nblocks + SGL_RED_SEG - 1) / SGL_RED_SEG) * n; }
-static int sgl_partial_sum(sgl_ctx* c, int nblocks, int n, int diag_k, double diag_add, double* out) {
+static int sgl_partial_sum(sgl_ctx* c, int nblocks, int n, int diag_k, double diag_add, double* out, double add_all = 0.0) {
     const int nseg = (nblocks + SGL_RED_SEG - 1) / SGL_RED_SEG;
+    if (diag_k == 0 && n * nseg <= 1024) {
+        partial_sum_small_kernel<<<dim3(1), dim3(1024), 0, c->stream>>>(c->ws, nblocks, n, nseg, add_all, out);
+        HIPCHK(hipGetLastError());
+        return SGL_OK;
+    }
+    if (add_all != 0.0) { sgl_set_error("partial sum: add_all only in the short form"); return SGL_EINVAL; }
     double* tmp = c->ws + (size_t)nblocks * n;
     partial_sum_stage1_kernel<<<dim3((n + 255) / 256, nseg), dim3(256), 0, c->stream>>>(c->ws, nblocks, n, tmp);
     HIPCHK(hipGetLastError());
@@ -290,7 +319,7 @@ __global__ __launch_bounds__(256) void rowsum_kernel(const double* __restrict__ 
 }
 
 
-int k_rowsum(sgl_ctx* c, const double* F, int k, int64_t cols, double* d_out) {
+int k_rowsum(sgl_ctx* c, const double* F, int k, int64_t cols, double* d_out, int add_eps) {
     // enough blocks to fill the chip at shard sizes too (125 000 cells used to get 62: 72 us for a 50 MB read)
     int nblocks = (int)((cols + 511) / 512);
     if (nblocks > 512) nblocks = 512;
@@ -299,7 +328,18 @@ int k_rowsum(sgl_ctx* c, const double* F, int k, int64_t cols, double* d_out) {
     SGLCHK(sgl_ws_reserve(c, sizeof(double) * sgl_partial_ws(nblocks, k)));
     rowsum_kernel<<<dim3(nblocks), dim3(256), 0, c->stream>>>(F, k, cols, cpb, c->ws);
     HIPCHK(hipGetLastError());
-    return sgl_partial_sum(c, nblocks, k, 0, 0.0, d_out);
+    // add_eps: d += 1e-15 (src/singlet.cpp:221) inside the final stage -- short form only (k x segments <= 1024), else the caller's
+    // k_scale_apply(add_eps = 1) does it as before
+    const int nseg = (nblocks + SGL_RED_SEG - 1) / SGL_RED_SEG;
+    if (add_eps && k * nseg > 1024) { sgl_set_error("k_rowsum: add_eps needs the short form"); return SGL_EINVAL; }
+    return sgl_partial_sum(c, nblocks, k, 0, 0.0, d_out, add_eps ? 1e-15 : 0.0);
+}
+// whether k_rowsum(..., add_eps = 1) is available at this rank (the caller then skips the add_eps of k_scale_apply)
+bool k_rowsum_can_add_eps(int k, int64_t cols) {
+    int nblocks = (int)((cols + 511) / 512);
+    if (nblocks > 512) nblocks = 512;
+    if (nblocks < 1) nblocks = 1;
+    return k * ((nblocks + SGL_RED_SEG - 1) / SGL_RED_SEG) <= 1024;
 }
 
 // d[i] += 1e-15 (once, by the add_eps kernel) and F[i, c] /= d[i]  (src/singlet.cpp:221-224)
@@ -350,6 +390,63 @@ __global__ __launch_bounds__(256) void cor_partial_kernel(const double* __restri
     if (threadIdx.x < 5) part[(size_t)blockIdx.x * 5 + threadIdx.x] = sm[threadIdx.x][0];
 }
 
+// The same with the final stage inside (round 5): the block that finishes LAST -- a ticket counter behind the partials, left at
+// zero for the next call -- sums the five columns of partials in block order and forms cor: the arithmetic of
+// cor_final_kernel in the same order, one launch instead of two.
+__global__ __launch_bounds__(256) void cor_fused_kernel(const double* __restrict__ x, const double* __restrict__ y, int64_t n,
+                                                        double* __restrict__ part, unsigned* __restrict__ ticket, double* __restrict__ out) {
+    double s[5] = {0, 0, 0, 0, 0};
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        const double a = x[t], b = y[t];
+        s[0] += a;
+        s[1] += b;
+        s[2] = fma(a, b, s[2]);
+        s[3] = fma(a, a, s[3]);
+        s[4] = fma(b, b, s[4]);
+    }
+    __shared__ double sm[5][256];
+    __shared__ bool last;
+    for (int q = 0; q < 5; ++q) sm[q][threadIdx.x] = s[q];
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w)
+            for (int q = 0; q < 5; ++q) sm[q][threadIdx.x] += sm[q][threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x < 5) part[(size_t)blockIdx.x * 5 + threadIdx.x] = sm[threadIdx.x][0];
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    const int nblocks = (int)gridDim.x;
+    const int lane = threadIdx.x;
+    if (lane >= 64) return;
+    double mine = 0.0;
+    if (lane < 5) {
+        int b = 0;
+        for (; b + 8 <= nblocks; b += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = __hip_atomic_load(&part[(size_t)(b + u) * 5 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) mine += v[u];
+        }
+        for (; b < nblocks; ++b) mine += __hip_atomic_load(&part[(size_t)b * 5 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // agent scope: not from this CU's L1
+    }
+    double t5[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) t5[q] = __shfl(mine, q, 64);
+    if (lane != 0) return;
+    *ticket = 0u;
+    const double nn = (double)n;
+    const double num = __dsub_rn(__dmul_rn(nn, t5[2]), __dmul_rn(t5[0], t5[1]));
+    const double vx = __dsub_rn(__dmul_rn(nn, t5[3]), __dmul_rn(t5[0], t5[0]));
+    const double vy = __dsub_rn(__dmul_rn(nn, t5[4]), __dmul_rn(t5[1], t5[1]));
+    out[0] = 1.0 - num / sqrt(__dmul_rn(vx, vy));
+}
+
 __global__ void cor_final_kernel(const double* __restrict__ part, int nblocks, int64_t n, double* __restrict__ out) {
     if (blockIdx.x != 0) return;
     // the five sums in block order (one lane each, loads eight blocks ahead: one thread walking all 5 x nblocks
@@ -385,6 +482,11 @@ int k_cor(sgl_ctx* c, const double* x, const double* y, int64_t n, double* out_d
     if (nblocks > 512) nblocks = 512;
     if (nblocks < 1) nblocks = 1;
     SGLCHK(sgl_ws_reserve(c, sizeof(double) * 5 * (size_t)nblocks));
+    if (!getenv("SGL_COR_TWO_KERNELS")) {   // one launch: the last block to finish forms the result (ticket at c->scalars[8], zero between calls)
+        cor_fused_kernel<<<dim3(nblocks), dim3(256), 0, c->stream>>>(x, y, n, c->ws, reinterpret_cast<unsigned*>(c->scalars + 8), out_dev);
+        HIPCHK(hipGetLastError());
+        return SGL_OK;
+    }
     cor_partial_kernel<<<dim3(nblocks), dim3(256), 0, c->stream>>>(x, y, n, c->ws);
     HIPCHK(hipGetLastError());
     cor_final_kernel<<<dim3(1), dim3(64), 0, c->stream>>>(c->ws, nblocks, n, out_dev);

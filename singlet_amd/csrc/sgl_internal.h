@@ -247,7 +247,8 @@ int k_build_segments(hipStream_t s, const DevCSC& M);
 // dense helpers
 int k_gram(sgl_ctx* c, const double* F, int k, int64_t cols, double* G, double diag_add);
 int k_gram_add_diag(hipStream_t s, double* G, int k, double v);
-int k_rowsum(sgl_ctx* c, const double* F, int k, int64_t cols, double* d_out);  // no +1e-15
+int k_rowsum(sgl_ctx* c, const double* F, int k, int64_t cols, double* d_out, int add_eps = 0);  // add_eps: + 1e-15 in the final stage
+bool k_rowsum_can_add_eps(int k, int64_t cols);
 int k_scale_apply(hipStream_t s, double* F, int k, int64_t cols, double* d, int add_eps);
 int k_cor(sgl_ctx* c, const double* x, const double* y, int64_t n, double* out_dev);
 int k_pad_gram(hipStream_t s, const double* G, int k, int KP, int GS, double* Gpad);
@@ -315,6 +316,7 @@ void sgl_mask_list_free(DevMaskList& L);
 int sgl_mask_list_select(sgl_ctx* c, int which, int64_t ncol, int32_t nrow, uint64_t seed, uint64_t inv_density, int mask_t,
                          int64_t col_offset, int64_t row_offset);
 void sgl_mask_lists_free_all(sgl_ctx* c);
+bool sgl_mask_lists_release_kept(sgl_ctx* c);   // memory pressure: drop the kept (not the current) masks; true if anything was freed
 int k_mask_gram_finalize(hipStream_t s, const double* G, const double* S, int k, int64_t ncols, double* out);
 int k_mse_test(sgl_ctx* c, const double* Wd, const double* H, int k, uint64_t seed, uint64_t inv_density,
                double* out_dev);

@@ -205,7 +205,8 @@ extern "C" int sgl_create(int device, sgl_ctx** out) {
     c->stream = c->own_stream;
     if (e == hipSuccess) {
         rc = dev_alloc(&c->scalars, 16);
-        if (rc == SGL_OK) rc = dev_alloc(&c->sweep_counters, 8);
+        if (rc == SGL_OK) e = hipMemsetAsync(c->scalars, 0, 16 * sizeof(double), c->stream);   // [8]: ticket of k_cor's last-block stage
+        if (rc == SGL_OK && e == hipSuccess) rc = dev_alloc(&c->sweep_counters, 8);
         if (rc == SGL_OK) e = hipMemsetAsync(c->sweep_counters, 0, 8 * sizeof(unsigned long long), c->stream);
         if (rc == SGL_OK && e == hipSuccess) e = hipHostMalloc((void**)&c->pinned, 16 * sizeof(double), hipHostMallocDefault);
     }
@@ -704,7 +705,11 @@ extern "C" int sgl_fit_init(sgl_ctx* c, int32_t k, const double* w_init, uint64_
     }
     HIPCHK(hipStreamSynchronize(c->stream));
     free_fit(c, true);
-    const int rc = fit_init_impl(c, k, w_init, synth_seed);
+    int rc = fit_init_impl(c, k, w_init, synth_seed);
+    if (rc == SGL_ENOMEM && sgl_mask_lists_release_kept(c)) {   // the kept masks of earlier fits are a cache: give them back and try once more
+        free_fit(c, true);
+        rc = fit_init_impl(c, k, w_init, synth_seed);
+    }
     if (rc != SGL_OK) { free_fit(c); return rc; }   // a half-built fit must not pass FIT_GUARD
     c->k = k;
     return SGL_OK;
@@ -793,9 +798,11 @@ extern "C" int sgl_step_h(sgl_ctx* c, double L1, double L2) {
 extern "C" int sgl_step_scale_h(sgl_ctx* c) {
     FIT_GUARD(c);
     if (c->team && sgl_team_size(c) > 1) { sgl_set_error("step API on a native team: use sgl_nmf_iterate / sgl_multi_iterate"); return SGL_ESTATE; }
-    { Phase ph(c, SGL_PH_SCALE); SGLCHK(k_rowsum(c, c->H, c->k, c->A.ncol, c->d)); }
+    // (one shard: the + 1e-15 of l.221 rides in the row sums' final stage; with a hook the sums are all-reduced first)
+    const int eps_in_sum = (!c->allreduce && k_rowsum_can_add_eps(c->k, c->A.ncol)) ? 1 : 0;
+    { Phase ph(c, SGL_PH_SCALE); SGLCHK(k_rowsum(c, c->H, c->k, c->A.ncol, c->d, eps_in_sum)); }
     SGLCHK(do_allreduce(c, c->d, c->k));
-    { Phase ph(c, SGL_PH_SCALE); SGLCHK(k_scale_apply(c->stream, c->H, c->k, c->A.ncol, c->d, 1)); }
+    { Phase ph(c, SGL_PH_SCALE); SGLCHK(k_scale_apply(c->stream, c->H, c->k, c->A.ncol, c->d, eps_in_sum ? 0 : 1)); }
     return SGL_OK;
 }
 
@@ -831,8 +838,9 @@ int sgl_scale_w_enqueue(sgl_ctx* c) {
     const int k = c->k;
     const int64_t m = c->A.nrow;
     Phase ph(c, SGL_PH_SCALE);
-    SGLCHK(k_rowsum(c, c->W, k, m, c->d));
-    SGLCHK(k_scale_apply(c->stream, c->W, k, m, c->d, 1));
+    const int eps_in_sum = k_rowsum_can_add_eps(k, m) ? 1 : 0;
+    SGLCHK(k_rowsum(c, c->W, k, m, c->d, eps_in_sum));
+    SGLCHK(k_scale_apply(c->stream, c->W, k, m, c->d, eps_in_sum ? 0 : 1));
     SGLCHK(k_cor(c, c->W, c->Wprev, (int64_t)k * m, c->scalars));
     return SGL_OK;
 }
@@ -931,7 +939,9 @@ int sgl_mask_workspace(sgl_ctx* c) {
         const char* e = getenv("SGL_GCOLS_MB");
         const int64_t mb = (e && atoll(e) > 0) ? atoll(e) : std::min<int64_t>(16384, std::max<int64_t>(256, (int64_t)(free_b >> 23)));
         const int64_t chunk = std::max<int64_t>(256, std::min<int64_t>(widest, (mb << 20) / ((int64_t)k * k * 8)));
-        SGLCHK(dev_alloc(&c->Gcols, (size_t)chunk * k * k));
+        int rc = dev_alloc(&c->Gcols, (size_t)chunk * k * k);
+        if (rc == SGL_ENOMEM && sgl_mask_lists_release_kept(c)) rc = dev_alloc(&c->Gcols, (size_t)chunk * k * k);
+        SGLCHK(rc);
         c->gcols_chunk = chunk;
     }
     if (!c->Wd) SGLCHK(dev_alloc(&c->Wd, (size_t)k * c->A.nrow));

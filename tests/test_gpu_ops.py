@@ -208,7 +208,8 @@ def test_rhs_tiled_tail_split(sa, ora, k, monkeypatch):
     have their tile range cut into pieces (own compact slabs, summed in piece order).  140 000 cells x 2500 genes: 274 (137
     at k <= 32) groups of 512 (1024) columns; with and without the tail split (SGL_TILED_NO_TAIL) the sums agree to rounding,
     and both with the oracle."""
-    A = ora.synth_csc(2500, 280000 if k <= 32 else 140000, 20)
+    quad = k <= 32 or 64 < k <= 96      # four columns per tuple: ranks up to 32, and the three passes of ranks 65 - 96 (round 5)
+    A = ora.synth_csc(2500, 280000 if quad else 140000, 20)
     rng = np.random.default_rng(k)
     W = rng.random((A.nrow, k))
     out = {}
@@ -756,3 +757,37 @@ def test_nnls_four_columns_per_wave_on_a_shared_gram_matches_the_lane_kernel(ctx
         assert np.linalg.norm(Xq[c] - xo) <= 1e-9 * max(np.linalg.norm(xo), 1e-300) and np.array_equal(Xq[c] == 0, xo == 0)
     Xs, ss = ctx.op_nnls(G, B[:40], X0[:40], 0.02, 0.01)
     assert ss == tot and np.array_equal(Xs, Xq[:40])
+
+
+@pytest.mark.parametrize("k", [49, 50])
+def test_nnls_generated_sweep_matches_the_compiled_kernel(ctx, ora, k, monkeypatch):
+    """Round 5: at the ranks it has instances for, the lane-per-column solve runs its sweep as generated, hand-scheduled asm
+    (gen_nnls_lane.py: a coordinate's serial step chain interleaved with its neighbours' row-update FMAs).  Same operations in
+    the same order per column: bit-identical solutions and equal sweep totals against the hipcc-scheduled kernel
+    (SGL_NNLS_NO_ASM=1), one pass and re-packed passes, ragged column counts, penalties on and off, warm and cold starts; and
+    the oracle's solution column by column."""
+    rng = np.random.default_rng(900 + k)
+    F = rng.random((3 * k + 5, k))
+    G = F.T @ F + 1e-15 * np.eye(k)
+    for ncols, L1, L2 in ((1, 0.0, 0.0), (63, 0.02, 0.0), (64 * 5 + 7, 0.02, 0.01), (5000 + 37, 0.0, 0.03)):
+        B = rng.normal(size=(ncols, k)) * 3 + 1.0
+        B *= np.exp(rng.normal(size=(ncols, 1)) * 2)
+        X0 = np.abs(rng.normal(size=(ncols, k))) * (rng.random((ncols, k)) < 0.5) * 1e-3
+        out = {}
+        for asm in (True, False):
+            for repack in (False, True):
+                if asm:
+                    monkeypatch.delenv("SGL_NNLS_NO_ASM", raising=False)
+                else:
+                    monkeypatch.setenv("SGL_NNLS_NO_ASM", "1")
+                if repack:
+                    monkeypatch.setenv("SGL_NNLS_REPACK_MIN_COLS", "512")
+                else:
+                    monkeypatch.delenv("SGL_NNLS_REPACK_MIN_COLS", raising=False)
+                out[(asm, repack)] = ctx.op_nnls(G, B, X0, L1, L2)
+        X, s = out[(False, False)]
+        for key, (Xo, so) in out.items():
+            assert np.array_equal(X, Xo) and s == so, (key, ncols)
+    for c in range(30):
+        xo, _, it = ora.nnls(G, B[c], X0[c], L1, L2)
+        assert np.linalg.norm(X[c] - xo) <= 1e-9 * max(np.linalg.norm(xo), 1e-300) and np.array_equal(X[c] == 0, xo == 0)
