@@ -33,14 +33,27 @@ KPS = [int(a) for a in sys.argv[1:]] or [50]
 
 
 def plan(KP):
+    """Registers from the bottom: the compiler's v[0 : V_T - 1] (28, or what is left of 256 at the largest ranks: 16 at KP = 50),
+    then T, D, G, B, X.  TOP = registers the kernel needs: small ranks leave room for more than two waves per SIMD.
+    Above KP = 50 b and x no longer fit 256 registers: x then lives in the ACCUMULATOR half of the register file, a[0 : 2 KP - 1]
+    (one wave per SIMD; a coordinate reads its x_i once and writes it once: two v_accvgpr moves each way), T grows by the
+    copies of x_i the chain works on."""
     NG = (KP + 15) // 16
     NGP = (NG + 1) & ~1                 # doubles per lane and row in LDS: even, so that a lane's piece starts 16-byte aligned
-    V_X = 256 - 2 * KP
-    V_B = V_X - 2 * KP
-    V_G = V_B - 4 * NG
-    V_D = V_G - 4
-    V_T = V_D - 20
-    return dict(KP=KP, NG=NG, NGP=NGP, V_T=V_T, V_D=V_D, V_G=V_G, V_B=V_B, V_X=V_X)
+    xa = 20 + 4 + 4 * NG + 4 * KP + 16 > 256
+    nt = 26 if xa else 20
+    own = nt + 4 + 4 * NG + (2 * KP if xa else 4 * KP)
+    V_T = max(16, min(28, 256 - own))
+    if V_T + own > 256 or KP > 64:
+        raise SystemExit("gen_nnls_lane.py: KP = %d does not fit the register file" % KP)
+    V_D = V_T + nt
+    V_G = V_D + 4
+    V_B = V_G + 4 * NG
+    V_X = V_B + 2 * KP                  # (xa: unused -- x is a[0 : 2 KP - 1])
+    TOP = V_X if xa else V_X + 2 * KP
+    total = TOP + (2 * KP if xa else 0)
+    return dict(KP=KP, NG=NG, NGP=NGP, V_T=V_T, V_D=V_D, V_G=V_G, V_B=V_B, V_X=V_X, TOP=TOP, XA=xa, NT=nt,
+                WAVES=max(1, min(8, 512 // ((total + 7) // 8 * 8))))
 
 
 def r2(b):
@@ -57,6 +70,8 @@ class Sweep:
         self.DEN, self.R, self.E, self.Q = T + 8, T + 10, T + 12, T + 14
         self.TOL = T + 16                   # the column's running tol
         self.GM = T + 18                    # 1.0 / 0.0: the stopped-column gate of this sweep
+        self.XH = [T + 20, T + 22]          # XA: x_i as the chain reads it (by coordinate parity), XN its new value
+        self.XN = T + 24
         self.L = []
 
     def b(self, j):
@@ -71,8 +86,12 @@ class Sweep:
     def head(self, i):
         """chain of coordinate i up to nd_i: reads b_i, x_i, D = (G_ii, 1 / G_ii)"""
         A, E2, ND = self.A, self.E2, self.ND[i & 1]
-        b, x, gii, rii = self.b(i), self.x(i), self.V_D, self.V_D + 2
-        ops = [
+        b, gii, rii = self.b(i), self.V_D, self.V_D + 2
+        x = self.XH[i & 1] if self.XA else self.x(i)
+        ops = []
+        if self.XA:   # x_i out of the accumulator file
+            ops += [f"v_accvgpr_read_b32 v{x}, a{2 * i}", f"v_accvgpr_read_b32 v{x + 1}, a{2 * i + 1}"]
+        ops += [
             f"v_mul_f64 {r2(A)}, {r2(b)}, {r2(rii)}",
             f"v_fma_f64 {r2(E2)}, -{r2(A)}, {r2(gii)}, {r2(b)}",
             f"v_fma_f64 {r2(A)}, {r2(E2)}, {r2(rii)}, {r2(A)}",      # b_i / G_ii, correctly rounded (Markstein)
@@ -93,9 +112,13 @@ class Sweep:
     def tail(self, i):
         """the rest of coordinate i's chain: x_i <- x_i - nd, tol += |nd / (x_i + 1e-15)| or tol = 1"""
         ND, DEN, R, E, Q = self.ND[i & 1], self.DEN, self.R, self.E, self.Q
-        x = self.x(i)
-        return [
-            f"v_add_f64 {r2(x)}, {r2(x)}, -{r2(ND)}",
+        if self.XA:
+            xo, x = self.XH[i & 1], self.XN
+            first = [f"v_add_f64 {r2(x)}, {r2(xo)}, -{r2(ND)}", f"v_accvgpr_write_b32 a{2 * i}, v{x}", f"v_accvgpr_write_b32 a{2 * i + 1}, v{x + 1}"]
+        else:
+            x = self.x(i)
+            first = [f"v_add_f64 {r2(x)}, {r2(x)}, -{r2(ND)}"]
+        return first + [
             f"v_add_f64 {r2(DEN)}, {r2(x)}, %[eps]",
             f"v_rcp_f64 {r2(R)}, {r2(DEN)}",
             f"v_fma_f64 {r2(E)}, -{r2(DEN)}, {r2(R)}, 1.0",
@@ -135,6 +158,8 @@ class Sweep:
             self.L.append(f"v_cndmask_b32_e64 v{self.TOL + 1}, v{self.Q + 1}, %[one_hi], s[{c0}:{c0 + 1}]")
             return
         c0 = 40 + 2 * (cmp_slot & 1)
+        if self.L and self.L[-1].startswith("v_rcp_f64") and r2(self.R) in s:
+            self.L.append("s_nop 0")   # transcendental result -> VALU read: one wait state (only where no FMA separates them)
         self.L.append(s.replace("{c0}", str(c0)).replace("{c0p}", str(c0 + 1)))
 
     def build(self):
@@ -191,6 +216,7 @@ def kernel_body(KP):
     def go_mask():
         # go = valid && it < 100 && tol / k > 1e-8   (src/singlet.cpp:231; the quotient correctly rounded: sgl_div_normal)
         A(f"v_rcp_f64 {r2(R)}, %[kd]")
+        A("s_nop 1")     # a transcendental's result needs a wait state before a VALU instruction reads it (gfx940+)
         A(f"v_fma_f64 {r2(E)}, -%[kd], {r2(R)}, 1.0")
         A(f"v_fma_f64 {r2(R)}, {r2(R)}, {r2(E)}, {r2(R)}")
         A(f"v_fma_f64 {r2(E)}, -%[kd], {r2(R)}, 1.0")
@@ -199,8 +225,10 @@ def kernel_body(KP):
         A(f"v_fma_f64 {r2(E)}, -%[kd], {r2(Q)}, {r2(TOL)}")
         A(f"v_fma_f64 {r2(Q)}, {r2(E)}, {r2(R)}, {r2(Q)}")
         A("v_cmp_gt_u32_e32 vcc, 100, %[it]")
+        A("s_nop 3")
         A(f"s_mov_b64 {c1}, vcc")
         A(f"v_cmp_lt_f64_e32 vcc, %[thr], {r2(Q)}")
+        A("s_nop 3")
         A(f"s_and_b64 {go}, vcc, {c1}")
         A(f"s_and_b64 {go}, {go}, %[valid]")
 
@@ -214,13 +242,17 @@ def kernel_body(KP):
         A("1:")
         A(f"s_mov_b64 exec, {sv}")
 
-    for r in range(s.V_B, 256):
+    for r in range(s.V_B, s.TOP):
         A(f"v_mov_b32 v{r}, 0")
+    if s.XA:
+        for r in range(2 * KP):
+            A(f"v_accvgpr_write_b32 a{r}, 0")
+    xr = (lambda q: f"a[{2 * q}:{2 * q + 1}]") if s.XA else (lambda q: r2(s.x(q)))
     j = KP - 1
     masked("%[valid]", [f"global_load_dwordx2 {r2(s.b(q))}, %[bp], off offset:{8 * q}" for q in range(KP - 1)],
            f"global_load_dwordx2 {r2(s.b(j))}, %[bp], off offset:{8 * j}")
-    masked("%[valid]", [f"global_load_dwordx2 {r2(s.x(q))}, %[xp], off offset:{8 * q}" for q in range(KP - 1)],
-           f"global_load_dwordx2 {r2(s.x(j))}, %[xp], off offset:{8 * j}")
+    masked("%[valid]", [f"global_load_dwordx2 {xr(q)}, %[xp], off offset:{8 * q}" for q in range(KP - 1)],
+           f"global_load_dwordx2 {xr(j)}, %[xp], off offset:{8 * j}")
     A("s_waitcnt vmcnt(0)")
     A(f"v_mov_b32 v{TOL}, %[lo]")
     A(f"v_mov_b32 v{TOL + 1}, %[hi]")
@@ -250,8 +282,8 @@ def kernel_body(KP):
     A("3:")                                      # ---- {go} = the columns left unfinished (only when the pass re-packs)
     A(f"v_mov_b32 %[lo], v{TOL}")
     A(f"v_mov_b32 %[hi], v{TOL + 1}")
-    masked("%[valid]", [f"global_store_dwordx2 %[xp], {r2(s.x(q))}, off offset:{8 * q}" for q in range(KP - 1)],
-           f"global_store_dwordx2 %[xp], {r2(s.x(j))}, off offset:{8 * j}")
+    masked("%[valid]", [f"global_store_dwordx2 %[xp], {xr(q)}, off offset:{8 * q}" for q in range(KP - 1)],
+           f"global_store_dwordx2 %[xp], {xr(j)}, off offset:{8 * j}")
     masked(go, [f"global_store_dwordx2 %[bp], {r2(s.b(q))}, off offset:{8 * q}" for q in range(KP - 1)],
            f"global_store_dwordx2 %[bp], {r2(s.b(j))}, off offset:{8 * j}")
     A(f"s_mov_b64 %[um], {go}")
@@ -268,7 +300,9 @@ def main():
         out.append(f"// ---- KP = {KP}: T v{p['V_T']}, D v{p['V_D']}, G v{p['V_G']}, B v{p['V_B']}, X v{p['V_X']}")
         out.append(f"#define NNLS_ASM_VT_{KP} {p['V_T']}")
         out.append(f"#define NNLS_ASM_NGP_{KP} {p['NGP']}")
-        out.append(f"#define NNLS_ASM_VCLOB_{KP} " + ", ".join(f'"v{r}"' for r in range(p['V_T'], 256)))
+        out.append(f"#define NNLS_ASM_WAVES_{KP} {p['WAVES']}")
+        out.append(f"#define NNLS_ASM_VCLOB_{KP} " + ", ".join([f'"v{r}"' for r in range(p['V_T'], p['TOP'])] +
+                                                                ([f'"a{r}"' for r in range(2 * KP)] if p['XA'] else [])))
         out.append(f"#define NNLS_ASM_BODY_{KP} \\\n{s.text(L)}")
         out.append("")
     sys.stdout.write("\n".join(out) + "\n")

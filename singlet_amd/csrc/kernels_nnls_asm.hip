@@ -10,11 +10,10 @@
 #include "nnls_lane_gen.inc"
 
 #define SGL_DEFINE_NNLS_ASM_KERNEL(KP)                                                                                              \
-    __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void nnls_lane_asm_kernel_##KP(            \
+    __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NNLS_ASM_WAVES_##KP, NNLS_ASM_WAVES_##KP))) void nnls_lane_asm_kernel_##KP(            \
         const double* __restrict__ Gpad, int gs_in, double* __restrict__ B, double* __restrict__ X,                                \
         const int64_t* __restrict__ col_nnz, int k, int64_t ncols, double L1, double L2,                                           \
         unsigned long long* __restrict__ sweep_counter, NnlsPass ps) {                                                             \
-        asm volatile("" ::: "v255");                                                                                                \
         constexpr int NG = (KP + 15) / 16, NGP = NNLS_ASM_NGP_##KP, ROW = 16 * NGP;                                                \
         const int64_t n_in = ps.list ? (int64_t)*ps.count : ncols;                                                                  \
         if ((int64_t)blockIdx.x * blockDim.x >= n_in) return;                                                                       \

@@ -759,8 +759,10 @@ int sgl_nnls_shared(sgl_ctx* c, const double* G, double* B, double* X, const int
     // sweeps; four columns per wave (kernels_nnls.hip, nnls_quad_shared_kernel) is shorter there: a rank's gene block on a team,
     // small matrices.  Same bits either way.  (SGL_NNLS_QUAD_SHARED_MAX_COLS: the column count up to which it runs; 0 = never)
     {
+        // Crossover against the lane kernel with its generated sweep (profiles/r5_quad_shared_crossover.txt): ~128 columns per
+        // factor -- 6400 at k = 50 (0.25 against 0.29 ms at 6000 columns, 0.29 against 0.26 at 12 000), 3840 at k = 30 -- at most 8192.
         const char* e = getenv("SGL_NNLS_QUAD_SHARED_MAX_COLS");   // read per call (two per iteration): the tests switch it
-        const long long qs_max = e ? atoll(e) : 8192ll;
+        const long long qs_max = e ? atoll(e) : std::min<long long>(8192ll, 128ll * k);
         if (k >= 12 && k <= 64 && ncols <= qs_max) return k_nnls_quad_shared(c->stream, G, B, X, col_nnz, k, ncols, L1, L2, counter);
     }
     if (k <= SGL_LANE_NNLS_MAX_K) {

@@ -308,3 +308,58 @@ def test_half_lane_nnls_x_in_agprs(tmp_path_factory):
             assert max(int(x, 0) for x in re.findall(r"\ba\[(0x[0-9a-fA-F]+|\d+)\]", asm_text)) == 2 * kh - 1
         else:
             assert scratch <= 64, "%s spills %d bytes" % (name, scratch)
+
+
+# ---- nnls_lane_asm_kernel_<KP>: the whole solve of a column in ONE asm statement that owns v[V_T : TOP - 1] -----------------------
+ASM_NNLS_SRC = os.path.join(CSRC, "kernels_nnls_asm.hip")
+
+
+def test_generated_nnls_sweep_owns_its_registers(tmp_path_factory):
+    """kernels_nnls_asm.hip keeps b, x and the sweep's working set in named registers v[V_T : TOP - 1] (gen_nnls_lane.py's plan),
+    all clobbers of the one asm statement that holds a column's solve: hipcc must keep its own values (the statement's
+    operands included) below V_T, the kernel descriptor must cover TOP registers and no more (the plan is what sets the waves
+    per SIMD), there must be exactly one such statement per kernel with KP x KP row-update FMAs per sweep, and no scratch access
+    inside it."""
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not installed")
+    subprocess.run(["make", "-C", CSRC, "nnls_lane_gen.inc"], check=True, capture_output=True, timeout=120)
+    inc = open(os.path.join(CSRC, "nnls_lane_gen.inc")).read()
+    kps = [int(v) for v in re.findall(r"X_\((\d+)\)", inc.split("SGL_NNLS_ASM_INSTANCES(X_)")[1].splitlines()[0])]
+    assert kps and max(kps) <= 50
+    text = _device_asm(ASM_NNLS_SRC, tmp_path_factory.mktemp("asm"))
+    for KP in kps:
+        vt = int(re.search(r"#define NNLS_ASM_VT_%d (\d+)" % KP, inc).group(1))
+        clob = re.search(r"#define NNLS_ASM_VCLOB_%d (.*)" % KP, inc).group(1)
+        top = max(int(v) for v in re.findall(r'"v(\d+)"', clob)) + 1
+        m = re.search(r"^(_Z\d+nnls_lane_asm_kernel_%d\w*):[^\n]*\n(.*?)s_endpgm" % KP, text, re.S | re.M)
+        assert m, "nnls_lane_asm_kernel_%d not found" % KP
+        body = m.group(2)
+        meta = text[text.index(".amdhsa_kernel " + m.group(1)):]
+        meta = meta[:meta.index(".end_amdhsa_kernel")]
+        in_asm, worst = False, -1
+        for line in body.splitlines():
+            if "#ASMSTART" in line:
+                in_asm = True
+                continue
+            if "#ASMEND" in line:
+                in_asm = False
+                continue
+            code = line.split(";")[0]
+            if in_asm or not code.strip():
+                continue
+            r = _vregs(code)
+            if r:
+                worst = max(worst, max(r))
+        assert 0 <= worst < vt, "KP=%d: hipcc allocated v%d, the generated sweep owns v[%d:%d]" % (KP, worst, vt, top - 1)
+        nfree = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", meta).group(1))
+        assert top <= nfree <= (top + 7) // 8 * 8, (KP, nfree, top)
+        blocks = [b for b in re.findall(r"#ASMSTART(.*?)#ASMEND", body, re.S) if "v_fmac_f64_dpp" in b]
+        assert len(blocks) == 1
+        assert blocks[0].count("v_fmac_f64_dpp") == KP * KP
+        assert "scratch_" not in blocks[0] and "buffer_" not in blocks[0]
+        # every transcendental result is at least one instruction away from its first reader (gfx940+ hazard)
+        lines = [x.strip() for x in blocks[0].splitlines() if x.strip()]
+        for a, b in zip(lines, lines[1:]):
+            mm = re.match(r"v_rcp_f64 (v\[\d+:\d+\])", a)
+            if mm:
+                assert mm.group(1) not in b.split(",", 1)[-1] or b.startswith("s_nop"), (a, b)
