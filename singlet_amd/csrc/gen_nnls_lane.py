@@ -27,6 +27,7 @@ second SGPR beside a select's mask would break the constant-bus limit), %[l1] %[
 1e-15, k, 1e-8), %[bp] %[xp] (the lane's column of B / X), %[valid] (lanes that own a column), %[it] %[lo] %[hi] (sweeps done,
 tol: in / out), %[toend] %[klast] (run to the end / k == KP), %[ran] (sweeps executed, in / out), %[um] (out: lanes left
 unfinished); s[40:51] and vcc are clobbered."""
+import os
 import sys
 
 KPS = [int(a) for a in sys.argv[1:]] or [50]
@@ -187,10 +188,11 @@ class Sweep:
                     chain.append(tl.pop(0))
             order = ([i + 1] if i + 1 < KP else []) + [j for j in range(KP) if j != i + 1]   # b_{i+1} first: head(i + 1) waits for it
             nf = 0
+            stride = int(os.environ.get("SGL_GEN_NNLS_STRIDE", "2"))   # FMAs per chain instruction (A/B builds; 2: 25 slots for 23)
             for j in order:
                 L.append(self.fma(i, j))
                 nf += 1
-                if nf >= 2 and nf % 2 == 0 and chain:
+                if nf >= 2 and nf % stride == 0 and chain:
                     op, slot = chain.pop(0)
                     self.emit(op, slot)
             for op, slot in chain:   # (short ranks: more chain instructions than FMA pairs)

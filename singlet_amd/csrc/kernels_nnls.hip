@@ -42,7 +42,7 @@ int k_nnls_lane_launch4(hipStream_t s, const double* Gpad, int KP, double* B, do
 int k_nnls_half_launch(hipStream_t s, const double* Gpad, int KP, double* B, double* X, const int64_t* col_nnz, int k,
                        int64_t ncols, double L1, double L2, unsigned long long* sweep_counter, const NnlsPass& ps);
 // the sweep as generated asm (kernels_nnls_asm.hip): the ranks it has instances for, same protocol as the lane kernels
-bool nnls_lane_asm_has(int KP, double L1);
+bool nnls_lane_asm_has(int KP, double L1, int64_t ncols);
 int k_nnls_lane_launch_asm(hipStream_t s, const double* Gpad, int KP, double* B, double* X, const int64_t* col_nnz, int k,
                            int64_t ncols, double L1, double L2, unsigned long long* sweep_counter, const NnlsPass& ps, dim3 g, dim3 b);
 
@@ -191,7 +191,7 @@ int nnls_pack_alloc(NnlsScratch& sc, int64_t ncols) {
 int k_nnls_lane(hipStream_t s, const double* Gpad, int KP, double* B, double* X, const int64_t* col_nnz, int k,
                 int64_t ncols, double L1, double L2, unsigned long long* sweep_counter, const NnlsScratch* scr, bool pack_by_sweeps) {
     if (ncols <= 0) return SGL_OK;
-    auto launch_lane = nnls_lane_asm_has(KP, L1) ? k_nnls_lane_launch_asm
+    auto launch_lane = nnls_lane_asm_has(KP, L1, ncols) ? k_nnls_lane_launch_asm
                        : (KP <= 40) ? k_nnls_lane_launch1 : (KP <= 64 ? k_nnls_lane_launch2 : (KP <= 104 ? k_nnls_lane_launch3 : k_nnls_lane_launch4));
     const bool half = nnls_use_half(KP);
     auto launch = [&](hipStream_t s_, const double* Gp_, int KP_, double* B_, double* X_, const int64_t* nz_, int k_, int64_t nc_, double L1_,

@@ -89,9 +89,13 @@
 
 SGL_NNLS_ASM_INSTANCES(SGL_DEFINE_NNLS_ASM_KERNEL)
 
-// whether the generated sweep serves this padded rank (a padded coordinate is an exact no-op only with L1 >= 0)
-bool nnls_lane_asm_has(int KP, double L1) {
+// whether the generated sweep serves this padded rank (a padded coordinate is an exact no-op only with L1 >= 0).  Above KP = 50
+// (x in the accumulator registers, ONE wave per SIMD) it wins where the solve is short of waves anyway -- the W side's 30 000
+// genes: nnls_w 0.596 -> 0.459 ms at k = 64 -- and loses to the compiled kernel's two waves per SIMD on long launches (nnls_h per
+// 200 000 cells k = 52: 1.51 -> 1.74 ms, k = 64: 2.56 -> 2.61): used up to 65 536 columns there (profiles/r5_nnls_generated_sweep.txt).
+bool nnls_lane_asm_has(int KP, double L1, int64_t ncols) {
     if (!(L1 >= 0.0) || getenv("SGL_NNLS_NO_ASM")) return false;
+    if (KP > 50 && ncols > 65536 && !getenv("SGL_NNLS_ASM_ALWAYS")) return false;
 #define SGL_NNLS_ASM_HAS(K_) if (KP == K_) return true;
     SGL_NNLS_ASM_INSTANCES(SGL_NNLS_ASM_HAS)
 #undef SGL_NNLS_ASM_HAS

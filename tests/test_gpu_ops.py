@@ -759,7 +759,7 @@ def test_nnls_four_columns_per_wave_on_a_shared_gram_matches_the_lane_kernel(ctx
     assert ss == tot and np.array_equal(Xs, Xq[:40])
 
 
-@pytest.mark.parametrize("k", [1, 2, 3, 4, 7, 9, 10, 15, 16, 17, 19, 20, 24, 29, 30, 31, 32, 33, 39, 40, 41, 43, 44, 47, 48, 49, 50])
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 7, 9, 10, 15, 16, 17, 19, 20, 24, 29, 30, 31, 32, 33, 39, 40, 41, 43, 44, 47, 48, 49, 50, 51, 52, 55, 56, 59, 60, 63, 64])
 def test_nnls_generated_sweep_matches_the_compiled_kernel(ctx, ora, k, monkeypatch):
     """Round 5: at the ranks it has instances for, the lane-per-column solve runs its sweep as generated, hand-scheduled asm
     (gen_nnls_lane.py: a coordinate's serial step chain interleaved with its neighbours' row-update FMAs).  Same operations in

@@ -325,12 +325,14 @@ def test_generated_nnls_sweep_owns_its_registers(tmp_path_factory):
     subprocess.run(["make", "-C", CSRC, "nnls_lane_gen.inc"], check=True, capture_output=True, timeout=120)
     inc = open(os.path.join(CSRC, "nnls_lane_gen.inc")).read()
     kps = [int(v) for v in re.findall(r"X_\((\d+)\)", inc.split("SGL_NNLS_ASM_INSTANCES(X_)")[1].splitlines()[0])]
-    assert kps and max(kps) <= 50
+    assert kps and max(kps) <= 64
     text = _device_asm(ASM_NNLS_SRC, tmp_path_factory.mktemp("asm"))
     for KP in kps:
         vt = int(re.search(r"#define NNLS_ASM_VT_%d (\d+)" % KP, inc).group(1))
         clob = re.search(r"#define NNLS_ASM_VCLOB_%d (.*)" % KP, inc).group(1)
         top = max(int(v) for v in re.findall(r'"v(\d+)"', clob)) + 1
+        nacc = len(re.findall(r'"a\d+"', clob))      # ranks above 50: x in a[0 : 2 KP - 1]
+        assert nacc == (2 * KP if KP > 50 else 0)
         m = re.search(r"^(_Z\d+nnls_lane_asm_kernel_%d\w*):[^\n]*\n(.*?)s_endpgm" % KP, text, re.S | re.M)
         assert m, "nnls_lane_asm_kernel_%d not found" % KP
         body = m.group(2)
@@ -352,7 +354,7 @@ def test_generated_nnls_sweep_owns_its_registers(tmp_path_factory):
                 worst = max(worst, max(r))
         assert 0 <= worst < vt, "KP=%d: hipcc allocated v%d, the generated sweep owns v[%d:%d]" % (KP, worst, vt, top - 1)
         nfree = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", meta).group(1))
-        assert top <= nfree <= (top + 7) // 8 * 8, (KP, nfree, top)
+        assert top + nacc <= nfree <= (top + 7) // 8 * 8 + nacc, (KP, nfree, top, nacc)
         blocks = [b for b in re.findall(r"#ASMSTART(.*?)#ASMEND", body, re.S) if "v_fmac_f64_dpp" in b]
         assert len(blocks) == 1
         assert blocks[0].count("v_fmac_f64_dpp") == KP * KP
