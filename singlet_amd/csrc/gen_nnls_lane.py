@@ -44,9 +44,14 @@ def plan(KP):
     xa = 20 + 4 + 4 * NG + 4 * KP + 16 > 256
     nt = 26 if xa else 20
     own = nt + 4 + 4 * NG + (2 * KP if xa else 4 * KP)
-    V_T = max(16, min(28, 256 - own))
-    if V_T + own > 256 or KP > 64:
+    acc = 2 * KP if xa else 0
+    if 16 + own > 256 or KP > 64:
         raise SystemExit("gen_nnls_lane.py: KP = %d does not fit the register file" % KP)
+    # the compiler's share: 28 registers, or as few as 16 where that buys the second or third wave per SIMD (one wave issues an
+    # FP64 instruction only every ~7.5 cycles, two reach 4.8 per SIMD: mix3 micro-benchmark; k = 30: nnls_h 0.515 -> 0.492 ms per
+    # 200 000 cells with three; a fourth measured nothing at k = 20) or is all that is left (KP = 50)
+    waves = lambda vt: max(1, min(8, 512 // ((vt + own + acc + 7) // 8 * 8)))
+    V_T = max(range(16, min(28, 256 - own) + 1), key=lambda vt: (min(waves(vt), 3), vt))
     V_D = V_T + nt
     V_G = V_D + 4
     V_B = V_G + 4 * NG
