@@ -41,6 +41,10 @@ int k_nnls_lane_launch4(hipStream_t s, const double* Gpad, int KP, double* B, do
 
 int k_nnls_half_launch(hipStream_t s, const double* Gpad, int KP, double* B, double* X, const int64_t* col_nnz, int k,
                        int64_t ncols, double L1, double L2, unsigned long long* sweep_counter, const NnlsPass& ps);
+// the two-lanes-per-column solve as generated asm (kernels_nnls_half_asm.hip): padded rank it serves k with (0: none)
+int nnls_half_asm_kp(int k, double L1);
+int k_nnls_half_launch_asm(hipStream_t s, const double* Gpad, int KP, double* B, double* X, const int64_t* col_nnz, int k,
+                           int64_t ncols, double L1, double L2, unsigned long long* sweep_counter, const NnlsPass& ps);
 // the sweep as generated asm (kernels_nnls_asm.hip): the ranks it has instances for, same protocol as the lane kernels
 bool nnls_lane_asm_has(int KP, double L1, int64_t ncols);
 int k_nnls_lane_launch_asm(hipStream_t s, const double* Gpad, int KP, double* B, double* X, const int64_t* col_nnz, int k,
@@ -194,9 +198,11 @@ int k_nnls_lane(hipStream_t s, const double* Gpad, int KP, double* B, double* X,
     auto launch_lane = nnls_lane_asm_has(KP, L1, ncols) ? k_nnls_lane_launch_asm
                        : (KP <= 40) ? k_nnls_lane_launch1 : (KP <= 64 ? k_nnls_lane_launch2 : (KP <= 104 ? k_nnls_lane_launch3 : k_nnls_lane_launch4));
     const bool half = nnls_use_half(KP);
+    const bool half_asm = half && nnls_half_asm_kp(k, L1) == KP;
     auto launch = [&](hipStream_t s_, const double* Gp_, int KP_, double* B_, double* X_, const int64_t* nz_, int k_, int64_t nc_, double L1_,
                       double L2_, unsigned long long* sw_, const NnlsPass& ps_, dim3 g_, dim3 b_) {
-        return half ? k_nnls_half_launch(s_, Gp_, KP_, B_, X_, nz_, k_, nc_, L1_, L2_, sw_, ps_)
+        return half_asm ? k_nnls_half_launch_asm(s_, Gp_, KP_, B_, X_, nz_, k_, nc_, L1_, L2_, sw_, ps_)
+               : half ? k_nnls_half_launch(s_, Gp_, KP_, B_, X_, nz_, k_, nc_, L1_, L2_, sw_, ps_)
                     : launch_lane(s_, Gp_, KP_, B_, X_, nz_, k_, nc_, L1_, L2_, sw_, ps_, g_, b_);
     };
     if (nnls_needs_xt(KP) && (scr == nullptr || scr->xt == nullptr || scr->cap < ncols)) {
@@ -206,8 +212,9 @@ int k_nnls_lane(hipStream_t s, const double* Gpad, int KP, double* B, double* X,
     double* xt = nnls_needs_xt(KP) ? scr->xt : nullptr;
     const dim3 g((unsigned)((ncols + 255) / 256)), b(256);
     const bool repack = scr != nullptr && scr->list[0] != nullptr && scr->cap >= ncols && ncols >= nnls_repack_min_cols();
-    // first pass in descending order of the previous solve's sweep counts (lane instances up to k = 64; SGL_NNLS_NO_PACK: A/B)
-    const bool pack = pack_by_sweeps && !half && scr != nullptr && scr->prev_it != nullptr && scr->pack_cap >= ncols && ncols >= 65536 &&
+    // first pass in descending order of the previous solve's sweep counts (lane instances up to k = 64 and the generated two-lane
+    // solve above; SGL_NNLS_NO_PACK: A/B)
+    const bool pack = pack_by_sweeps && (!half || half_asm) && scr != nullptr && scr->prev_it != nullptr && scr->pack_cap >= ncols && ncols >= 65536 &&
                       !getenv("SGL_NNLS_NO_PACK");
     const int32_t* list0 = nullptr;
     const uint32_t* count0 = nullptr;
@@ -221,7 +228,7 @@ int k_nnls_lane(hipStream_t s, const double* Gpad, int KP, double* B, double* X,
         list0 = scr->packed;
         count0 = n_dev;   // = ncols
     }
-    uint8_t* prev_it = pack_by_sweeps && !half && scr != nullptr && scr->prev_it != nullptr && scr->pack_cap >= ncols ? scr->prev_it : nullptr;
+    uint8_t* prev_it = pack_by_sweeps && (!half || half_asm) && scr != nullptr && scr->prev_it != nullptr && scr->pack_cap >= ncols ? scr->prev_it : nullptr;
     if (!repack) {
         const NnlsPass one = {list0, count0, nullptr, nullptr, nullptr, nullptr, 0, xt, ncols, 1, prev_it};
         SGLCHK(launch(s, Gpad, KP, B, X, col_nnz, k, ncols, L1, L2, sweep_counter, one, g, b));

@@ -572,7 +572,12 @@ static int build_tiles(sgl_ctx* c, DevCSC& M, int k) {
     return k_build_segments(c->stream, M);
 }
 
-static int lane_kp(int k) { return nnls_lane_kp(k); }
+int nnls_half_asm_kp(int k, double L1);
+// padded rank of the lane / two-lane solve for rank k: the generated two-lane solve pads to multiples of 4 (k = 100 unpadded)
+static int lane_kp(int k, double L1) {
+    const int kp = nnls_half_asm_kp(k, L1);
+    return kp ? kp : nnls_lane_kp(k);
+}
 
 // ------------------------------------------------------------ input staging --
 extern "C" int sgl_log_normalize(sgl_ctx* c, double scale_factor) {
@@ -668,7 +673,7 @@ static int fit_init_impl(sgl_ctx* c, int32_t k, const double* w_init, uint64_t s
     {
         const int64_t cap = std::max<int64_t>(c->A.ncol, c->A.nrow);
         if (k <= SGL_LANE_NNLS_MAX_K) SGLCHK(nnls_scratch_alloc(c->nnls_scr, cap, k));
-        if (k <= 64 && c->A.ncol >= 65536) SGLCHK(nnls_pack_alloc(c->nnls_scr, c->A.ncol));   // sweep-count packing of the H-side solve
+        if (k <= SGL_LANE_NNLS_MAX_K && c->A.ncol >= 65536) SGLCHK(nnls_pack_alloc(c->nnls_scr, c->A.ncol));   // sweep-count packing of the H-side solve (lane kernels; above k = 64 the generated two-lane solve)
     }
     HIPCHK(hipMemsetAsync(c->W, 0, sizeof(double) * ((size_t)k * mpad + 2), c->stream));
     HIPCHK(hipMemsetAsync(c->red, 0, sizeof(double) * ((size_t)k * mpad + (size_t)k * k + (size_t)k), c->stream));
@@ -766,7 +771,7 @@ int sgl_nnls_shared(sgl_ctx* c, const double* G, double* B, double* X, const int
         if (k >= 12 && k <= 64 && ncols <= qs_max) return k_nnls_quad_shared(c->stream, G, B, X, col_nnz, k, ncols, L1, L2, counter);
     }
     if (k <= SGL_LANE_NNLS_MAX_K) {
-        const int KP = lane_kp(k);
+        const int KP = lane_kp(k, L1);
         SGLCHK(k_pad_gram(c->stream, G, k, KP, nnls_gram_stride(KP), c->Gpad));
         // the H side of a plain fit packs its waves by the sweep counts of the previous iteration (kernels_nnls.hip)
         return k_nnls_lane(c->stream, c->Gpad, KP, B, X, col_nnz, k, ncols, L1, L2, counter, &c->nnls_scr, h_side && ncols == c->A.ncol);
@@ -1576,7 +1581,7 @@ extern "C" int sgl_op_nnls(sgl_ctx* c, const double* G, const double* B, double*
     if (k <= 64 && getenv("SGL_OP_NNLS_QUAD_SHARED")) {   // tests: the four-columns-per-wave solve of short launches (sgl_nnls_shared)
         rc = k_nnls_quad_shared(c->stream, dG.p, dB.p, dX.p, nullptr, k, ncols, L1, L2, c->sweep_counters + 4);
     } else if (k <= SGL_LANE_NNLS_MAX_K) {
-        const int KP = lane_kp(k);
+        const int KP = lane_kp(k, L1);
         rc = dGp.alloc((size_t)SGL_LANE_NNLS_MAX_K * (SGL_LANE_NNLS_MAX_K + 16) + 64);
         if (rc == SGL_OK) rc = k_pad_gram(c->stream, dG.p, k, KP, nnls_gram_stride(KP), dGp.p);
         if (rc == SGL_OK && (ncols >= nnls_repack_min_cols() || k > 64)) rc = nnls_scratch_alloc(scr, ncols, k);

@@ -759,6 +759,46 @@ def test_nnls_four_columns_per_wave_on_a_shared_gram_matches_the_lane_kernel(ctx
     assert ss == tot and np.array_equal(Xs, Xq[:40])
 
 
+HALF_ASM_RANKS = [65, 66, 68, 69, 72, 75, 76, 79, 80, 83, 84, 88, 89, 92, 95, 96, 97, 98, 99, 100, 101, 104, 105, 108, 111, 112, 116, 117, 120, 123, 124, 125, 127, 128]
+
+
+@pytest.mark.parametrize("k", HALF_ASM_RANKS)
+def test_nnls_generated_two_lane_solve_matches_the_compiled_kernel(ctx, ora, k, monkeypatch):
+    """Round 5: ranks 65 ... 128 against a shared Gram run the two-lanes-per-column solve as generated asm (gen_nnls_half.py: one
+    half computes a coordinate's step under a gate, only nd crosses the halves, the step's chain interleaved with the row
+    updates; padded to multiples of 4 where the compiled instances pad to 8; above 100 with x in the accumulator registers).  Bit-identical solutions and equal sweep totals
+    against the hipcc-scheduled kernel (SGL_NNLS_NO_ASM=1): one pass and re-packed passes, ragged column counts down to one,
+    a launch long enough for the 512-thread workgroups, penalties on and off, warm starts; and the oracle column by column."""
+    rng = np.random.default_rng(1900 + k)
+    F = rng.random((3 * k + 5, k))
+    G = F.T @ F + 1e-15 * np.eye(k)
+    for ncols, L1, L2 in ((1, 0.0, 0.0), (31, 0.02, 0.0), (32 * 5 + 7, 0.02, 0.01), (3000 + 37, 0.0, 0.03), (66000 + 5, 0.01, 0.0)):
+        if ncols > 60000 and k not in (72, 84, 100, 116, 128):
+            continue
+        B = rng.normal(size=(ncols, k)) * 3 + 1.0
+        B *= np.exp(rng.normal(size=(ncols, 1)) * 2)
+        X0 = np.abs(rng.normal(size=(ncols, k))) * (rng.random((ncols, k)) < 0.5) * 1e-3
+        out = {}
+        for asm in (True, False):
+            for repack in (False, True):
+                if asm:
+                    monkeypatch.delenv("SGL_NNLS_NO_ASM", raising=False)
+                else:
+                    monkeypatch.setenv("SGL_NNLS_NO_ASM", "1")
+                if repack:
+                    monkeypatch.setenv("SGL_NNLS_REPACK_MIN_COLS", "512")
+                else:
+                    monkeypatch.delenv("SGL_NNLS_REPACK_MIN_COLS", raising=False)
+                out[(asm, repack)] = ctx.op_nnls(G, B, X0, L1, L2)
+        X, s = out[(False, False)]
+        for key, (Xo, so) in out.items():
+            assert np.array_equal(X, Xo) and s == so, (key, ncols)
+        if ncols == 3037:
+            for c in range(12):
+                xo, _, it = ora.nnls(G, B[c], X0[c], L1, L2)
+                assert np.linalg.norm(X[c] - xo) <= 1e-9 * max(np.linalg.norm(xo), 1e-300) and np.array_equal(X[c] == 0, xo == 0)
+
+
 @pytest.mark.parametrize("k", [1, 2, 3, 4, 7, 9, 10, 15, 16, 17, 19, 20, 24, 29, 30, 31, 32, 33, 39, 40, 41, 43, 44, 47, 48, 49, 50, 51, 52, 55, 56, 59, 60, 63, 64])
 def test_nnls_generated_sweep_matches_the_compiled_kernel(ctx, ora, k, monkeypatch):
     """Round 5: at the ranks it has instances for, the lane-per-column solve runs its sweep as generated, hand-scheduled asm

@@ -25,10 +25,10 @@ def _device_asm(src, tmpdir):
     unit = os.path.splitext(os.path.basename(src))[0]
     kept = os.path.join(CSRC, "asm", unit + ".s")
     deps = [src] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))] + [os.path.join(ROOT, "include", "singlet_hip.h")]
+    gen = {"kernels_tiled": "acc_tiled_gen.inc", "kernels_nnls_asm": "nnls_lane_gen.inc", "kernels_nnls_half_asm": "nnls_half_gen.inc"}
+    deps = [d for d in deps if not d.endswith("_gen.inc") or os.path.basename(d) == gen.get(unit)]   # a unit's own generated code only
     if unit == "kernels_tiled":
         deps.append(os.path.join(CSRC, "gen_acc_tiled.py"))
-    else:
-        deps = [d for d in deps if not d.endswith("acc_tiled_gen.inc")]
     if os.path.exists(kept) and all(os.path.getmtime(kept) >= os.path.getmtime(d) for d in deps):
         return open(kept).read()
     out = os.path.join(str(tmpdir), unit + ".s")
@@ -365,3 +365,68 @@ def test_generated_nnls_sweep_owns_its_registers(tmp_path_factory):
             mm = re.match(r"v_rcp_f64 (v\[\d+:\d+\])", a)
             if mm:
                 assert mm.group(1) not in b.split(",", 1)[-1] or b.startswith("s_nop"), (a, b)
+
+
+ASM_NNLS_HALF_SRC = os.path.join(CSRC, "kernels_nnls_half_asm.hip")
+
+
+def test_generated_two_lane_solve_owns_its_registers(tmp_path_factory):
+    """kernels_nnls_half_asm.hip (ranks 65 ... 128, gen_nnls_half.py): the kernel descriptor covers the register plan and leaves the
+    waves per SIMD the plan counts on, one asm statement per kernel with KP x KH row-update FMAs per sweep, every register it
+    names inside the plan or an operand hipcc placed outside it, no scratch access inside it -- and the two hazards the generator pads itself: a transcendental's result is not read by the next
+    instruction, a v_permlane32_swap does not read a register a VALU instruction wrote within the two instructions before."""
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not installed")
+    subprocess.run(["make", "-C", CSRC, "nnls_half_gen.inc"], check=True, capture_output=True, timeout=120)
+    inc = open(os.path.join(CSRC, "nnls_half_gen.inc")).read()
+    kps = [int(v) for v in re.findall(r"X_\((\d+)\)", inc.split("SGL_NNLS_HALF_ASM_INSTANCES(X_)")[1].splitlines()[0])]
+    assert kps and min(kps) >= 68 and max(kps) <= 128
+    text = _device_asm(ASM_NNLS_HALF_SRC, tmp_path_factory.mktemp("asm"))
+    for KP in kps:
+        KH = KP // 2
+        vt = int(re.search(r"#define NNLS_HALF_ASM_VT_%d (\d+)" % KP, inc).group(1))
+        clob = re.search(r"#define NNLS_HALF_ASM_VCLOB_%d (.*)" % KP, inc).group(1)
+        top = max(int(v) for v in re.findall(r'"v(\d+)"', clob)) + 1
+        nacc = len(re.findall(r'"a\d+"', clob))      # ranks above 100: x in a[0 : 2 KH - 1]
+        assert nacc == (2 * KH if KP > 100 else 0)
+        m = re.search(r"^(_Z\d+nnls_half_asm_kernel_%d\w*):[^\n]*\n(.*?)s_endpgm" % KP, text, re.S | re.M)
+        assert m, "nnls_half_asm_kernel_%d not found" % KP
+        body = m.group(2)
+        meta = text[text.index(".amdhsa_kernel " + m.group(1)):]
+        meta = meta[:meta.index(".end_amdhsa_kernel")]
+        # (the solve is ONE statement and its registers are its clobbers: hipcc cannot keep a live value in them across it, and is
+        #  free to use them as temporaries before and after -- it does; what has to hold is that the descriptor covers the plan)
+        waves = int(re.search(r"#define NNLS_HALF_ASM_WAVES_%d (\d+)" % KP, inc).group(1))
+        nfree = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", meta).group(1))
+        assert top + nacc <= nfree and 512 // ((nfree + 7) // 8 * 8) >= waves, (KP, nfree, top, nacc, waves)
+        blocks = [b for b in re.findall(r"#ASMSTART(.*?)#ASMEND", body, re.S) if "v_fmac_f64_dpp" in b]
+        assert len(blocks) == 1
+        assert blocks[0].count("v_fmac_f64_dpp") == KP * KH
+        assert blocks[0].count("v_permlane32_swap_b32") == 2 * KP + 4      # nd of every coordinate, tol twice per sweep
+        assert "scratch_" not in blocks[0] and "buffer_" not in blocks[0]
+        lines = [x.strip() for x in blocks[0].splitlines() if x.strip()]
+        named = set()
+        for ins in lines:
+            named |= _vregs(ins.split(";")[0])
+        outside = {v for v in named if not (vt <= v < top)}
+        assert len(outside) <= 16 and max(named) < nfree, (KP, sorted(outside))   # the statement's vector operands (eleven registers, hipcc may pass a pair twice)
+        for a, b in zip(lines, lines[1:]):
+            mm = re.match(r"v_rcp_f64 (v\[\d+:\d+\])", a)
+            if mm:
+                assert mm.group(1) not in b.split(",", 1)[-1] or b.startswith("s_nop"), (a, b)
+        for q, ins in enumerate(lines):
+            if not ins.startswith("v_permlane32_swap_b32"):
+                continue
+            regs = {int(v) for v in re.findall(r"v(\d+)", ins)}
+            wait = 0
+            for prev in reversed(lines[max(0, q - 2):q]):   # the two instructions before: an s_nop N counts N + 1 wait states
+                if prev.startswith("s_nop"):
+                    wait += int(prev.split()[1]) + 1
+                    continue
+                if wait >= 2:
+                    break
+                if prev.startswith("v_") and not prev.startswith("v_cmp"):
+                    d = prev.split(None, 1)[1].split(",")[0].strip()
+                    lo, hi = (d[2:-1].split(":") if d.startswith("v[") else (d[1:], d[1:]))
+                    assert not (regs & set(range(int(lo), int(hi) + 1))), (KP, prev, ins)
+                wait += 1
