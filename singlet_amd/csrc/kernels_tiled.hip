@@ -890,12 +890,14 @@ int k_acc_tiled_all(hipStream_t s, const DevTiled& S, const double* F, double* B
 // part size the entry streams are built for at rank k (0: no tiled path): even, at most 64.  A pass costs the same whatever its
 // part size within a layout (one address add, one ds_read_b128, two FMAs per entry tuple), and the quad layout of parts up to 32
 // serves FOUR columns per tuple where the pair layout serves two: ranks 65 - 96 run as THREE quad passes (1.5 x the cost of a
-// k = 64 pass) instead of two pair passes (2 x); 97 - 128 as two pair passes (four quad passes would cost the same).
+// k = 64 pass) instead of two pair passes (2 x); 97 - 128 as FOUR quad passes (2.0 x the k = 64 pass; the two pair passes measure
+// 2.4 x -- rhs_h per 200 000 cells at k = 100: 5.84 -> 4.89 ms, k = 128: 6.48 -> 5.01; profiles/r5_k_sweep_200k_cells.txt).
 // One pass over half-height tiles with four factors per lane was priced and loses: 15 % more LDS time than the two passes
 // (scripts/r5/r5_pad_model.py).  SGL_TILED_NO_QUAD3=1: two pair passes (A/B, tests).
 int tiled_part_size(int k) {
     if (k <= 64) return k;
     if (k > 128) return 0;
-    const int parts = (k <= 96 && !getenv("SGL_TILED_NO_QUAD3") && !getenv("SGL_TILED_NO_QUAD")) ? 3 : (k + 63) / 64;
+    const bool quad = !getenv("SGL_TILED_NO_QUAD3") && !getenv("SGL_TILED_NO_QUAD");
+    const int parts = quad ? (k <= 96 ? 3 : 4) : (k + 63) / 64;
     return ((k + parts - 1) / parts + 1) & ~1;
 }

@@ -149,7 +149,7 @@ def test_rhs_both_orientations(ctx, ora, sa, k):
 @pytest.mark.parametrize("k", [1, 2, 7, 10, 16, 30, 31, 32, 33, 50, 64, 65, 70, 100, 127, 128])
 def test_rhs_tiled_kernel_all_ranks(ctx, ora, sa, k, monkeypatch):
     """The LDS-tiled accumulate (which = 2 / 3): four columns per LDS instruction up to k = 32 (256-byte tile rows),
-    two up to k = 64, two passes over factor halves for 64 < k <= 128 (strided factor rows and outputs), odd ranks
+    two up to k = 64, three / four quad passes over factor parts for 64 < k <= 128 (strided factor rows and outputs), odd ranks
     through the re-pitched staging.  1e-14 to the oracle as it runs by default (a matrix this small has its tile range cut
     over the CUs: partial sums added in range order); with the range whole (SGL_TILED_RANGES=1) bit-equal to the plain CSC
     kernel (same products, same order)."""
@@ -208,7 +208,7 @@ def test_rhs_tiled_tail_split(sa, ora, k, monkeypatch):
     have their tile range cut into pieces (own compact slabs, summed in piece order).  140 000 cells x 2500 genes: 274 (137
     at k <= 32) groups of 512 (1024) columns; with and without the tail split (SGL_TILED_NO_TAIL) the sums agree to rounding,
     and both with the oracle."""
-    quad = k <= 32 or 64 < k <= 96      # four columns per tuple: ranks up to 32, and the three passes of ranks 65 - 96 (round 5)
+    quad = k <= 32 or 64 < k <= 128     # four columns per tuple: ranks up to 32, and the three / four passes of ranks 65 - 128 (round 5)
     A = ora.synth_csc(2500, 280000 if quad else 140000, 20)
     rng = np.random.default_rng(k)
     W = rng.random((A.nrow, k))
