@@ -48,7 +48,7 @@ def parse(argv=None):
     ap.add_argument("--maxit", type=int, default=10, help="--workload ard: iterations per masked fit")
     ap.add_argument("--trace", type=int, default=5, help="--workload ard: trace_test_mse (mse_test every this many iterations)")
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=10)   # 2 warm-up + 10 timed iterations at fixed maxit
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--genes", type=int, default=30000)
     ap.add_argument("--cells", type=int, default=1000000)
