@@ -390,63 +390,6 @@ __global__ __launch_bounds__(256) void cor_partial_kernel(const double* __restri
     if (threadIdx.x < 5) part[(size_t)blockIdx.x * 5 + threadIdx.x] = sm[threadIdx.x][0];
 }
 
-// The same with the final stage inside (round 5): the block that finishes LAST -- a ticket counter behind the partials, left at
-// zero for the next call -- sums the five columns of partials in block order and forms cor: the arithmetic of
-// cor_final_kernel in the same order, one launch instead of two.
-__global__ __launch_bounds__(256) void cor_fused_kernel(const double* __restrict__ x, const double* __restrict__ y, int64_t n,
-                                                        double* __restrict__ part, unsigned* __restrict__ ticket, double* __restrict__ out) {
-    double s[5] = {0, 0, 0, 0, 0};
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
-        const double a = x[t], b = y[t];
-        s[0] += a;
-        s[1] += b;
-        s[2] = fma(a, b, s[2]);
-        s[3] = fma(a, a, s[3]);
-        s[4] = fma(b, b, s[4]);
-    }
-    __shared__ double sm[5][256];
-    __shared__ bool last;
-    for (int q = 0; q < 5; ++q) sm[q][threadIdx.x] = s[q];
-    __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) {
-        if ((int)threadIdx.x < w)
-            for (int q = 0; q < 5; ++q) sm[q][threadIdx.x] += sm[q][threadIdx.x + w];
-        __syncthreads();
-    }
-    if (threadIdx.x < 5) part[(size_t)blockIdx.x * 5 + threadIdx.x] = sm[threadIdx.x][0];
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) last = atomicAdd(ticket, 1u) == gridDim.x - 1;
-    __syncthreads();
-    if (!last) return;
-    __threadfence();
-    const int nblocks = (int)gridDim.x;
-    const int lane = threadIdx.x;
-    if (lane >= 64) return;
-    double mine = 0.0;
-    if (lane < 5) {
-        int b = 0;
-        for (; b + 8 <= nblocks; b += 8) {
-            double v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = __hip_atomic_load(&part[(size_t)(b + u) * 5 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-            for (int u = 0; u < 8; ++u) mine += v[u];
-        }
-        for (; b < nblocks; ++b) mine += __hip_atomic_load(&part[(size_t)b * 5 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // agent scope: not from this CU's L1
-    }
-    double t5[5];
-#pragma unroll
-    for (int q = 0; q < 5; ++q) t5[q] = __shfl(mine, q, 64);
-    if (lane != 0) return;
-    *ticket = 0u;
-    const double nn = (double)n;
-    const double num = __dsub_rn(__dmul_rn(nn, t5[2]), __dmul_rn(t5[0], t5[1]));
-    const double vx = __dsub_rn(__dmul_rn(nn, t5[3]), __dmul_rn(t5[0], t5[0]));
-    const double vy = __dsub_rn(__dmul_rn(nn, t5[4]), __dmul_rn(t5[1], t5[1]));
-    out[0] = 1.0 - num / sqrt(__dmul_rn(vx, vy));
-}
-
 __global__ void cor_final_kernel(const double* __restrict__ part, int nblocks, int64_t n, double* __restrict__ out) {
     if (blockIdx.x != 0) return;
     // the five sums in block order (one lane each, loads eight blocks ahead: one thread walking all 5 x nblocks
@@ -482,11 +425,10 @@ int k_cor(sgl_ctx* c, const double* x, const double* y, int64_t n, double* out_d
     if (nblocks > 512) nblocks = 512;
     if (nblocks < 1) nblocks = 1;
     SGLCHK(sgl_ws_reserve(c, sizeof(double) * 5 * (size_t)nblocks));
-    if (!getenv("SGL_COR_TWO_KERNELS")) {   // one launch: the last block to finish forms the result (ticket at c->scalars[8], zero between calls)
-        cor_fused_kernel<<<dim3(nblocks), dim3(256), 0, c->stream>>>(x, y, n, c->ws, reinterpret_cast<unsigned*>(c->scalars + 8), out_dev);
-        HIPCHK(hipGetLastError());
-        return SGL_OK;
-    }
+    // (Round 5 tried the final stage inside the first kernel -- the block that finishes last sums the partials, a ticket counter
+    //  behind them: 37.7 us per call at the 125 000-cell shard with the partials staged through LDS, 48.5 without, against
+    //  10.9 + 14.4 us for these two launches: a back-to-back launch on one stream costs less than the fence, the ticket and a
+    //  lone block's serial tail.  Taken out; the same held for the row sums.  profiles/README.md)
     cor_partial_kernel<<<dim3(nblocks), dim3(256), 0, c->stream>>>(x, y, n, c->ws);
     HIPCHK(hipGetLastError());
     cor_final_kernel<<<dim3(1), dim3(64), 0, c->stream>>>(c->ws, nblocks, n, out_dev);

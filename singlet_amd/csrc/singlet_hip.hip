@@ -205,7 +205,7 @@ extern "C" int sgl_create(int device, sgl_ctx** out) {
     c->stream = c->own_stream;
     if (e == hipSuccess) {
         rc = dev_alloc(&c->scalars, 16);
-        if (rc == SGL_OK) e = hipMemsetAsync(c->scalars, 0, 16 * sizeof(double), c->stream);   // [8]: ticket of k_cor's last-block stage
+        if (rc == SGL_OK) e = hipMemsetAsync(c->scalars, 0, 16 * sizeof(double), c->stream);
         if (rc == SGL_OK && e == hipSuccess) rc = dev_alloc(&c->sweep_counters, 8);
         if (rc == SGL_OK) e = hipMemsetAsync(c->sweep_counters, 0, 8 * sizeof(unsigned long long), c->stream);
         if (rc == SGL_OK && e == hipSuccess) e = hipHostMalloc((void**)&c->pinned, 16 * sizeof(double), hipHostMallocDefault);
