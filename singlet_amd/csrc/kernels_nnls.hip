@@ -230,7 +230,8 @@ int k_nnls_lane(hipStream_t s, const double* Gpad, int KP, double* B, double* X,
     }
     uint8_t* prev_it = pack_by_sweeps && (!half || half_asm) && scr != nullptr && scr->prev_it != nullptr && scr->pack_cap >= ncols ? scr->prev_it : nullptr;
     if (!repack) {
-        const NnlsPass one = {list0, count0, nullptr, nullptr, nullptr, nullptr, 0, xt, ncols, 1, prev_it};
+        // fresh = 2: a packed single pass of one to two workgroups per CU may pair the longest waves with the shortest (kernels_nnls_asm.hip)
+        const NnlsPass one = {list0, count0, nullptr, nullptr, nullptr, nullptr, 0, xt, ncols, (list0 != nullptr && !getenv("SGL_NNLS_NO_SNAKE")) ? 2 : 1, prev_it};
         SGLCHK(launch(s, Gpad, KP, B, X, col_nnz, k, ncols, L1, L2, sweep_counter, one, g, b));
         HIPCHK(hipGetLastError());
         return SGL_OK;

@@ -16,7 +16,14 @@
         unsigned long long* __restrict__ sweep_counter, NnlsPass ps) {                                                             \
         constexpr int NG = (KP + 15) / 16, NGP = NNLS_ASM_NGP_##KP, ROW = 16 * NGP;                                                \
         const int64_t n_in = ps.list ? (int64_t)*ps.count : ncols;                                                                  \
-        if ((int64_t)blockIdx.x * blockDim.x >= n_in) return;                                                                       \
+        /* A packed single pass (columns in descending order of their previous sweep counts) of 257 ... 512 workgroups is ONE      */ \
+        /* round of the chip, two workgroups per CU, and lasts as long as the SIMD whose two waves take longest: in launch order   */ \
+        /* CU c would get the sorted workgroups c and c + 256 -- the longest with the next longest.  A SIMD's time is about         */ \
+        /* 7.5 max + 2.1 min sweep units (two waves share the FP64 pipe at 4.8 cycles per instruction, one alone gets 7.5), so the  */ \
+        /* second layer runs in ASCENDING order: CU c gets c and (last - c).  Positions only: a column's arithmetic is the same.    */ \
+        unsigned bx = blockIdx.x;                                                                                                   \
+        if (ps.fresh == 2 && gridDim.x > 256u && gridDim.x <= 512u && bx >= 256u) bx = gridDim.x - 1u - (bx - 256u);                \
+        if ((int64_t)bx * blockDim.x >= n_in) return;                                                                               \
         extern __shared__ __attribute__((aligned(16))) double nnls_asm_lds[];                                                       \
         double* const Gl = nnls_asm_lds;              /* Gl[i][l][m] = G[i, l + 16 m] */                                            \
         double* const Dl = nnls_asm_lds + KP * ROW;   /* (G_ii, 1 / G_ii) */                                                        \
@@ -29,7 +36,7 @@
             Dl[2 * j + 1] = Gpad[KP * gs_in + j];   /* row KP of the padded Gram: the correctly rounded reciprocals */              \
         }                                                                                                                           \
         __syncthreads();                                                                                                            \
-        const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;                                                         \
+        const int64_t gid = (int64_t)bx * blockDim.x + threadIdx.x;                                                                 \
         const bool in_range = gid < n_in;                                                                                           \
         const int64_t col = in_range ? (ps.list ? (int64_t)ps.list[gid] : gid) : 0;                                                 \
         const bool resume = ps.list != nullptr && !ps.fresh;                                                                        \
