@@ -74,7 +74,8 @@ int nnls_scratch_alloc(NnlsScratch& sc, int64_t cap, int k_for_xt) {
     bool ok = true;
     // x scratch of the k > 64 instances; lists / per-column state only where re-packing is used
     if (nnls_needs_xt(nnls_lane_kp(k_for_xt))) ok = hipMalloc(&sc.xt, sizeof(double) * (size_t)cap * k_for_xt) == hipSuccess;
-    if (ok && cap >= nnls_repack_min_cols())
+    const bool two_lane = k_for_xt > 64 && nnls_use_half(nnls_lane_kp(k_for_xt));   // re-packs from half the columns (k_nnls_lane)
+    if (ok && cap >= ((two_lane && !getenv("SGL_NNLS_REPACK_MIN_COLS")) ? nnls_repack_min_cols() / 2 : nnls_repack_min_cols()))
         ok = hipMalloc(&sc.list[0], sizeof(int32_t) * cap) == hipSuccess && hipMalloc(&sc.list[1], sizeof(int32_t) * cap) == hipSuccess &&
              hipMalloc(&sc.counts, sizeof(uint32_t) * (SGL_NNLS_MAX_PASSES + 1)) == hipSuccess &&
              hipMalloc(&sc.it_state, (size_t)cap) == hipSuccess && hipMalloc(&sc.tol_state, sizeof(double) * cap) == hipSuccess;
@@ -211,7 +212,10 @@ int k_nnls_lane(hipStream_t s, const double* Gpad, int KP, double* B, double* X,
     }
     double* xt = nnls_needs_xt(KP) ? scr->xt : nullptr;
     const dim3 g((unsigned)((ncols + 255) / 256)), b(256);
-    const bool repack = scr != nullptr && scr->list[0] != nullptr && scr->cap >= ncols && ncols >= nnls_repack_min_cols();
+    // (the two-lane solves put 32 columns in a wave: the chip is as full at half the columns, and re-packing pays from there --
+    //  nnls_h per 200 000 columns k = 100 6.56 -> 6.16 ms, k = 128 11.44 -> 10.27; scripts/r5/r5_step26.sh)
+    const int64_t repack_min = (half && !getenv("SGL_NNLS_REPACK_MIN_COLS")) ? nnls_repack_min_cols() / 2 : nnls_repack_min_cols();
+    const bool repack = scr != nullptr && scr->list[0] != nullptr && scr->cap >= ncols && ncols >= repack_min;
     // first pass in descending order of the previous solve's sweep counts (lane instances up to k = 64 and the generated two-lane
     // solve above; SGL_NNLS_NO_PACK: A/B)
     const bool pack = pack_by_sweeps && (!half || half_asm) && scr != nullptr && scr->prev_it != nullptr && scr->pack_cap >= ncols && ncols >= 65536 &&
@@ -251,7 +255,7 @@ int k_nnls_lane(hipStream_t s, const double* Gpad, int KP, double* B, double* X,
         ps.next_count = last ? nullptr : scr->counts + p + 1;
         ps.it_state = scr->it_state;
         ps.tol_state = scr->tol_state;
-        ps.final_below = (int32_t)std::min<int64_t>(64 * 1024, nnls_repack_min_cols() / 4);
+        ps.final_below = (int32_t)std::min<int64_t>(64 * 1024, repack_min / 4);
         ps.xt = xt;
         ps.xt_stride = ncols;
         SGLCHK(launch(s, Gpad, KP, B, X, col_nnz, k, ncols, L1, L2, sweep_counter, ps, g, b));

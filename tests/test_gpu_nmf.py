@@ -56,14 +56,17 @@ def test_c_nmf_stop_decision(sa, ora):
     _check(got, ref)
 
 
-def test_c_nmf_empty_columns_keep_stale_values(sa, ora):
+@pytest.mark.parametrize("k", [5, 30, 70, 104])
+def test_c_nmf_empty_columns_keep_stale_values(sa, ora, k):
+    """(k = 5 / 30: the lane solve resp. four columns per wave; 70 / 104: the generated two-lane solve without / with x in the
+    accumulator registers -- a lane pair without a column must stay out of the loads, the sweeps and the stores)"""
     rng = np.random.default_rng(5)
     D = (rng.random((120, 150)) < 0.1) * (rng.random((120, 150)) + 0.5)
     D[:, 7] = 0      # empty cell: h[:, 7] stays 0 then is only rescaled
     D[33, :] = 0     # empty gene: w[:, 33] keeps its (rescaled) initial values
     from test_gpu_ops import _csc_from_dense
     A = ora.CSC(*_csc_from_dense(D))
-    w0 = ora.synth_winit(5, 120)
+    w0 = ora.synth_winit(k, 120)
     ref = ora.c_nmf(A, A.t(), 0.0, 3, 0.01, 0.01, 0, 0, 0, w0)
     got = sa.c_nmf(to_dgc(sa, A), None, 0.0, 3, False, 0.01, 0.01, 0, 0, 0, w0.T)
     _check(got, ref)
