@@ -194,7 +194,15 @@ __global__ void partial_sum_stage1_kernel(const double* __restrict__ part, int n
     const int b0 = blockIdx.y * SGL_RED_SEG;
     const int b1 = (b0 + SGL_RED_SEG < nblocks) ? b0 + SGL_RED_SEG : nblocks;
     double s = 0.0;
-    for (int b = b0; b < b1; ++b) s += part[(size_t)b * n + e];
+    int b = b0;
+    for (; b + 8 <= b1; b += 8) {   // eight loads in flight, added in block order
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(b + u) * n + e];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; b < b1; ++b) s += part[(size_t)b * n + e];
     tmp[(size_t)blockIdx.y * n + e] = s;
 }
 __global__ void partial_sum_stage2_kernel(const double* __restrict__ tmp, int nseg, int n, int diag_k, double diag_add,
@@ -219,7 +227,15 @@ __global__ __launch_bounds__(1024) void partial_sum_small_kernel(const double* _
         const int b0 = sgm * SGL_RED_SEG;
         const int b1 = (b0 + SGL_RED_SEG < nblocks) ? b0 + SGL_RED_SEG : nblocks;
         double s = 0.0;
-        for (int b = b0; b < b1; ++b) s += part[(size_t)b * n + e];
+        int b = b0;
+        for (; b + 8 <= b1; b += 8) {   // eight loads in flight, added in block order
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(b + u) * n + e];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; b < b1; ++b) s += part[(size_t)b * n + e];
         tmp[t] = s;
     }
     __syncthreads();
@@ -305,6 +321,13 @@ __global__ __launch_bounds__(256) void rowsum_kernel(const double* __restrict__ 
         double s0 = 0.0, s1 = 0.0;
         if (row < k) {
             int64_t cc = c_begin + ty;
+            for (; cc + 28 < c_end; cc += 32) {   // eight loads in flight; the two sums take them in the order of the plain loop below
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = F[(cc + 4 * u) * k + row];
+#pragma unroll
+                for (int u = 0; u < 8; u += 2) { s0 += v[u]; s1 += v[u + 1]; }
+            }
             for (; cc + 4 < c_end; cc += 8) {
                 s0 += F[cc * k + row];
                 s1 += F[(cc + 4) * k + row];
@@ -390,23 +413,22 @@ __global__ __launch_bounds__(256) void cor_partial_kernel(const double* __restri
     if (threadIdx.x < 5) part[(size_t)blockIdx.x * 5 + threadIdx.x] = sm[threadIdx.x][0];
 }
 
-__global__ void cor_final_kernel(const double* __restrict__ part, int nblocks, int64_t n, double* __restrict__ out) {
+__global__ __launch_bounds__(256) void cor_final_kernel(const double* __restrict__ part, int nblocks, int64_t n, double* __restrict__ out) {
     if (blockIdx.x != 0) return;
-    // the five sums in block order (one lane each, loads eight blocks ahead: one thread walking all 5 x nblocks
-    // partials took 64 us -- more than the reduction it finishes)
+    // the five sums in block order, one lane each, out of LDS: the partials come in with one round of loads by all 256 threads
+    // (five lanes walking them from memory eight at a time took 14 us at 367 blocks; one thread walking all of them 64 us)
+    __shared__ double pl[5 * 256];
     const int lane = threadIdx.x;
     double mine = 0.0;
-    if (lane < 5) {
-        int b = 0;
-        for (; b + 8 <= nblocks; b += 8) {
-            double v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(b + u) * 5 + lane];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) mine += v[u];
-        }
-        for (; b < nblocks; ++b) mine += part[(size_t)b * 5 + lane];
+    for (int b0 = 0; b0 < nblocks; b0 += 256) {
+        const int nb = (nblocks - b0 < 256) ? nblocks - b0 : 256;
+        __syncthreads();
+        for (int e = lane; e < nb * 5; e += 256) pl[e] = part[(size_t)b0 * 5 + e];
+        __syncthreads();
+        if (lane < 5)
+            for (int b = 0; b < nb; ++b) mine += pl[b * 5 + lane];
     }
+    if (lane >= 64) return;
     double s[5];
 #pragma unroll
     for (int q = 0; q < 5; ++q) s[q] = __shfl(mine, q, 64);
@@ -431,7 +453,7 @@ int k_cor(sgl_ctx* c, const double* x, const double* y, int64_t n, double* out_d
     //  lone block's serial tail.  Taken out; the same held for the row sums.  profiles/README.md)
     cor_partial_kernel<<<dim3(nblocks), dim3(256), 0, c->stream>>>(x, y, n, c->ws);
     HIPCHK(hipGetLastError());
-    cor_final_kernel<<<dim3(1), dim3(64), 0, c->stream>>>(c->ws, nblocks, n, out_dev);
+    cor_final_kernel<<<dim3(1), dim3(256), 0, c->stream>>>(c->ws, nblocks, n, out_dev);
     HIPCHK(hipGetLastError());
     return SGL_OK;
 }
