@@ -20,9 +20,13 @@
         /* round of the chip, two workgroups per CU, and lasts as long as the SIMD whose two waves take longest: in launch order   */ \
         /* CU c would get the sorted workgroups c and c + 256 -- the longest with the next longest.  A SIMD's time is about         */ \
         /* 7.5 max + 2.1 min sweep units (two waves share the FP64 pipe at 4.8 cycles per instruction, one alone gets 7.5), so the  */ \
-        /* second layer runs in ASCENDING order: CU c gets c and (last - c).  Positions only: a column's arithmetic is the same.    */ \
+        /* second layer runs in ASCENDING order, and the CUs that get no second workgroup (512 - count of them, the END of the       */ \
+        /* first layer) host the LONGEST ones: a wave alone takes 7.5 max.  Positions only: a column's arithmetic is the same.       */ \
         unsigned bx = blockIdx.x;                                                                                                   \
-        if (ps.fresh == 2 && gridDim.x > 256u && gridDim.x <= 512u && bx >= 256u) bx = gridDim.x - 1u - (bx - 256u);                \
+        if (ps.fresh == 2 && gridDim.x > 256u && gridDim.x <= 512u) {                                                               \
+            const unsigned alone = 512u - gridDim.x;                                                                                \
+            bx = bx >= 256u ? gridDim.x - 1u - (bx - 256u) : (bx < 256u - alone ? alone + bx : bx - (256u - alone));               \
+        }                                                                                                                           \
         if ((int64_t)bx * blockDim.x >= n_in) return;                                                                               \
         extern __shared__ __attribute__((aligned(16))) double nnls_asm_lds[];                                                       \
         double* const Gl = nnls_asm_lds;              /* Gl[i][l][m] = G[i, l + 16 m] */                                            \
