@@ -606,7 +606,9 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29541")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        if mode == "native":
+        if mode == "native" or os.environ.get("SGL_BENCH_HOOK_BACKEND") == "gloo":
+            # (SGL_BENCH_HOOK_BACKEND=gloo with --comm hook and SGL_BENCH_FORCE_DEVICE=0: a rehearsal of the process-per-GPU form on a
+            #  1-GPU box -- every rank its own context on the one device, the hook's all-reduce through gloo; not a scaling point)
             dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))

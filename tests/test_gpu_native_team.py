@@ -246,6 +246,36 @@ def test_bench_launcher_free_forms_print_one_json_line(argv, mode, n):
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(d["roofline"])
 
 
+@pytest.mark.parametrize("nproc", [2, 3])
+def test_bench_process_per_gpu_form_with_several_processes_on_one_device(nproc):
+    """The driver's N > 1 command -- `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` -- with every rank's
+    context on device 0 (SGL_BENCH_FORCE_DEVICE) and the hook's all-reduce through gloo (SGL_BENCH_HOOK_BACKEND): a rehearsal of
+    the process-per-GPU form on a 1-GPU box.  Everything on the host side that only runs with world > 1 does run: the sharding by
+    rank, the agreement of the ranks' tol bits after warm-up, the gather of every rank's phases, the max-over-ranks clock, one JSON
+    line from rank 0 with `per_rank` and `rank_imbalance`.  (RCCL itself refuses two ranks on one device: that part stays with the
+    team of one and the loopback team.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(SGL_BENCH_FORCE_DEVICE="0", SGL_BENCH_HOOK_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+                        "--master-port", str(29560 + nproc), os.path.join(root, "bench.py"), "--gpus", str(nproc), "--comm", "hook",
+                        "--genes", "3000", "--cells", "40001", "--k", "12", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, env=env, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                   # rank 0 alone prints
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == nproc and d["steps"] == 3 and d["value"] > 0 and d["scaling"] == "strong"
+    assert d["comm"]["mode"] == "hook" and d["comm"]["host_coordination"] == "gloo" and d["comm"]["tol_bit_identical_across_ranks"] is True
+    assert [q["rank"] for q in d["per_rank"]] == list(range(nproc))
+    assert sum(q["cells"] for q in d["per_rank"]) == 40001 and max(q["cells"] for q in d["per_rank"]) - min(q["cells"] for q in d["per_rank"]) <= 1
+    assert all(q["phases_ms_per_step"]["comm"] > 0 for q in d["per_rank"])
+    assert d["rank_imbalance"]["slowest_rank_by_compute"] in range(nproc)
+
+
 def test_team_call_times_out_instead_of_hanging():
     """A rank whose worker is blocked on the host (test hook SGL_TEAM_TEST_STALL) keeps its peers waiting for its part of the
     exchange.  The watchdog of the team call (SGL_TEAM_TIMEOUT_S) must release them and report SGL_ECOMM instead of hanging
