@@ -684,7 +684,7 @@ def main():
             ctx = sa.Context(local_rank)
             ctx.set_stream(stream.cuda_stream)
             mode = "hook"
-            hook_group = dist.new_group(backend="nccl")
+            hook_group = None if os.environ.get("SGL_BENCH_HOOK_BACKEND") == "gloo" else dist.new_group(backend="nccl")
     if mode == "hook":
         ctx.set_allreduce(torch_allreduce_hook(dist, torch.device("cuda", local_rank), group=hook_group))
 
