@@ -114,6 +114,22 @@ def plan(args, env):
     return {"form": "one-gpu", "world": 1, "rank": 0, "local_rank": 0}
 
 
+def pick_device(local_rank, visible, forced=None):
+    """Device index of a process-per-GPU rank, from counts only (no GPU call): the launcher's LOCAL_RANK when that many devices are
+    visible; with FEWER visible than LOCAL_RANK + 1 -- a launcher that isolates one device per rank (HIP_VISIBLE_DEVICES /
+    ROCR_VISIBLE_DEVICES set per process) -- the rank's own device is index LOCAL_RANK modulo the visible count, i.e. 0 when one
+    is visible.  -> (device, how).  `forced` = SGL_BENCH_FORCE_DEVICE (rehearsals on a 1-GPU box)."""
+    if forced is not None and str(forced).strip() != "":
+        return int(forced), "forced by SGL_BENCH_FORCE_DEVICE"
+    visible = int(visible)
+    if visible < 1:
+        raise SystemExit("bench.py: no gfx950 device visible to local rank %d" % local_rank)
+    if local_rank < visible:
+        return int(local_rank), "LOCAL_RANK"
+    return int(local_rank % visible), ("LOCAL_RANK %d but only %d device(s) visible to this process (devices isolated per rank): "
+                                       "index %d" % (local_rank, visible, local_rank % visible))
+
+
 def _cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
@@ -584,8 +600,10 @@ def main():
     import torch
     import singlet_amd as sa
 
-    if "SGL_BENCH_FORCE_DEVICE" in os.environ:   # plumbing tests on a 1-GPU box: every rank on one device (RCCL then refuses the team)
-        local_rank = int(os.environ["SGL_BENCH_FORCE_DEVICE"])
+    # SGL_BENCH_FORCE_DEVICE: plumbing tests on a 1-GPU box, every rank on one device (RCCL then refuses the team).  Otherwise the
+    # launcher's LOCAL_RANK -- unless it isolates the devices per rank, where every process sees its own as index 0
+    # (torch.cuda.device_count() reads the count without initialising the runtime)
+    local_rank, device_how = pick_device(local_rank, torch.cuda.device_count(), os.environ.get("SGL_BENCH_FORCE_DEVICE"))
     torch.cuda.set_device(local_rank)
     mode = args.comm
     if args.native_comm:
@@ -729,7 +747,7 @@ def main():
     layout = ctx.layout_get()
 
     nnz_total = nnz_local
-    phases_all, rank_info = [phases], [{"device": int(local_rank), "cells": int(n_loc), "nnz": int(nnz_local)}]
+    phases_all, rank_info = [phases], [{"device": int(local_rank), "device_from": device_how, "cells": int(n_loc), "nnz": int(nnz_local)}]
     if dist is not None:
         elapsed = reduce_host([elapsed], dist.ReduceOp.MAX)[0]
         nnz_total = int(reduce_host([float(nnz_local)], dist.ReduceOp.SUM)[0])

@@ -485,6 +485,12 @@ SGL_API int sgl_layout_builds(sgl_ctx* ctx, int64_t* out4);
  * per cell (H-update), per gene (W-update); 0 where the lists are not built (no masked pass yet, or the hashing kernels run).
  * One masked iteration forms out2[0] + out2[1] rank-one downdates w_r w_r^T: the work unit of the measurement in bench.py. */
 SGL_API int sgl_mask_pairs(sgl_ctx* ctx, int64_t* out2);
+/* Host wall-clock seconds of the calling thread's LAST one-shot call (sgl_c_nmf / sgl_c_ard_nmf: what an R caller of
+ * run_nmf -> .Call(_singlet_c_nmf), R/run_nmf.R:39-59, src/RcppExports.cpp:98-116, waits for around the iterations).  Up to n of
+ * out[0] host -> device copies of the dgCMatrix slots, [1] validation kernels (ascending rows, finite values), [2] device transpose
+ * (At = NULL), [3] sgl_fit_init (entry streams, w), [4] the ALS loop, [5] factors back to the host, [6] bytes copied in,
+ * [7] 1.0 when SINGLET_HIP_CACHE served the resident matrix of the previous call (nothing uploaded), [8] the whole call. */
+SGL_API int sgl_call_times_get(double* out, int32_t n);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""What an R caller sees: the ONE-SHOT call c_nmf(A, At = NULL, ...) -- host dgCMatrix slots in, host factors out -- at the
+benchmark's shapes, next to the resident loop bench.py times (R/run_nmf.R:39-59 -> .Call(_singlet_c_nmf), src/RcppExports.cpp:98-116).
+
+  python scripts/one_shot_rate.py [--genes 30000 --cells 1000000 --k 50 --maxit 100 --tol 1e-5] [--staged T]
+
+The host matrix is the benchmark's synthetic matrix: generated on the device by the library's own generator and downloaded into
+ordinary (pageable) numpy arrays, as R's slots are.  Three calls: (1) the one-shot call (upload, validation, device transpose,
+entry streams, iterations, factors back), with the library's own wall-clock split (sgl_call_times_get); (2) the same call again
+(a second fit on the same matrix: everything is paid again); (3) twice with SINGLET_HIP_CACHE=1: the second of those finds the
+matrix resident.  One JSON line."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import singlet_amd as sa  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--genes", type=int, default=30000)
+    ap.add_argument("--cells", type=int, default=1000000)
+    ap.add_argument("--k", type=int, default=50)
+    ap.add_argument("--maxit", type=int, default=100)
+    ap.add_argument("--tol", type=float, default=1e-5)
+    ap.add_argument("--L1", type=float, default=0.01)
+    ap.add_argument("--staged", type=int, default=None, help="SGL_UPLOAD_STAGED for the A/B leg (host threads of the staged copy)")
+    a = ap.parse_args()
+
+    t0 = time.perf_counter()
+    with sa.Context(0) as c:
+        c.synth(a.genes, a.cells, 20)
+        c.fit_init(a.k, None)
+        w0, _, _ = c.get_factors(h=False)             # the generator's initial w (genes x k), as R would pass runif()
+        x, i, p64 = c.download(0)
+    A = sa.dgCMatrix(x, i, p64.astype(np.int32), (a.genes, a.cells))
+    del x, i
+    host_bytes = A.x.nbytes + A.i.nbytes + A.p.nbytes
+    gen_s = time.perf_counter() - t0
+
+    def one_call(tag):
+        t = time.perf_counter()
+        r = sa.c_nmf(A, None, a.tol, a.maxit, False, a.L1, a.L1, 0.0, 0.0, 0, w0.T)
+        wall = time.perf_counter() - t
+        ct = sa.call_times()
+        setup = ct["h2d_s"] + ct["validate_s"] + ct["transpose_s"] + ct["fit_init_s"]
+        return {"call": tag, "wall_s": wall, "iterations": int(r["iter"]), "tol_last": float(r["tol"][-1]), "library_split_s": ct,
+                "setup_s": setup, "h2d_GBps": (ct["h2d_bytes"] / ct["h2d_s"] / 1e9) if ct["h2d_s"] > 0 else None,
+                "iter_per_s_inclusive": r["iter"] / wall, "iter_per_s_loop_only": r["iter"] / ct["iterate_s"] if ct["iterate_s"] > 0 else None}
+
+    out = {"config": "synthetic CSC %d genes x %d cells (nnz %d), k=%d, c_nmf(A, At=NULL, tol=%g, maxit=%d, L1=%g)"
+                     % (a.genes, a.cells, A.nnz, a.k, a.tol, a.maxit, a.L1),
+           "host_bytes_in": int(host_bytes), "host_generate_s": gen_s, "calls": []}
+    os.environ.pop("SINGLET_HIP_CACHE", None)
+    os.environ.pop("SGL_UPLOAD_STAGED", None)
+    sa.c_nmf(sa.dgCMatrix(A.x[:A.p[64]], A.i[:A.p[64]], A.p[:65], (a.genes, 64)), None, 0.0, 1, False, a.L1, a.L1, 0.0, 0.0, 0, w0.T)  # code objects
+    out["calls"].append(one_call("one-shot, first call on this matrix (pages never pinned)"))
+    out["calls"].append(one_call("one-shot, second call (everything paid again)"))
+    if a.staged:
+        os.environ["SGL_UPLOAD_STAGED"] = str(a.staged)
+        out["calls"].append(one_call("one-shot, SGL_UPLOAD_STAGED=%d" % a.staged))
+        out["calls"].append(one_call("one-shot, SGL_UPLOAD_STAGED=%d, again" % a.staged))
+        os.environ.pop("SGL_UPLOAD_STAGED", None)
+    os.environ["SINGLET_HIP_CACHE"] = "1"
+    out["calls"].append(one_call("SINGLET_HIP_CACHE=1, fills the cache"))
+    out["calls"].append(one_call("SINGLET_HIP_CACHE=1, matrix resident from the previous call"))
+    os.environ.pop("SINGLET_HIP_CACHE", None)
+    sa._lib.load().sgl_cache_release()
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -4,7 +4,7 @@
 from .sparse import dgCMatrix, as_dgCMatrix  # noqa: F401
 from .context import Context, Multi, comm_unique_id, comm_available, device_count, split_cells_by_nnz, LEVELS16, SYNTH_SEED  # noqa: F401
 from .api import (c_nmf, c_ard_nmf, c_linked_nmf, c_nmf_dense, c_nmf_sparse_list, c_ard_nmf_dense, c_ard_nmf_sparse_list, c_project_model, Rcpp_predict, run_nmf, ard_nmf, cross_validate_nmf,  # noqa: F401
-                  GetBestRank, project_model, CVData, PreprocessData, weight_by_split)
+                  GetBestRank, project_model, CVData, PreprocessData, weight_by_split, call_times)
 from ._lib import SingletHipError, LIB_PATH  # noqa: F401
 
 __version__ = "0.1.0"

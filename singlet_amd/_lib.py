@@ -135,6 +135,7 @@ SIGNATURES = {
     "sgl_layout_get": (C.c_int, [C.c_void_p, i64p]),
     "sgl_layout_builds": (C.c_int, [C.c_void_p, i64p]),
     "sgl_mask_pairs": (C.c_int, [C.c_void_p, i64p]),
+    "sgl_call_times_get": (C.c_int, [f64p, C.c_int32]),
 }
 
 _lib = None

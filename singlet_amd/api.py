@@ -55,6 +55,16 @@ def _verbose_log(verbose, ard=False):
     return log
 
 
+CALL_TIMES_KEYS = ("h2d_s", "validate_s", "transpose_s", "fit_init_s", "iterate_s", "d2h_s", "h2d_bytes", "cached", "total_s")
+
+
+def call_times():
+    """Host wall-clock split of this thread's last one-shot call (c_nmf / c_ard_nmf): sgl_call_times_get."""
+    out = np.zeros(len(CALL_TIMES_KEYS))
+    check(_lib.load().sgl_call_times_get(ptr(out, f64p), int(out.size)))
+    return dict(zip(CALL_TIMES_KEYS, (float(v) for v in out)))
+
+
 def c_nmf(A, At, tol, maxit, verbose, L1_w, L1_h, L2_w, L2_h, threads, w):
     """.Call(`_singlet_c_nmf`, ...) -> list(w = k x m, d = k, h = k x n)  (src/singlet.cpp:665)."""
     L = _lib.load()

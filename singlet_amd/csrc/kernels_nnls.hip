@@ -790,10 +790,10 @@ static int launch_nnls_quad(hipStream_t s, const double* G, int64_t gstride, con
     return SGL_OK;
 }
 
-int k_nnls_wave(hipStream_t s, const double* G, int64_t gstride, const double* B, double* X, const int64_t* col_nnz,
+int k_nnls_percol(hipStream_t s, const double* G, int64_t gstride, const double* B, double* X, const int64_t* col_nnz,
                 int k, int64_t ncols, double L1, double L2, unsigned long long* sweep_counter) {
     if (ncols <= 0) return SGL_OK;
-    if (k > SGL_MAX_K) { sgl_set_error("k_nnls_wave: k=%d > %d", k, SGL_MAX_K); return SGL_EINVAL; }
+    if (k > SGL_MAX_K) { sgl_set_error("k_nnls_percol: k=%d > %d", k, SGL_MAX_K); return SGL_EINVAL; }
     // per-column Grams: four columns per wave while four waves' triangles fit a CU's LDS (k <= 50).  Measured at
     // 30 000 x 100 000 (nnls_h, ms): k = 10: 1.1 vs 4.4 for nnls_wave_kernel, k = 30: 5.8 vs 14.0, k = 50: 21.5 vs
     // 27.1; at k = 64 (two waves per CU) 48.4 vs 38.5, so larger ranks stay on the wave kernel.  (env: A/B tests)

@@ -166,7 +166,10 @@ void sgl_team_detach(sgl_ctx* c) {
     if (!T) return;
     for (size_t i = 0; i < T->local.size(); ++i)
         if (T->local[i] == c) {
-            if (!T->loopback && i < T->comm.size() && T->comm[i] && rccl_api()) (void)rccl_api()->CommDestroy(T->comm[i]);
+            // (a broken team whose librccl cannot abort keeps its communicators: destroying one would wait for the very
+            //  collectives that never complete -- leaked on purpose, see team_abort)
+            if (!T->loopback && i < T->comm.size() && T->comm[i] && rccl_api() && !(T->broken.load() && !rccl_api()->CommAbort))
+                (void)rccl_api()->CommDestroy(T->comm[i]);
             T->local.erase(T->local.begin() + i);
             T->rank.erase(T->rank.begin() + i);
             if (i < T->comm.size()) T->comm.erase(T->comm.begin() + i);
@@ -191,15 +194,21 @@ static void team_abort(sgl_team* T) {
     if (T->loopback || T->comm.empty()) return;
     RcclApi* R = rccl_api();
     if (!R) return;
+    // A librccl without ncclCommAbort can only destroy, and ncclCommDestroy WAITS for the collectives in flight -- the very ones
+    // this abort is meant to break: then nothing is torn down here; the team is marked broken (every later call is refused with
+    // SGL_ECOMM) and the communicators stay as they are until sgl_multi_destroy (round-5 advice).
+    if (!R->CommAbort) return;
     for (size_t i = 0; i < T->comm.size(); ++i) {
         std::unique_lock<std::timed_mutex> lk;
         if (i < T->comm_mu.size() && T->comm_mu[i]) {
             lk = std::unique_lock<std::timed_mutex>(*T->comm_mu[i], std::defer_lock);
-            (void)lk.try_lock_for(std::chrono::seconds(2));   // an owner stuck inside an enqueue must not stop the abort
+            // the owner holds its mutex only while it enqueues (microseconds); one that is stuck INSIDE an enqueue keeps its
+            // communicator -- aborting it under the owner's feet would race with the enqueue -- and the abort of its peers'
+            // communicators is what releases it
+            if (!lk.try_lock_for(std::chrono::seconds(2))) continue;
         }
         if (T->comm[i]) {
-            if (R->CommAbort) (void)R->CommAbort(T->comm[i]);
-            else (void)R->CommDestroy(T->comm[i]);
+            (void)R->CommAbort(T->comm[i]);
             T->comm[i] = nullptr;
         }
     }
@@ -361,6 +370,8 @@ static int team_parallel(sgl_team* T, F&& fn) {
             team_abort(T);
             lk.lock();
         }
+        // (this second wait has no bound on purpose: the job closes over the caller's stack, so the call cannot return while a
+        //  worker may still run it; after the abort above every device-side wait of the workers has ended)
         P->cv_done.wait(lk, [&] { return P->pending == 0; });
         P->job = nullptr;
     }
@@ -502,17 +513,19 @@ static int team_exchange(sgl_team* T, int who, std::initializer_list<Xfer> ops) 
             HIPCHK(hipSetDevice(T->local[i]->device));
             SGLCHK(sgl_phase_begin(T->local[i], SGL_PH_COMM, &pe[i]));
         }
-        SGLCHK(group_begin(T));
-        int rc = SGL_OK;
-        for (const Xfer& x : ops)
-            if (rc == SGL_OK) rc = xfer_issue(T, 0, nl, x);
-        SGLCHK(group_end(T));
-        SGLCHK(rc);
-        for (int i = 0; i < nl; ++i) {
-            HIPCHK(hipSetDevice(T->local[i]->device));
-            SGLCHK(sgl_phase_end(T->local[i], &pe[i]));
+        int rc = group_begin(T);
+        if (rc == SGL_OK) {
+            for (const Xfer& x : ops)
+                if (rc == SGL_OK) rc = xfer_issue(T, 0, nl, x);
+            const int rc_end = group_end(T);
+            if (rc == SGL_OK) rc = rc_end;
         }
-        return SGL_OK;
+        for (int i = 0; i < nl; ++i) {   // the phases end on every exit
+            if (hipSetDevice(T->local[i]->device) != hipSuccess && rc == SGL_OK) { sgl_set_error("team: hipSetDevice failed"); rc = SGL_EHIP; }
+            const int rc_pe = sgl_phase_end(T->local[i], &pe[i]);
+            if (rc == SGL_OK) rc = rc_pe;
+        }
+        return rc;
     }
     sgl_ctx* c = T->local[who];
     HIPCHK(hipSetDevice(c->device));
@@ -523,32 +536,39 @@ static int team_exchange(sgl_team* T, int who, std::initializer_list<Xfer> ops) 
     }
     PhaseEvent pe;
     SGLCHK(sgl_phase_begin(c, SGL_PH_COMM, &pe));
+    // (one exit: whatever fails below, the phase's two events go back to the context -- round-5 advice)
+    int rc = SGL_OK;
     if (T->loopback) {
-        SGLCHK(team_barrier(T));
-        if (who == 0) {
-            for (const Xfer& x : ops) SGLCHK(xfer_issue(T, 0, nl, x));
-            HIPCHK(hipSetDevice(c->device));
+        rc = team_barrier(T);
+        if (rc == SGL_OK && who == 0) {
+            for (const Xfer& x : ops)
+                if (rc == SGL_OK) rc = xfer_issue(T, 0, nl, x);
+            if (rc == SGL_OK && hipSetDevice(c->device) != hipSuccess) { sgl_set_error("team: hipSetDevice failed"); rc = SGL_EHIP; }
         }
-        SGLCHK(team_barrier(T));
+        if (rc == SGL_OK) rc = team_barrier(T);
     } else {
         // enq first, failed second (the failing worker writes failed first, reads enq second): either this rank sees the
         // failure and enqueues nothing, or the failing rank sees the pending step and aborts the communicators
         TeamPool* P = T->pool;
         if (P) {
             P->enq.fetch_add(1);
-            if (P->failed.load()) { sgl_set_error("team: another rank failed"); return SGL_ECOMM; }
+            if (P->failed.load()) { sgl_set_error("team: another rank failed"); rc = SGL_ECOMM; }
         }
-        std::unique_lock<std::timed_mutex> lk;
-        if ((size_t)who < T->comm_mu.size() && T->comm_mu[who]) lk = std::unique_lock<std::timed_mutex>(*T->comm_mu[who]);
-        SGLCHK(team_refused(T));
-        SGLCHK(group_begin(T));
-        int rc = SGL_OK;
-        for (const Xfer& x : ops)
-            if (rc == SGL_OK) rc = xfer_issue(T, who, who + 1, x);
-        SGLCHK(group_end(T));
-        SGLCHK(rc);
+        if (rc == SGL_OK) {
+            std::unique_lock<std::timed_mutex> lk;
+            if ((size_t)who < T->comm_mu.size() && T->comm_mu[who]) lk = std::unique_lock<std::timed_mutex>(*T->comm_mu[who]);
+            rc = team_refused(T);
+            if (rc == SGL_OK) rc = group_begin(T);
+            if (rc == SGL_OK) {
+                for (const Xfer& x : ops)
+                    if (rc == SGL_OK) rc = xfer_issue(T, who, who + 1, x);
+                const int rc_end = group_end(T);   // a group that was begun is always ended
+                if (rc == SGL_OK) rc = rc_end;
+            }
+        }
     }
-    return sgl_phase_end(c, &pe);
+    const int rc_pe = sgl_phase_end(c, &pe);
+    return rc != SGL_OK ? rc : rc_pe;
 }
 
 // ---------------------------------------------------------------- team set-up --
@@ -848,7 +868,7 @@ static int team_ard_iterate(sgl_team* T, double L1, double L2, uint64_t seed, ui
             SGLCHK(k_mask_gram_finalize(c->stream, c->G, c->Sbuf + (size_t)(g0 + q0) * k * k, k, nq, c->Gcols));
             SGLCHK(sgl_phase_end(c, &pe));
             SGLCHK(sgl_phase_begin(c, SGL_PH_NNLS_W, &pe));
-            SGLCHK(k_nnls_wave(c->stream, c->Gcols, (int64_t)k * k, c->red + (size_t)(g0 + q0) * k, c->W + (size_t)(g0 + q0) * k,
+            SGLCHK(k_nnls_percol(c->stream, c->Gcols, (int64_t)k * k, c->red + (size_t)(g0 + q0) * k, c->W + (size_t)(g0 + q0) * k,
                                c->col_nnz_At_global + g0 + q0, k, nq, L1, L2, c->sweep_counters + 1));
             SGLCHK(sgl_phase_end(c, &pe));
         }

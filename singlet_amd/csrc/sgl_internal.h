@@ -300,7 +300,11 @@ int nnls_pack_alloc(NnlsScratch& sc, int64_t ncols);
 // few columns against a shared Gram (k <= 64): four columns per wave, the Gram staged in LDS; B is read only
 int k_nnls_quad_shared(hipStream_t s, const double* G, const double* B, double* X, const int64_t* col_nnz, int k, int64_t ncols,
                        double L1, double L2, unsigned long long* sweep_counter);
-int k_nnls_wave(hipStream_t s, const double* G, int64_t gstride, const double* B, double* X, const int64_t* col_nnz,
+// THE DISPATCH of every solve that is not the lane / two-lane / shared-quad kernel (until round 6 named k_nnls_wave, after its
+// last resort): per-column Grams (gstride = k * k: the masked path, one GPU AND the gene blocks of a team, multi.hip) run four
+// columns per wave -- nnls_quad_kernel (triangles in LDS, k < 40 / 47) or nnls_quad_global_kernel (k <= 112 / 128) -- and only
+// above that, or with a shared Gram above k = 128 (gstride = 0), the wave-per-column kernel
+int k_nnls_percol(hipStream_t s, const double* G, int64_t gstride, const double* B, double* X, const int64_t* col_nnz,
                 int k, int64_t ncols, double L1, double L2, unsigned long long* sweep_counter);
 
 // masked path

@@ -9,7 +9,10 @@
 #include <string.h>
 #include <algorithm>
 #include <string>
+#include <chrono>
 #include <mutex>
+#include <thread>
+#include <vector>
 #include <stdlib.h>
 
 // ------------------------------------------------------------------ errors --
@@ -24,6 +27,25 @@ void sgl_set_error(const char* fmt, ...) {
 
 extern "C" const char* sgl_last_error(void) { return g_err; }
 extern "C" int sgl_abi_version(void) { return 2; }
+
+// ---------------------------------------------------- wall clock of a one-shot call --
+// What an R caller pays around the iterations (round-5 verdict: "what R sees"): host seconds of the LAST one-shot call of this
+// thread (sgl_c_nmf / sgl_c_ard_nmf), split where the call synchronises anyway.  sgl_call_times_get (include/singlet_hip.h section 4).
+struct CallTimes {
+    double h2d_s = 0, validate_s = 0, transpose_s = 0, fit_init_s = 0, iterate_s = 0, d2h_s = 0, h2d_bytes = 0, cached = 0, total_s = 0,
+           create_s = 0;
+};
+static thread_local CallTimes g_times;
+static double wall_now() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+extern "C" int sgl_call_times_get(double* out, int32_t n) {
+    if (!out || n < 0) { sgl_set_error("sgl_call_times_get: bad arguments"); return SGL_EINVAL; }
+    const double v[10] = {g_times.h2d_s, g_times.validate_s, g_times.transpose_s, g_times.fit_init_s, g_times.iterate_s, g_times.d2h_s,
+                          g_times.h2d_bytes, g_times.cached, g_times.total_s, g_times.create_s};
+    for (int32_t q = 0; q < n && q < 10; ++q) out[q] = v[q];
+    return SGL_OK;
+}
 
 static bool device_is_gfx950(int dev) {
     hipDeviceProp_t prop;
@@ -267,6 +289,84 @@ static int do_allreduce(sgl_ctx* c, double* dev_ptr, int64_t count) {
 }
 
 // ----------------------------------------------------------------- upload ---
+// Host -> device copy of a large slot.  Default: one hipMemcpyAsync from the caller's (pageable) memory -- the runtime pins the
+// pages in place and DMAs from them.  SGL_UPLOAD_STAGED=T (T = 2 .. 16 host threads): the slot is cut into T contiguous parts, each
+// moved by its own thread through two pinned 8 MB buffers on its own stream (memcpy into one buffer while the other is in
+// flight) -- for hosts whose in-place pinning is slow.  Which one is faster on the test box: profiles/r6_one_shot_*.json.
+struct StagePool {
+    std::mutex mu;
+    std::vector<void*> free_bufs;
+    static constexpr size_t BUF = (size_t)8 << 20;
+    void* take() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (!free_bufs.empty()) { void* b = free_bufs.back(); free_bufs.pop_back(); return b; }
+        }
+        void* b = nullptr;
+        if (hipHostMalloc(&b, BUF, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        return b;
+    }
+    void give(void* b) { std::lock_guard<std::mutex> lk(mu); free_bufs.push_back(b); }
+    void release() {
+        std::lock_guard<std::mutex> lk(mu);
+        for (void* b : free_bufs) (void)hipHostFree(b);
+        free_bufs.clear();
+    }
+};
+static StagePool g_stage;
+
+static int h2d_staged(sgl_ctx* c, char* dst, const char* src, size_t bytes, int T) {
+    std::vector<int> rcs((size_t)T, SGL_OK);
+    std::vector<std::thread> th;
+    const size_t part = ((bytes + (size_t)T - 1) / (size_t)T + 4095) & ~(size_t)4095;
+    auto work = [&](int t) {
+        const size_t lo = std::min(bytes, part * (size_t)t), hi = std::min(bytes, lo + part);
+        if (lo >= hi) return;
+        if (hipSetDevice(c->device) != hipSuccess) { rcs[(size_t)t] = SGL_EHIP; return; }
+        hipStream_t st = nullptr;
+        hipEvent_t ev[2] = {nullptr, nullptr};
+        void* pin[2] = {g_stage.take(), g_stage.take()};
+        bool ok = pin[0] && pin[1] && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess &&
+                  hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) == hipSuccess;
+        size_t q = 0;
+        for (size_t off = lo; ok && off < hi; off += StagePool::BUF, ++q) {
+            const size_t n = std::min(StagePool::BUF, hi - off);
+            const int b = (int)(q & 1);
+            if (q >= 2) ok = hipEventSynchronize(ev[b]) == hipSuccess;
+            if (!ok) break;
+            memcpy(pin[b], src + off, n);
+            ok = hipMemcpyAsync(dst + off, pin[b], n, hipMemcpyHostToDevice, st) == hipSuccess && hipEventRecord(ev[b], st) == hipSuccess;
+        }
+        if (st && hipStreamSynchronize(st) != hipSuccess) ok = false;
+        for (auto e : ev) if (e) (void)hipEventDestroy(e);
+        if (st) (void)hipStreamDestroy(st);
+        for (void* b : pin) if (b) g_stage.give(b);
+        if (!ok) { (void)hipGetLastError(); rcs[(size_t)t] = SGL_EHIP; }
+    };
+    try {
+        for (int t = 1; t < T; ++t) th.emplace_back(work, t);
+    } catch (...) {
+        for (auto& x : th) x.join();
+        sgl_set_error("upload: could not start the staging threads");
+        return SGL_ENOMEM;
+    }
+    work(0);
+    for (auto& x : th) x.join();
+    (void)hipSetDevice(c->device);
+    for (int rc : rcs)
+        if (rc != SGL_OK) { sgl_set_error("upload: a staged host -> device copy failed"); return rc; }
+    return SGL_OK;
+}
+
+static int sgl_h2d(sgl_ctx* c, void* dst, const void* src, size_t bytes) {
+    if (bytes == 0) return SGL_OK;
+    const char* e = getenv("SGL_UPLOAD_STAGED");
+    const int T = e ? std::max(0, std::min(16, atoi(e))) : 0;
+    if (T >= 2 && bytes >= ((size_t)64 << 20)) return h2d_staged(c, static_cast<char*>(dst), static_cast<const char*>(src), bytes, T);
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    return SGL_OK;
+}
+
 static int upload_one(sgl_ctx* c, DevCSC& M, const double* x, const int32_t* i, const int32_t* p, int32_t nrow,
                       int32_t ncol) {
     const int64_t nnz = (int64_t)p[ncol];
@@ -276,15 +376,20 @@ static int upload_one(sgl_ctx* c, DevCSC& M, const double* x, const int32_t* i, 
     M.nrow = nrow;
     M.ncol = ncol;
     M.nnz = nnz;
+    const double t0 = wall_now();
     SGLCHK(dev_alloc(&M.x, (size_t)nnz));
     SGLCHK(dev_alloc(&M.i, (size_t)nnz));
     SGLCHK(dev_alloc(&M.p, (size_t)ncol + 1));
-    HIPCHK(hipMemcpyAsync(M.x, x, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(M.i, i, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice, c->stream));
+    SGLCHK(sgl_h2d(c, M.x, x, sizeof(double) * (size_t)nnz));
+    SGLCHK(sgl_h2d(c, M.i, i, sizeof(int32_t) * (size_t)nnz));
     int32_t* p32 = nullptr;
     SGLCHK(dev_alloc(&p32, (size_t)ncol + 1));
     int rc = SGL_OK;
     if (hipMemcpyAsync(p32, p, sizeof(int32_t) * ((size_t)ncol + 1), hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = SGL_EHIP;
+    if (rc == SGL_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = SGL_EHIP;   // (the copies from pageable memory have all but ended here anyway)
+    const double t1 = wall_now();
+    g_times.h2d_s += t1 - t0;
+    g_times.h2d_bytes += 12.0 * (double)nnz + 4.0 * ((double)ncol + 1);
     if (rc == SGL_OK) rc = k_widen_p(c->stream, p32, (int64_t)ncol + 1, M.p);
     // the kernels index factor rows by these values: refuse anything that is not a valid dgCMatrix
     int flag = 0;
@@ -292,6 +397,7 @@ static int upload_one(sgl_ctx* c, DevCSC& M, const double* x, const int32_t* i, 
     if (rc == SGL_OK) rc = k_all_finite(c->stream, M.x, nnz, reinterpret_cast<int*>(p32));
     if (rc == SGL_OK && hipMemcpyAsync(&flag, p32, sizeof(int), hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = SGL_EHIP;
     if (hipStreamSynchronize(c->stream) != hipSuccess && rc == SGL_OK) rc = SGL_EHIP;
+    g_times.validate_s += wall_now() - t1;
     dev_free(p32);
     if (rc == SGL_EHIP) { sgl_set_error("upload: a HIP call failed: %s", hipGetErrorString(hipGetLastError())); return rc; }
     if (rc == SGL_OK && flag != 0) {
@@ -383,7 +489,10 @@ extern "C" int sgl_upload_csc(sgl_ctx* c, const double* Ax, const int32_t* Ai, c
         if ((int64_t)Atp[nrow] != c->A.nnz) { sgl_set_error("At has %d non-zeros, A has %lld", Atp[nrow], (long long)c->A.nnz); return SGL_EINVAL; }
         SGLCHK(upload_one(c, c->At, Atx, Ati, Atp, ncol, nrow));
     } else {
+        const double t0 = wall_now();
         SGLCHK(sgl_device_transpose(c));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        g_times.transpose_s += wall_now() - t0;
     }
     return finish_matrix(c);
 }
@@ -455,8 +564,13 @@ extern "C" int sgl_upload_dense(sgl_ctx* c, const double* A, int32_t nrow, int32
                              hipStreamSynchronize(c->stream) != hipSuccess)) rc = SGL_EHIP;
         dev_free(dflag);
         if (rc == SGL_EHIP) sgl_set_error("sgl_upload_dense: HIP call failed");
-        SGLCHK(rc);
-        if (flag != 0) { sgl_set_error("sgl_upload_dense: non-finite value (NA / NaN / Inf) in the matrix"); return SGL_EINVAL; }
+        if (rc == SGL_OK && flag != 0) { sgl_set_error("sgl_upload_dense: non-finite value (NA / NaN / Inf) in the matrix"); rc = SGL_EINVAL; }
+        if (rc != SGL_OK) {   // the refused copy does not stay resident until the next upload
+            (void)hipStreamSynchronize(c->stream);
+            dev_free(c->Adense);
+            c->Adense = nullptr;
+            return rc;
+        }
     }
     DevCSC& M = c->A;
     M.nrow = nrow; M.ncol = ncol;
@@ -776,7 +890,7 @@ int sgl_nnls_shared(sgl_ctx* c, const double* G, double* B, double* X, const int
         // the H side of a plain fit packs its waves by the sweep counts of the previous iteration (kernels_nnls.hip)
         return k_nnls_lane(c->stream, c->Gpad, KP, B, X, col_nnz, k, ncols, L1, L2, counter, &c->nnls_scr, h_side && ncols == c->A.ncol);
     }
-    return k_nnls_wave(c->stream, G, 0, B, X, col_nnz, k, ncols, L1, L2, counter);
+    return k_nnls_percol(c->stream, G, 0, B, X, col_nnz, k, ncols, L1, L2, counter);
 }
 
 extern "C" int sgl_step_begin(sgl_ctx* c) {
@@ -1000,7 +1114,7 @@ int sgl_predict_mask_dev(sgl_ctx* c, const DevCSC& M, const int64_t* col_nnz, co
         { Phase ph(c, SGL_PH_MASK);
           SGLCHK(k_mask_gram_cols(c->stream, c0, nc, M.nrow, col_nnz, F, c->G, k, seed, inv_density, mask_t, col_off, row_off, c->Gcols, L)); }
         { Phase ph(c, nnls_phase);
-          SGLCHK(k_nnls_wave(c->stream, c->Gcols, (int64_t)k * k, Bbuf + (size_t)c0 * k, X + (size_t)c0 * k,
+          SGLCHK(k_nnls_percol(c->stream, c->Gcols, (int64_t)k * k, Bbuf + (size_t)c0 * k, X + (size_t)c0 * k,
                              col_nnz ? col_nnz + c0 : nullptr, k, nc, L1, L2, counter)); }
     }
     return SGL_OK;
@@ -1185,6 +1299,7 @@ static int acquire_ctx(const double* Ax, const int32_t* Ai, const int32_t* Ap, c
         (!Atx || (g_cache.atx == Atx && g_cache.ati == Ati && g_cache.atp == Atp))) {
         *out = g_cache.c;
         *cached = true;
+        g_times.cached = 1.0;   // the resident matrix of the previous call serves this one: nothing uploaded
         return SGL_OK;
     }
     if (g_cache.c) { sgl_destroy(g_cache.c); g_cache = CachedCtx(); }
@@ -1220,6 +1335,7 @@ struct AcquiredCtx {   // destroys a non-cached context on scope exit; serialise
 extern "C" int sgl_cache_release(void) {
     std::lock_guard<std::mutex> lk(g_cache_mu);
     if (g_cache.c) { sgl_destroy(g_cache.c); g_cache = CachedCtx(); }
+    g_stage.release();   // the pinned staging buffers of SGL_UPLOAD_STAGED
     return SGL_OK;
 }
 
@@ -1240,11 +1356,23 @@ extern "C" int sgl_c_nmf(const double* Ax, const int32_t* Ai, const int32_t* Ap,
             return sgl_c_nmf_multi(want, Ax, Ai, Ap, nrow, ncol, tol, maxit, L1_w, L1_h, L2_w, L2_h, w_init, k, w_out, d_out, h_out, n_iter, tol_trace, cb);
         }
     }
+    g_times = CallTimes();
+    const double t_call = wall_now();
     AcquiredCtx hd;
     SGLCHK(acquire_ctx(Ax, Ai, Ap, Atx, Ati, Atp, nrow, ncol, &hd.c, &hd.cached));
+    const double t_fit = wall_now();
     SGLCHK(sgl_fit_init(hd.c, k, w_init, 0));
+    HIPCHK(hipStreamSynchronize(hd.c->stream));
+    const double t_run = wall_now();
     SGLCHK(sgl_nmf_run(hd.c, tol, maxit, L1_w, L1_h, L2_w, L2_h, n_iter, tol_trace, cb));
-    return hd.done(sgl_get_factors(hd.c, w_out, d_out, h_out));
+    const double t_get = wall_now();
+    const int rc = sgl_get_factors(hd.c, w_out, d_out, h_out);
+    const double t_end = wall_now();
+    g_times.fit_init_s = t_run - t_fit;
+    g_times.iterate_s = t_get - t_run;
+    g_times.d2h_s = t_end - t_get;
+    g_times.total_s = t_end - t_call;
+    return hd.done(rc);
 }
 
 // c_linked_nmf's link matrices (src/singlet.cpp:1059-1065): each is used only if its column count
@@ -1330,13 +1458,25 @@ extern "C" int sgl_c_ard_nmf(const double* Ax, const int32_t* Ai, const int32_t*
                                        trace_test_mse, w_out, d_out, h_out, test_mse, iter, tol_out, score_overfit, n_trace, cb);
         }
     }
+    g_times = CallTimes();
+    const double t_call = wall_now();
     AcquiredCtx hd;
     SGLCHK(acquire_ctx(Ax, Ai, Ap, Atx, Ati, Atp, nrow, ncol, &hd.c, &hd.cached));
+    const double t_fit = wall_now();
     SGLCHK(sgl_fit_init(hd.c, k, w_init, 0));
+    HIPCHK(hipStreamSynchronize(hd.c->stream));
+    const double t_run = wall_now();
     int32_t nit = 0;
     SGLCHK(sgl_ard_run(hd.c, tol, maxit, L1, L2, seed, inv_density, overfit_threshold, trace_test_mse, test_mse, iter,
                        tol_out, score_overfit, n_trace, &nit, cb));
-    return hd.done(sgl_get_factors(hd.c, w_out, d_out, h_out));
+    const double t_get = wall_now();
+    const int rc = sgl_get_factors(hd.c, w_out, d_out, h_out);
+    const double t_end = wall_now();
+    g_times.fit_init_s = t_run - t_fit;
+    g_times.iterate_s = t_get - t_run;
+    g_times.d2h_s = t_end - t_get;
+    g_times.total_s = t_end - t_call;
+    return hd.done(rc);
 }
 
 // c_ard_nmf_dense (src/singlet.cpp:1357-1361; dense predict_mask :506-533, mse_test :608-632): the CSC image through
@@ -1587,7 +1727,7 @@ extern "C" int sgl_op_nnls(sgl_ctx* c, const double* G, const double* B, double*
         if (rc == SGL_OK && (ncols >= nnls_repack_min_cols() || k > 64)) rc = nnls_scratch_alloc(scr, ncols, k);
         if (rc == SGL_OK) rc = k_nnls_lane(c->stream, dGp.p, KP, dB.p, dX.p, nullptr, k, ncols, L1, L2, c->sweep_counters + 4, &scr);
     } else {
-        rc = k_nnls_wave(c->stream, dG.p, 0, dB.p, dX.p, nullptr, k, ncols, L1, L2, c->sweep_counters + 4);
+        rc = k_nnls_percol(c->stream, dG.p, 0, dB.p, dX.p, nullptr, k, ncols, L1, L2, c->sweep_counters + 4);
     }
     unsigned long long sw = 0;
     if (rc == SGL_OK && (hipMemcpyAsync(X, dX.p, sizeof(double) * (size_t)k * ncols, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||

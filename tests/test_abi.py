@@ -102,7 +102,10 @@ def test_reference_build_products_stay_out_of_history():
     assert tracked.stdout.strip() == ""
     ign = open(os.path.join(ROOT, ".gitignore")).read()
     assert "oracle/_ref/" in ign
-    assert not os.path.exists(os.path.join(ROOT, ".gpurunignore")) or "oracle/_ref" not in open(os.path.join(ROOT, ".gpurunignore")).read()
+    # the built librng_ref.so travels to the GPU box like the other built libraries; the extracted reference text (*.inc) need not
+    # (round-5 verdict): .gpurunignore may name oracle/_ref/*.inc, never the directory or the library
+    gi = open(os.path.join(ROOT, ".gpurunignore")).read().split() if os.path.exists(os.path.join(ROOT, ".gpurunignore")) else []
+    assert all(ln == "oracle/_ref/*.inc" for ln in gi if "oracle/_ref" in ln), gi
     for f in ("oracle/make_ref.sh", "oracle/ref_rng_shim.cpp", "tests/golden/make_rng_ref.py", "tests/golden/rng_ref.npz"):
         assert os.path.exists(os.path.join(ROOT, f)), f
     # the shim holds no reference text: it includes the extracted class

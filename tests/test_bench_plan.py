@@ -114,3 +114,18 @@ def test_report_names_the_straggler_by_its_compute_time():
     args = bench.parse(["--gpus", "4", "--steps", "10", "--genes", "300", "--cells", "1000", "--k", "5", "--no-cpu-baseline"])
     out = bench.report(args, _fake_run(4, slow_rank=2))
     assert out["rank_imbalance"]["slowest_rank_by_compute"] == 2 and out["rank_imbalance"]["max_over_min_compute"] > 1.2
+
+
+def test_process_per_gpu_device_pick_survives_a_launcher_that_isolates_the_devices():
+    """The driver's N > 1 command gives every process a LOCAL_RANK.  Normally all N devices are visible and the rank takes device
+    LOCAL_RANK; a launcher that sets HIP_VISIBLE_DEVICES per process leaves ONE device visible, index 0 -- ranks > 0 must not ask
+    for a device that does not exist (round-5 verdict: they died before any RCCL call)."""
+    for lr in range(8):
+        assert bench.pick_device(lr, 8) == (lr, "LOCAL_RANK")
+        dev, how = bench.pick_device(lr, 1)
+        assert dev == 0 and (how == "LOCAL_RANK" if lr == 0 else "isolated" in how)
+    assert bench.pick_device(5, 4)[0] == 1                      # fewer devices than ranks: wraps (RCCL then refuses, hook path)
+    assert bench.pick_device(3, 8, forced="0") == (0, "forced by SGL_BENCH_FORCE_DEVICE")
+    assert bench.pick_device(3, 8, forced="") == (3, "LOCAL_RANK")
+    with pytest.raises(SystemExit):
+        bench.pick_device(0, 0)

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("m,n,k,ranks", [(300, 1000, 8, 2), (257, 700, 30, 3), (500, 640, 50, 2), (130, 900, 70, 4), (96, 400, 5, 7), (210, 520, 100, 2),
-                                          (230, 500, 120, 3)])
+                                          (230, 500, 120, 3), (300, 1000, 8, 8), (263, 1100, 50, 8), (150, 640, 70, 8)])
 def test_team_on_one_device_matches_the_oracle_and_the_single_shard(sa, ora, m, n, k, ranks):
     A = ora.synth_csc(m, n, 20)
     At = A.t()
@@ -138,7 +138,8 @@ def test_team_refuses_what_it_does_not_support(sa, ora):
             c.ard_run(0.0, 2, 0.01, 0.0, 1, 20, 1e9, 1)  # a rank of a one-process team does not run the loop alone
 
 
-@pytest.mark.parametrize("m,n,k,ranks,inv", [(300, 900, 8, 2, 20), (257, 700, 30, 3, 10), (400, 520, 50, 2, 20), (420, 640, 70, 4, 10)])
+@pytest.mark.parametrize("m,n,k,ranks,inv", [(300, 900, 8, 2, 20), (257, 700, 30, 3, 10), (400, 520, 50, 2, 20), (420, 640, 70, 4, 10),
+                                             (300, 900, 8, 8, 20), (263, 800, 50, 8, 10), (150, 640, 70, 7, 10)])
 def test_sharded_masked_path_matches_the_oracle_and_the_single_shard(sa, ora, m, n, k, ranks, inv):
     """c_ard_nmf with the cells sharded (src/singlet.cpp:469-503, 571-607 are the reference's own chunked
     forms, `i + offset` at :485, `j + offset` at :590): per-gene right-hand sides and Gram downdates are
