@@ -141,12 +141,15 @@ def _cpu_model():
     return "unknown"
 
 
-def cpu_baseline(args):
+def cpu_baseline(args, w_start=None, it_start=0):
     """The oracle (line-by-line restatement of singlet's OpenMP path, oracle/singlet_oracle.c) MEASURED on
     this host's cores on a bounded sample of the same workload: the first `cpu_sample_cells` cells
     (default 200 000 = the slice SURVEY.md 8d prescribes; --cpu-sample-cells 0 = all cells) x all genes,
-    same k / penalties, A and t(A) in host memory.  One warm-up iteration, then ALS iterations 2-3 timed
-    inside the C code (omp_get_wtime per phase).  Two builds of the same source: gcc -O2 (R's default
+    same k / penalties, A and t(A) in host memory.  One warm-up iteration, then two ALS iterations timed
+    inside the C code (omp_get_wtime per phase).  w_start (round 6): the w of the GPU fit after its `it_start`
+    iterations -- the CPU then times iterations it_start + 2 .. it_start + 3 of the SAME fit, where the NNLS needs
+    the sweeps the GPU's timed iterations needed (from the generator's initial w it would time iterations 2 - 3:
+    46 sweeps per cell against the GPU window's 29, ~10 % in the GPU's favour: round-5 verdict).  Two builds of the same source: gcc -O2 (R's default
     level, what `value` reports) and -O3 -march=native (the generous variant).  When the sample is not
     the whole matrix the per-cell phases are scaled to the full cell count; the part of predict(At)
     that does not grow with the cells (the m NNLS solves of the W-update) is separated with a second,
@@ -158,7 +161,8 @@ def cpu_baseline(args):
     ns = args.cells if args.cpu_sample_cells <= 0 else min(args.cpu_sample_cells, args.cells)
     t0 = time.perf_counter()
     full = ora.synth_csc(args.genes, ns, args.inv_density)
-    w0 = ora.synth_winit(args.k, args.genes)
+    w0 = ora.synth_winit(args.k, args.genes) if w_start is None else np.ascontiguousarray(w_start, dtype=np.float64)
+    assert w0.shape == (args.genes, args.k)
     full_t = full.t()
     gen_s = time.perf_counter() - t0
 
@@ -221,10 +225,12 @@ def cpu_baseline(args):
     except Exception as e:  # noqa: BLE001
         out["native_build"] = {"error": repr(e)}
     what = "all %d cells (full)" % ns if ns == args.cells else "%d cells (first %d of %d)" % (ns, ns, args.cells)
+    out["iterations_timed"] = ("2-3 of a fit from the generator's initial w" if w_start is None else
+                               "%d-%d of the fit the GPU timed (w after the GPU's iteration %d handed over)" % (it_start + 2, it_start + 3, it_start))
     out["sample"] = ("oracle/singlet_oracle.c, restatement of singlet's OpenMP path, %d threads on %s; %s x %d genes, k=%d; "
-                     "1 warm-up + ALS iterations 2-3 timed in C: %.2f s/iter on the sample (predict(A) %.2f, scale(h) %.3f, "
+                     "1 warm-up + ALS iterations %s timed in C: %.2f s/iter on the sample (predict(A) %.2f, scale(h) %.3f, "
                      "predict(At) %.2f, scale(w)+cor %.3f)%s; generation + transpose %.1f s not timed"
-                     % (cores, out["cpu_model"], what, args.genes, args.k, float(pf.sum()), pf[0], pf[1], pf[2], pf[3],
+                     % (cores, out["cpu_model"], what, args.genes, args.k, out["iterations_timed"], float(pf.sum()), pf[0], pf[1], pf[2], pf[3],
                         "" if ns == args.cells else "; per-cell phases scaled x%.1f, the W-side NNLS (%.2f s, from a "
                         "half-size run) not scaled" % (scale, b), gen_s))
     return out
@@ -365,7 +371,7 @@ def report(args, run):
                                "w_per_wave": sweeps["w_wave_sweeps"] / (args.steps * ((run["w_cols_rank0"] + 63) // 64))}
     if world == 1 and not args.no_cpu_baseline:
         try:
-            out["cpu_baseline"] = cpu_baseline(args)
+            out["cpu_baseline"] = cpu_baseline(args, run.get("w_start"), args.warmup + args.steps)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         except Exception as e:  # noqa: BLE001 - the baseline is reported, never required
             out["cpu_baseline"] = {"error": repr(e)}
@@ -757,7 +763,8 @@ def main():
 
     if rank == 0:
         mb = (m + world - 1) // world if (world > 1 and mode == "native") else m
-        out = report(args, {"world": world, "elapsed": elapsed, "tols": tols, "dims": (m, n_loc, nnz_local), "nnz_total": nnz_total,
+        w_start = ctx.get_factors(h=False)[0] if (world == 1 and not args.no_cpu_baseline) else None   # for the CPU baseline's window
+        out = report(args, {"world": world, "w_start": w_start, "elapsed": elapsed, "tols": tols, "dims": (m, n_loc, nnz_local), "nnz_total": nnz_total,
                             "phases": phases, "phases_all": phases_all, "rank_info": rank_info if world > 1 else None,
                             "sweeps": sweeps, "layout": layout, "gen_s": gen_s, "w_cols_rank0": min(mb, m),
                             "comm": {"mode": mode, "note": comm_note, "rccl_nranks": comm_info["nranks"] if comm_info["is_rccl"] else None,

@@ -894,10 +894,14 @@ int k_acc_tiled_all(hipStream_t s, const DevTiled& S, const double* F, double* B
 // 2.4 x -- rhs_h per 200 000 cells at k = 100: 5.84 -> 4.89 ms, k = 128: 6.48 -> 5.01; profiles/r5_k_sweep_200k_cells.txt).
 // One pass over half-height tiles with four factors per lane was priced and loses: 15 % more LDS time than the two passes
 // (scripts/r5/r5_pad_model.py).  SGL_TILED_NO_QUAD3=1: two pair passes (A/B, tests).
+// Round 6: ranks above 128 too -- ceil(k / 32) quad passes over the same stream (the reference's nnls / predict have no rank
+// limit, src/singlet.cpp:229-250, and RunNMF hands ard_nmf k_max = 1e4, R/RunNMF.R:131); until then they fell to the plain
+// wave-per-column gather (acc_kernel).  SGL_TILED_MAX_K=128 restores that (A/B, tests).
 int tiled_part_size(int k) {
     if (k <= 64) return k;
-    if (k > 128) return 0;
+    const char* mk = getenv("SGL_TILED_MAX_K");
+    if (k > ((mk && atoi(mk) > 0) ? atoi(mk) : SGL_MAX_K)) return 0;
     const bool quad = !getenv("SGL_TILED_NO_QUAD3") && !getenv("SGL_TILED_NO_QUAD");
-    const int parts = quad ? (k <= 96 ? 3 : 4) : (k + 63) / 64;
+    const int parts = quad ? (k <= 96 ? 3 : (k + 31) / 32) : (k + 63) / 64;
     return ((k + parts - 1) / parts + 1) & ~1;
 }

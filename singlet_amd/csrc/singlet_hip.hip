@@ -11,7 +11,6 @@
 #include <string>
 #include <chrono>
 #include <mutex>
-#include <thread>
 #include <vector>
 #include <stdlib.h>
 
@@ -289,80 +288,12 @@ static int do_allreduce(sgl_ctx* c, double* dev_ptr, int64_t count) {
 }
 
 // ----------------------------------------------------------------- upload ---
-// Host -> device copy of a large slot.  Default: one hipMemcpyAsync from the caller's (pageable) memory -- the runtime pins the
-// pages in place and DMAs from them.  SGL_UPLOAD_STAGED=T (T = 2 .. 16 host threads): the slot is cut into T contiguous parts, each
-// moved by its own thread through two pinned 8 MB buffers on its own stream (memcpy into one buffer while the other is in
-// flight) -- for hosts whose in-place pinning is slow.  Which one is faster on the test box: profiles/r6_one_shot_*.json.
-struct StagePool {
-    std::mutex mu;
-    std::vector<void*> free_bufs;
-    static constexpr size_t BUF = (size_t)8 << 20;
-    void* take() {
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            if (!free_bufs.empty()) { void* b = free_bufs.back(); free_bufs.pop_back(); return b; }
-        }
-        void* b = nullptr;
-        if (hipHostMalloc(&b, BUF, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-        return b;
-    }
-    void give(void* b) { std::lock_guard<std::mutex> lk(mu); free_bufs.push_back(b); }
-    void release() {
-        std::lock_guard<std::mutex> lk(mu);
-        for (void* b : free_bufs) (void)hipHostFree(b);
-        free_bufs.clear();
-    }
-};
-static StagePool g_stage;
-
-static int h2d_staged(sgl_ctx* c, char* dst, const char* src, size_t bytes, int T) {
-    std::vector<int> rcs((size_t)T, SGL_OK);
-    std::vector<std::thread> th;
-    const size_t part = ((bytes + (size_t)T - 1) / (size_t)T + 4095) & ~(size_t)4095;
-    auto work = [&](int t) {
-        const size_t lo = std::min(bytes, part * (size_t)t), hi = std::min(bytes, lo + part);
-        if (lo >= hi) return;
-        if (hipSetDevice(c->device) != hipSuccess) { rcs[(size_t)t] = SGL_EHIP; return; }
-        hipStream_t st = nullptr;
-        hipEvent_t ev[2] = {nullptr, nullptr};
-        void* pin[2] = {g_stage.take(), g_stage.take()};
-        bool ok = pin[0] && pin[1] && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess &&
-                  hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) == hipSuccess;
-        size_t q = 0;
-        for (size_t off = lo; ok && off < hi; off += StagePool::BUF, ++q) {
-            const size_t n = std::min(StagePool::BUF, hi - off);
-            const int b = (int)(q & 1);
-            if (q >= 2) ok = hipEventSynchronize(ev[b]) == hipSuccess;
-            if (!ok) break;
-            memcpy(pin[b], src + off, n);
-            ok = hipMemcpyAsync(dst + off, pin[b], n, hipMemcpyHostToDevice, st) == hipSuccess && hipEventRecord(ev[b], st) == hipSuccess;
-        }
-        if (st && hipStreamSynchronize(st) != hipSuccess) ok = false;
-        for (auto e : ev) if (e) (void)hipEventDestroy(e);
-        if (st) (void)hipStreamDestroy(st);
-        for (void* b : pin) if (b) g_stage.give(b);
-        if (!ok) { (void)hipGetLastError(); rcs[(size_t)t] = SGL_EHIP; }
-    };
-    try {
-        for (int t = 1; t < T; ++t) th.emplace_back(work, t);
-    } catch (...) {
-        for (auto& x : th) x.join();
-        sgl_set_error("upload: could not start the staging threads");
-        return SGL_ENOMEM;
-    }
-    work(0);
-    for (auto& x : th) x.join();
-    (void)hipSetDevice(c->device);
-    for (int rc : rcs)
-        if (rc != SGL_OK) { sgl_set_error("upload: a staged host -> device copy failed"); return rc; }
-    return SGL_OK;
-}
-
+// Host -> device copy of a large slot: one hipMemcpyAsync from the caller's (pageable) memory -- the runtime pins the pages in
+// place and DMAs from them at the link's rate (config 3: 18.0 GB in 0.319 s = 56.5 GB/s on the first touch of the pages,
+// profiles/r6_one_shot_config3.json).  A staged copy (8 host threads, each through two pinned 8 MB buffers on its own stream) was
+// built and measured SLOWER -- 39.5 - 49.6 GB/s at config 3, 4.6 - 7.8 GB/s on config 2's 0.6 GB -- and taken out again (round 6).
 static int sgl_h2d(sgl_ctx* c, void* dst, const void* src, size_t bytes) {
     if (bytes == 0) return SGL_OK;
-    const char* e = getenv("SGL_UPLOAD_STAGED");
-    const int T = e ? std::max(0, std::min(16, atoi(e))) : 0;
-    if (T >= 2 && bytes >= ((size_t)64 << 20)) return h2d_staged(c, static_cast<char*>(dst), static_cast<const char*>(src), bytes, T);
     HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
     return SGL_OK;
 }
@@ -1335,7 +1266,6 @@ struct AcquiredCtx {   // destroys a non-cached context on scope exit; serialise
 extern "C" int sgl_cache_release(void) {
     std::lock_guard<std::mutex> lk(g_cache_mu);
     if (g_cache.c) { sgl_destroy(g_cache.c); g_cache = CachedCtx(); }
-    g_stage.release();   // the pinned staging buffers of SGL_UPLOAD_STAGED
     return SGL_OK;
 }
 

@@ -146,7 +146,7 @@ def test_rhs_both_orientations(ctx, ora, sa, k):
     assert rel_fro(ctx.op_rhs(1, H), ora.rhs(At, H)) < 1e-14
 
 
-@pytest.mark.parametrize("k", [1, 2, 7, 10, 16, 30, 31, 32, 33, 50, 64, 65, 70, 100, 127, 128])
+@pytest.mark.parametrize("k", [1, 2, 7, 10, 16, 30, 31, 32, 33, 50, 64, 65, 70, 100, 127, 128, 129, 150, 200, 257, 600])
 def test_rhs_tiled_kernel_all_ranks(ctx, ora, sa, k, monkeypatch):
     """The LDS-tiled accumulate (which = 2 / 3): four columns per LDS instruction up to k = 32 (256-byte tile rows),
     two up to k = 64, three / four quad passes over factor parts for 64 < k <= 128 (strided factor rows and outputs), odd ranks
