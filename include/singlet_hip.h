@@ -491,6 +491,13 @@ SGL_API int sgl_mask_pairs(sgl_ctx* ctx, int64_t* out2);
  * (At = NULL), [3] sgl_fit_init (entry streams, w), [4] the ALS loop, [5] factors back to the host, [6] bytes copied in,
  * [7] 1.0 when SINGLET_HIP_CACHE served the resident matrix of the previous call (nothing uploaded), [8] the whole call. */
 SGL_API int sgl_call_times_get(double* out, int32_t n);
+/* Device memory the library keeps for reuse (round 6): blocks of 64 MB and more that a context frees -- the matrix slots, the
+ * entry streams, the factors of a one-shot call -- are cached per device and serve the next request they fit instead of going
+ * back to the driver, whose hipMalloc right after such a free takes seconds (3 s for config 3's 22 GB streams: as long as the
+ * fit; R's ard_nmf makes tens of such calls, R/ard_nmf.R:95-160).  *cached_bytes = bytes cached on the current device.  They
+ * stay reserved by the process until sgl_cache_release(); SGL_POOL=0 in the environment switches the caching off,
+ * SGL_POOL_MAX_GB caps it (default: 70 % of the device memory). */
+SGL_API int sgl_pool_info(int64_t* cached_bytes);
 
 #ifdef __cplusplus
 }

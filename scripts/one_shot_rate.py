@@ -2,13 +2,14 @@
 """What an R caller sees: the ONE-SHOT call c_nmf(A, At = NULL, ...) -- host dgCMatrix slots in, host factors out -- at the
 benchmark's shapes, next to the resident loop bench.py times (R/run_nmf.R:39-59 -> .Call(_singlet_c_nmf), src/RcppExports.cpp:98-116).
 
-  python scripts/one_shot_rate.py [--genes 30000 --cells 1000000 --k 50 --maxit 100 --tol 1e-5] [--staged T]
+  python scripts/one_shot_rate.py [--genes 30000 --cells 1000000 --k 50 --maxit 100 --tol 1e-5]
 
 The host matrix is the benchmark's synthetic matrix: generated on the device by the library's own generator and downloaded into
 ordinary (pageable) numpy arrays, as R's slots are.  Three calls: (1) the one-shot call (upload, validation, device transpose,
 entry streams, iterations, factors back), with the library's own wall-clock split (sgl_call_times_get); (2) the same call again
 (a second fit on the same matrix: everything is paid again); (3) twice with SINGLET_HIP_CACHE=1: the second of those finds the
-matrix resident.  One JSON line."""
+matrix resident.  One JSON line.  (profiles/r6_one_shot_config{2,3}.json were taken at commit 8c7f0bf with an A/B leg, SGL_UPLOAD_STAGED=8:
+a staged copy through pinned buffers, measured slower than the runtime's in-place pinning and removed from the library.)"""
 import argparse
 import json
 import os
@@ -29,7 +30,6 @@ def main():
     ap.add_argument("--maxit", type=int, default=100)
     ap.add_argument("--tol", type=float, default=1e-5)
     ap.add_argument("--L1", type=float, default=0.01)
-    ap.add_argument("--staged", type=int, default=None, help="SGL_UPLOAD_STAGED for the A/B leg (host threads of the staged copy)")
     a = ap.parse_args()
 
     t0 = time.perf_counter()
@@ -57,15 +57,10 @@ def main():
                      % (a.genes, a.cells, A.nnz, a.k, a.tol, a.maxit, a.L1),
            "host_bytes_in": int(host_bytes), "host_generate_s": gen_s, "calls": []}
     os.environ.pop("SINGLET_HIP_CACHE", None)
-    os.environ.pop("SGL_UPLOAD_STAGED", None)
     sa.c_nmf(sa.dgCMatrix(A.x[:A.p[64]], A.i[:A.p[64]], A.p[:65], (a.genes, 64)), None, 0.0, 1, False, a.L1, a.L1, 0.0, 0.0, 0, w0.T)  # code objects
     out["calls"].append(one_call("one-shot, first call on this matrix (pages never pinned)"))
     out["calls"].append(one_call("one-shot, second call (everything paid again)"))
-    if a.staged:
-        os.environ["SGL_UPLOAD_STAGED"] = str(a.staged)
-        out["calls"].append(one_call("one-shot, SGL_UPLOAD_STAGED=%d" % a.staged))
-        out["calls"].append(one_call("one-shot, SGL_UPLOAD_STAGED=%d, again" % a.staged))
-        os.environ.pop("SGL_UPLOAD_STAGED", None)
+    out["calls"].append(one_call("one-shot, third call"))
     os.environ["SINGLET_HIP_CACHE"] = "1"
     out["calls"].append(one_call("SINGLET_HIP_CACHE=1, fills the cache"))
     out["calls"].append(one_call("SINGLET_HIP_CACHE=1, matrix resident from the previous call"))

@@ -136,6 +136,7 @@ SIGNATURES = {
     "sgl_layout_builds": (C.c_int, [C.c_void_p, i64p]),
     "sgl_mask_pairs": (C.c_int, [C.c_void_p, i64p]),
     "sgl_call_times_get": (C.c_int, [f64p, C.c_int32]),
+    "sgl_pool_info": (C.c_int, [i64p]),
 }
 
 _lib = None

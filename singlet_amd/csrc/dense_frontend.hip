@@ -137,7 +137,7 @@ void sgl_dense_release(sgl_ctx* c) {
         if (R) (void)R->destroy_handle((rb_handle)c->rocblas);
         c->rocblas = nullptr;
     }
-    if (c->Adense) (void)hipFree(c->Adense);
+    if (c->Adense) (void)sgl_pool_free(c->Adense);
     c->Adense = nullptr;
     c->dense_gemm = false;
 }

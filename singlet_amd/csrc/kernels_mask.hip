@@ -760,12 +760,12 @@ int k_mse_test(sgl_ctx* c, const double* Wd, const double* H, int k, uint64_t se
     if (lists && !Lw.val_ok && !Lw.val_refused && !getenv("SGL_MSE_NO_VALS")) {
         const size_t want = (size_t)Lw.total + 64;
         if (Lw.cap_val < want) {
-            if (Lw.val) (void)hipFree(Lw.val);
+            if (Lw.val) (void)sgl_pool_free(Lw.val);
             Lw.val = nullptr; Lw.cap_val = 0;
             size_t free_b = 0, total_b = 0;
-            HIPCHK(hipMemGetInfo(&free_b, &total_b));
+            HIPCHK(sgl_pool_mem_info(&free_b, &total_b));
             const size_t cap = (size_t)((double)Lw.total * 1.02) + 1024;
-            if (8.0 * (double)cap > 0.2 * (double)free_b || hipMalloc(&Lw.val, sizeof(double) * cap) != hipSuccess) {
+            if (8.0 * (double)cap > 0.2 * (double)free_b || sgl_pool_malloc(&Lw.val, sizeof(double) * cap) != hipSuccess) {
                 (void)hipGetLastError();
                 Lw.val = nullptr;
                 Lw.val_refused = true;

@@ -160,7 +160,7 @@ template <typename T_>
 static int t_alloc(T_** p, size_t count) {
     *p = nullptr;
     if (count == 0) count = 1;
-    hipError_t e = hipMalloc((void**)p, count * sizeof(T_));
+    hipError_t e = sgl_pool_malloc((void**)p, count * sizeof(T_));
     if (e != hipSuccess) {
         (void)hipGetLastError();
         sgl_set_error("hipMalloc of %zu bytes failed: %s", count * sizeof(T_), hipGetErrorString(e));
@@ -174,7 +174,7 @@ static int t_alloc(T_** p, size_t count) {
 template <typename T_>
 static int t_reserve(T_** p, size_t* cap, size_t count) {
     if (*p != nullptr && *cap >= count) return SGL_OK;
-    if (*p) (void)hipFree(*p);
+    if (*p) (void)sgl_pool_free(*p);
     *p = nullptr;
     *cap = 0;
     const size_t want = count + count / 32 + 64;
@@ -184,15 +184,15 @@ static int t_reserve(T_** p, size_t* cap, size_t count) {
 }
 
 void sgl_tiled_free(DevTiled& S) {
-    if (S.seg) (void)hipFree(S.seg);
-    if (S.perm) (void)hipFree(S.perm);
-    if (S.roff) (void)hipFree(S.roff);
-    if (S.x) (void)hipFree(S.x);
-    if (S.cstart) (void)hipFree(S.cstart);
-    if (S.cnt) (void)hipFree(S.cnt);
-    if (S.gtab) (void)hipFree(S.gtab);
-    if (S.part) (void)hipFree(S.part);
-    if (S.xm) (void)hipFree(S.xm);
+    if (S.seg) (void)sgl_pool_free(S.seg);
+    if (S.perm) (void)sgl_pool_free(S.perm);
+    if (S.roff) (void)sgl_pool_free(S.roff);
+    if (S.x) (void)sgl_pool_free(S.x);
+    if (S.cstart) (void)sgl_pool_free(S.cstart);
+    if (S.cnt) (void)sgl_pool_free(S.cnt);
+    if (S.gtab) (void)sgl_pool_free(S.gtab);
+    if (S.part) (void)sgl_pool_free(S.part);
+    if (S.xm) (void)sgl_pool_free(S.xm);
     S = DevTiled();
 }
 
@@ -225,7 +225,7 @@ static int tiled_build_perm(sgl_ctx* c, const DevCSC& M, DevTiled& S) {
         tiled_col_keys_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(M.p, n, keys, iota);
         size_t tmp_bytes = 0;
         if (hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tmp_bytes, keys, keys_out, iota, S.perm, n, 0, 32, s) != hipSuccess) rc = SGL_EHIP;
-        if (rc == SGL_OK && hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 1) != hipSuccess) { (void)hipGetLastError(); rc = SGL_ENOMEM; }
+        if (rc == SGL_OK && sgl_pool_malloc(&tmp, tmp_bytes ? tmp_bytes : 1) != hipSuccess) { (void)hipGetLastError(); rc = SGL_ENOMEM; }
         if (rc == SGL_OK && hipcub::DeviceRadixSort::SortPairsDescending(tmp, tmp_bytes, keys, keys_out, iota, S.perm, n, 0, 32, s) != hipSuccess) rc = SGL_EHIP;
     }
     // share of the non-zeros held by the heaviest workgroup's columns (the first 8 x 64 of the order): the tile-range
@@ -245,15 +245,17 @@ static int tiled_build_perm(sgl_ctx* c, const DevCSC& M, DevTiled& S) {
         S.top_share = M.nnz > 0 ? (double)tn / (double)M.nnz : 0.0;
         S.top_share4 = M.nnz > 0 ? (double)tn2 / (double)M.nnz : 0.0;
     }
-    if (keys) (void)hipFree(keys);
-    if (keys_out) (void)hipFree(keys_out);
-    if (iota) (void)hipFree(iota);
-    if (tmp) (void)hipFree(tmp);
+    if (keys) (void)sgl_pool_free(keys);
+    if (keys_out) (void)sgl_pool_free(keys_out);
+    if (iota) (void)sgl_pool_free(iota);
+    if (tmp) (void)sgl_pool_free(tmp);
     if (rc == SGL_OK && e != hipSuccess) rc = SGL_EHIP;
     if (rc != SGL_OK) { sgl_set_error("tiled build: sorting the columns by their non-zero count failed"); return rc; }
     S.perm_nnz = M.nnz;
     return SGL_OK;
 }
+
+void sgl_trace_setup(const char* what);   // singlet_hip.hip (SGL_TRACE_SETUP=1)
 
 int sgl_tiled_build(sgl_ctx* c, const DevCSC& M, int k, DevTiled& S) {
     hipStream_t s = c->stream;
@@ -298,12 +300,14 @@ int sgl_tiled_build(sgl_ctx* c, const DevCSC& M, int k, DevTiled& S) {
     // only, so a rank sweep computes it once
     int rc = SGL_OK;
     if (!tiled_sort_columns()) {
-        if (S.perm) { (void)hipFree(S.perm); S.perm = nullptr; S.cap_perm = 0; }
+        if (S.perm) { (void)sgl_pool_free(S.perm); S.perm = nullptr; S.cap_perm = 0; }
     } else if (!S.perm || S.perm_nnz != M.nnz || S.cap_perm < (size_t)M.ncol) {
         rc = tiled_build_perm(c, M, S);
     }
+    sgl_trace_setup("  stream: column order");
     // segment starts per (tile, column); kept for the masked value array
     if (rc == SGL_OK) rc = t_reserve(&S.seg, &S.cap_seg, (size_t)(S.T + 1) * (size_t)M.ncol);
+    sgl_trace_setup("  stream: segment buffer reserved");
     DevCSC tmp = M;
     tmp.tile_rows = TR;
     tmp.ntiles = S.T;
@@ -326,9 +330,11 @@ int sgl_tiled_build(sgl_ctx* c, const DevCSC& M, int k, DevTiled& S) {
             hipStreamSynchronize(s) != hipSuccess) { sgl_set_error("tiled build: reading the stream size failed"); rc = SGL_EHIP; }
     }
     S.E = E;
+    sgl_trace_setup("  stream: segments, counts, scan");
     // + TILED_SLACK entries of slack: the kernel prefetches its ring (four or eight 64-entry sets) past the end
     if (rc == SGL_OK) rc = t_reserve(&S.roff, &S.cap_roff, (size_t)E + TILED_SLACK);
     if (rc == SGL_OK) rc = t_reserve(&S.x, &S.cap_x, (size_t)E + TILED_SLACK);
+    sgl_trace_setup("  stream: roff / x buffers reserved");
     if (rc == SGL_OK) {
         if (hipMemsetAsync(S.roff + E, 0, TILED_SLACK * sizeof(uint32_t), s) != hipSuccess ||
             hipMemsetAsync(S.x + E, 0, TILED_SLACK * sizeof(double), s) != hipSuccess) { sgl_set_error("tiled build: clearing the stream slack failed"); rc = SGL_EHIP; }
@@ -444,7 +450,7 @@ int sgl_tiled_build(sgl_ctx* c, const DevCSC& M, int k, DevTiled& S) {
     if (rc == SGL_OK && S.tail_R > 1)
         rc = t_reserve(&S.part, &S.cap_part, (size_t)S.tail_R * (size_t)k * (size_t)((nwg_x - S.tail_wg0) * TILED_NW * S.CW));
     hipError_t e = hipStreamSynchronize(s);
-    if (chunk_entries) (void)hipFree(chunk_entries);
+    if (chunk_entries) (void)sgl_pool_free(chunk_entries);
     if (rc == SGL_OK && e != hipSuccess) { sgl_set_error("tiled build failed: %s", hipGetErrorString(e)); rc = SGL_EHIP; }
     if (rc != SGL_OK) { sgl_tiled_free(S); return rc; }
     S.built = true;

@@ -38,7 +38,7 @@ template <typename T>
 static int talloc(T** p, size_t count) {
     *p = nullptr;
     if (count == 0) count = 1;
-    hipError_t e = hipMalloc((void**)p, count * sizeof(T));
+    hipError_t e = sgl_pool_malloc((void**)p, count * sizeof(T));
     if (e != hipSuccess) {
         (void)hipGetLastError();
         sgl_set_error("hipMalloc of %zu bytes failed: %s", count * sizeof(T), hipGetErrorString(e));
@@ -85,7 +85,7 @@ int sgl_device_transpose(sgl_ctx* c) {
             while (((int64_t)1 << end_bit) < (int64_t)A.nrow && end_bit < 31) ++end_bit;
             size_t tmp_bytes = 0;
             if (hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, A.i, keys_out, iota, perm, nnz, 0, end_bit, s) != hipSuccess) { rc = SGL_EHIP; break; }
-            if (hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 1) != hipSuccess) { (void)hipGetLastError(); sgl_set_error("transpose: temp alloc failed"); rc = SGL_ENOMEM; break; }
+            if (sgl_pool_malloc(&tmp, tmp_bytes ? tmp_bytes : 1) != hipSuccess) { (void)hipGetLastError(); sgl_set_error("transpose: temp alloc failed"); rc = SGL_ENOMEM; break; }
             if (hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, A.i, keys_out, iota, perm, nnz, 0, end_bit, s) != hipSuccess) { rc = SGL_EHIP; break; }
             int64_t blocks = std::min<int64_t>((nnz + 255) / 256, 256 * 32);
             gather_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(perm, nnz, colof, A.x, T.i, T.x);
@@ -94,11 +94,11 @@ int sgl_device_transpose(sgl_ctx* c) {
     } while (0);
     hipError_t e = hipStreamSynchronize(s);
     if (rc == SGL_EHIP || e != hipSuccess) { sgl_set_error("device transpose failed: %s", hipGetErrorString(e)); rc = SGL_EHIP; }
-    if (counts) (void)hipFree(counts);
-    if (colof) (void)hipFree(colof);
-    if (keys_out) (void)hipFree(keys_out);
-    if (iota) (void)hipFree(iota);
-    if (perm) (void)hipFree(perm);
-    if (tmp) (void)hipFree(tmp);
+    if (counts) (void)sgl_pool_free(counts);
+    if (colof) (void)sgl_pool_free(colof);
+    if (keys_out) (void)sgl_pool_free(keys_out);
+    if (iota) (void)sgl_pool_free(iota);
+    if (perm) (void)sgl_pool_free(perm);
+    if (tmp) (void)sgl_pool_free(tmp);
     return rc;
 }

@@ -591,7 +591,7 @@ static int team_gene_counts(sgl_team* T) {
         HIPCHK(hipSetDevice(c->device));
         const int64_t m = c->A.nrow;
         if (!c->col_nnz_At_global) {
-            hipError_t e = hipMalloc((void**)&c->col_nnz_At_global, sizeof(int64_t) * (size_t)std::max<int64_t>(m, 1));
+            hipError_t e = sgl_pool_malloc((void**)&c->col_nnz_At_global, sizeof(int64_t) * (size_t)std::max<int64_t>(m, 1));
             if (e != hipSuccess) { (void)hipGetLastError(); sgl_set_error("team: out of device memory"); return SGL_ENOMEM; }
         }
         HIPCHK(hipMemcpyAsync(c->col_nnz_At_global, c->col_nnz_At, sizeof(int64_t) * (size_t)m, hipMemcpyDeviceToDevice, c->stream));
@@ -775,7 +775,7 @@ static int team_mask_workspace(sgl_team* T) {
         SGLCHK(sgl_mask_workspace(c));
         if (N > 1 && !c->Sbuf) {
             const int64_t mb = (T->nrow + N - 1) / N;
-            hipError_t e = hipMalloc((void**)&c->Sbuf, sizeof(double) * (size_t)mb * N * c->k * c->k);
+            hipError_t e = sgl_pool_malloc((void**)&c->Sbuf, sizeof(double) * (size_t)mb * N * c->k * c->k);
             if (e != hipSuccess) { (void)hipGetLastError(); sgl_set_error("team: out of device memory for the per-gene downdates"); return SGL_ENOMEM; }
         }
     }

@@ -16,6 +16,15 @@
 
 void sgl_set_error(const char* fmt, ...);
 
+// device-memory pool (pool.hip): every allocation of the library goes through these; blocks >= 64 MB are cached on free
+hipError_t sgl_pool_malloc_raw(void** p, size_t bytes);
+template <typename T_>
+inline hipError_t sgl_pool_malloc(T_** p, size_t bytes) { return sgl_pool_malloc_raw(reinterpret_cast<void**>(p), bytes); }
+hipError_t sgl_pool_free(void* p);
+hipError_t sgl_pool_mem_info(size_t* free_b, size_t* total_b);
+void sgl_pool_release(void);
+size_t sgl_pool_cached_bytes(void);
+
 #define HIPCHK(expr)                                                                                   \
     do {                                                                                               \
         hipError_t e__ = (expr);                                                                       \

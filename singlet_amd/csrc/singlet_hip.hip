@@ -38,6 +38,15 @@ static thread_local CallTimes g_times;
 static double wall_now() {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
+// SGL_TRACE_SETUP=1: wall-clock deltas of the set-up steps on stderr (where a one-shot call's seconds go: allocator, stream build)
+void sgl_trace_setup(const char* what) {
+    static const bool on = getenv("SGL_TRACE_SETUP") != nullptr;
+    if (!on) return;
+    static thread_local double last = 0.0;
+    const double t = wall_now();
+    if (what) fprintf(stderr, "[sgl setup] %-34s %8.3f ms\n", what, last > 0.0 ? (t - last) * 1e3 : 0.0);
+    last = t;
+}
 extern "C" int sgl_call_times_get(double* out, int32_t n) {
     if (!out || n < 0) { sgl_set_error("sgl_call_times_get: bad arguments"); return SGL_EINVAL; }
     const double v[10] = {g_times.h2d_s, g_times.validate_s, g_times.transpose_s, g_times.fit_init_s, g_times.iterate_s, g_times.d2h_s,
@@ -65,7 +74,7 @@ template <typename T>
 static int dev_alloc(T** p, size_t count) {
     *p = nullptr;
     if (count == 0) count = 1;
-    hipError_t e = hipMalloc((void**)p, count * sizeof(T));
+    hipError_t e = sgl_pool_malloc((void**)p, count * sizeof(T));
     if (e != hipSuccess) {
         (void)hipGetLastError();
         sgl_set_error("hipMalloc of %zu bytes failed: %s", count * sizeof(T), hipGetErrorString(e));
@@ -76,7 +85,7 @@ static int dev_alloc(T** p, size_t count) {
 
 template <typename T>
 static void dev_free(T*& p) {
-    if (p) (void)hipFree(p);
+    if (p) (void)sgl_pool_free(p);
     p = nullptr;
 }
 
@@ -548,7 +557,7 @@ extern "C" int sgl_synth_csc_skewed(sgl_ctx* c, uint64_t S, uint64_t inv_density
         SGLCHK(dev_alloc(&skew, 32));
         HIPCHK(hipMemcpy(skew, tab, sizeof(tab), hipMemcpyHostToDevice));
     }
-    struct SkewFree { double* p; ~SkewFree() { if (p) (void)hipFree(p); } } skew_free{skew};
+    struct SkewFree { double* p; ~SkewFree() { if (p) (void)sgl_pool_free(p); } } skew_free{skew};
     free_fit(c);
     free_matrix(c);
     c->cell_offset = cell_offset;
@@ -707,6 +716,7 @@ static int fit_init_impl(sgl_ctx* c, int32_t k, const double* w_init, uint64_t s
     const int64_t m = c->A.nrow, n = c->A.ncol;
     // buffers exchanged by reduce-scatter / all-gather hold team_size equal gene blocks
     const int64_t mpad = team_gene_block(c) * std::max(1, sgl_team_size(c));
+    sgl_trace_setup(nullptr);
     SGLCHK(dev_alloc(&c->W, (size_t)k * mpad + 2));
     SGLCHK(dev_alloc(&c->Wprev, (size_t)k * m));
     SGLCHK(dev_alloc(&c->H, (size_t)k * n + 2));
@@ -720,6 +730,7 @@ static int fit_init_impl(sgl_ctx* c, int32_t k, const double* w_init, uint64_t s
         if (k <= SGL_LANE_NNLS_MAX_K) SGLCHK(nnls_scratch_alloc(c->nnls_scr, cap, k));
         if (k <= SGL_LANE_NNLS_MAX_K && c->A.ncol >= 65536) SGLCHK(nnls_pack_alloc(c->nnls_scr, c->A.ncol));   // sweep-count packing of the H-side solve (lane kernels; above k = 64 the generated two-lane solve)
     }
+    sgl_trace_setup("fit: factor buffers allocated");
     HIPCHK(hipMemsetAsync(c->W, 0, sizeof(double) * ((size_t)k * mpad + 2), c->stream));
     HIPCHK(hipMemsetAsync(c->red, 0, sizeof(double) * ((size_t)k * mpad + (size_t)k * k + (size_t)k), c->stream));
     if (w_init) HIPCHK(hipMemcpyAsync(c->W, w_init, sizeof(double) * (size_t)k * m, hipMemcpyHostToDevice, c->stream));
@@ -728,13 +739,17 @@ static int fit_init_impl(sgl_ctx* c, int32_t k, const double* w_init, uint64_t s
     std::vector<double> ones((size_t)k, 1.0);
     HIPCHK(hipMemcpyAsync(c->d, ones.data(), sizeof(double) * k, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));  // `ones` leaves scope
+    sgl_trace_setup("fit: factors initialised");
     SGLCHK(build_tiles(c, c->A, k));
     SGLCHK(build_tiles(c, c->At, k));
+    sgl_trace_setup("fit: build_tiles");
     // LDS-tiled accumulate (lanes over the factor rows): k <= 128
     c->use_tiled = false;
     if (tiled_part_size(k) > 0 && !getenv("SGL_NO_TILED")) {  // ranks above 64 run as two passes of k / 2 factor rows
         SGLCHK(sgl_tiled_build(c, c->A, tiled_part_size(k), c->TA));
+        sgl_trace_setup("fit: entry stream of A done");
         if (c->At.nnz > 0) SGLCHK(sgl_tiled_build(c, c->At, tiled_part_size(k), c->TAt));
+        sgl_trace_setup("fit: entry stream of At done");
         c->use_tiled = true;
     } else {  // no tiled path at this rank: do not sit on tens of GB of stale streams
         sgl_tiled_free(c->TA);
@@ -987,7 +1002,7 @@ int sgl_mask_workspace(sgl_ctx* c) {
         // quarters of the wave slots empty (nnls_h 196 -> 102 ms per 200 000 cells at 4 GB, 99 ms unchunked).  An eighth
         // of the free memory, at least 256 MB, at most 16 GB; SGL_GCOLS_MB overrides (A/B tests).
         size_t free_b = 0, total_b = 0;
-        HIPCHK(hipMemGetInfo(&free_b, &total_b));
+        HIPCHK(sgl_pool_mem_info(&free_b, &total_b));
         const char* e = getenv("SGL_GCOLS_MB");
         const int64_t mb = (e && atoll(e) > 0) ? atoll(e) : std::min<int64_t>(16384, std::max<int64_t>(256, (int64_t)(free_b >> 23)));
         const int64_t chunk = std::max<int64_t>(256, std::min<int64_t>(widest, (mb << 20) / ((int64_t)k * k * 8)));
@@ -1266,6 +1281,14 @@ struct AcquiredCtx {   // destroys a non-cached context on scope exit; serialise
 extern "C" int sgl_cache_release(void) {
     std::lock_guard<std::mutex> lk(g_cache_mu);
     if (g_cache.c) { sgl_destroy(g_cache.c); g_cache = CachedCtx(); }
+    sgl_pool_release();   // the device blocks the library keeps between calls (pool.hip) go back to the driver
+    return SGL_OK;
+}
+
+// bytes of device memory the library holds for reuse on the current device (pool.hip); sgl_cache_release() returns them
+extern "C" int sgl_pool_info(int64_t* cached_bytes) {
+    if (!cached_bytes) { sgl_set_error("sgl_pool_info: NULL argument"); return SGL_EINVAL; }
+    *cached_bytes = (int64_t)sgl_pool_cached_bytes();
     return SGL_OK;
 }
 
@@ -1527,7 +1550,7 @@ extern "C" int sgl_rcpp_predict(const double* Ax, const int32_t* Ai, const int32
 template <typename T>
 struct DevBuf {
     T* p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
+    ~DevBuf() { if (p) (void)sgl_pool_free(p); }
     int alloc(size_t n) { return dev_alloc(&p, n); }
 };
 // finish an operator: synchronise the stream, map a pending HIP error

@@ -467,6 +467,31 @@ def test_nnls(ctx, ora, k, L1, L2):
     assert sweeps == esw
 
 
+@pytest.mark.parametrize("k", [129, 130, 144, 145, 160, 161, 176, 177, 192, 193, 208, 209, 224, 225, 240, 241, 255, 256])
+def test_nnls_ranks_129_to_256_four_columns_per_wave_match_the_oracle_and_the_wave_kernel(ctx, ora, k, monkeypatch):
+    """Round 6: ranks 129 - 256 solve four columns per wave (nnls_quad_global_kernel<9 .. 16> against the shared Gram,
+    kernels_nnls_quad_big.hip) where they fell to the wave-per-column kernel: every instance at both ends of its rank range, a
+    ragged column count (a partial quad), skipped columns; the oracle's nnls (src/singlet.cpp:229-250) with equal sweep totals, and
+    the bits of the wave kernel."""
+    rng = np.random.default_rng(1000 + k)
+    ncols = 203
+    F = rng.random((3 * k + 5, k))
+    G = ora.aat(F)
+    B = rng.normal(size=(ncols, k)) * 3 + 1.0
+    X0 = np.abs(rng.normal(size=(ncols, k))) * (rng.random((ncols, k)) < 0.5) * 1e-3
+    monkeypatch.delenv("SGL_NNLS_NO_QUAD_BIG", raising=False)
+    X, sweeps = ctx.op_nnls(G, B, X0, 0.01, 0.02)
+    esw = 0
+    E = np.empty_like(X0)
+    for c in range(0, ncols):
+        E[c], _, it = ora.nnls(G, B[c], X0[c], 0.01, 0.02)
+        esw += it
+    assert rel_fro(X, E) < 1e-10 and np.array_equal(X == 0, E == 0) and sweeps == esw
+    monkeypatch.setenv("SGL_NNLS_NO_QUAD_BIG", "1")
+    Xw, sw = ctx.op_nnls(G, B, X0, 0.01, 0.02)
+    assert np.array_equal(Xw, X) and sw == sweeps
+
+
 @pytest.mark.parametrize("k", [7, 12, 50, 66, 72, 97, 104, 120])
 def test_nnls_repack_passes_are_bit_identical(ctx, k, monkeypatch):
     """The multi-pass lane kernel (stragglers re-packed between passes, nnls_lane.h) must give
