@@ -36,6 +36,6 @@ for (kern, gy), v in f.items():
 json.dump({"workload": {"genes": 30000, "cells": 1000000, "k": 50, "inv_density": 20},
            "layout": layouts,
            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python3 bench.py --steps 2 --warmup 1 "
-                     "--no-cpu-baseline`, scripts/prof_r4.sh; per launch of acc_tiled_kernel, averaged over its dispatches",
+                     "--no-cpu-baseline`, scripts/prof_r6.sh; per launch of acc_tiled_kernel, averaged over its dispatches",
            "bytes_per_launch": res}, open(out, "w"), indent=1)
 print(open(out).read())

@@ -52,6 +52,11 @@ __global__ __launch_bounds__(1024) void kern(double* out, int iters, double xin)
                 asm volatile("v_fma_f64 %0, %8, %9, %0\n v_fma_f64 %1, %8, %9, %1\n v_fma_f64 %2, %8, %9, %2\n v_fma_f64 %3, %8, %9, %3\n"
                              "v_fma_f64 %4, %8, %9, %4\n v_fma_f64 %5, %8, %9, %5\n v_fma_f64 %6, %8, %9, %6\n v_fma_f64 %7, %8, %9, %7"
                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(x), "v"(w));
+            } else if (MODE == 8) {  // round 6: v_cvt_f64_f32 (what an f32 copy of the factor in LDS would cost per factor)
+                float f = (float)w;
+                asm volatile("v_cvt_f64_f32 %0, %8\n v_cvt_f64_f32 %1, %8\n v_cvt_f64_f32 %2, %8\n v_cvt_f64_f32 %3, %8\n"
+                             "v_cvt_f64_f32 %4, %8\n v_cvt_f64_f32 %5, %8\n v_cvt_f64_f32 %6, %8\n v_cvt_f64_f32 %7, %8"
+                             : "=v"(a0), "=v"(a1), "=v"(a2), "=v"(a3), "=v"(a4), "=v"(a5), "=v"(a6), "=v"(a7) : "v"(f));
             } else if (MODE == 7) {  // v_readlane pairs
                 unsigned s0, s1, s2, s3;
                 asm volatile("v_readlane_b32 %0, %4, 3\n v_readlane_b32 %1, %5, 5\n v_readlane_b32 %2, %6, 7\n v_readlane_b32 %3, %7, 9\n"
@@ -89,6 +94,7 @@ int main() {
         run<2>("v_add_u32_dpp", th, 32);
         run<4>("v_permlane16_swap", th, 32);
         run<7>("v_readlane_b32", th, 16);
+        run<8>("v_cvt_f64_f32", th, 32);
     }
     return 0;
 }

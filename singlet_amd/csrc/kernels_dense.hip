@@ -264,11 +264,14 @@ static int sgl_partial_sum(sgl_ctx* c, int nblocks, int n, int diag_k, double di
     return SGL_OK;
 }
 
+int k_gram_big_partials(hipStream_t s, const double* F, int k, int64_t cols, int64_t cols_per_block, int nblocks, double* part);   // kernels_gram_big.hip
+
 int k_gram(sgl_ctx* c, const double* F, int k, int64_t cols, double* G, double diag_add) {
     if (k <= 0 || k > SGL_MAX_K) { sgl_set_error("k_gram: k=%d out of range", k); return SGL_EINVAL; }
     int nblocks = (int)((cols + 255) / 256);        // (at least 16 columns per block; fills the chip from ~65 000 columns on)
     if (nblocks > 1024) nblocks = 1024;
-    if (k > 128 && nblocks > 128) nblocks = 128;   // generic path: k x k doubles of workspace per block
+    const bool big_mfma = k > 128 && k <= 256 && !getenv("SGL_GRAM_BIG_VALU");   // ranks 129 - 256 on the matrix cores (kernels_gram_big.hip)
+    if (k > 128 && nblocks > (big_mfma ? 512 : 128)) nblocks = big_mfma ? 512 : 128;   // k x k doubles of workspace per block
     if (nblocks < 1) nblocks = 1;
     int64_t cpb = (cols + nblocks - 1) / nblocks;
     cpb = (cpb + 15) / 16 * 16;  // whole 16-column steps per block
@@ -285,6 +288,7 @@ int k_gram(sgl_ctx* c, const double* F, int k, int64_t cols, double* G, double d
     else if (NT == 6) gram_mfma_split_kernel<6><<<dim3(nblocks), dim3(256), 0, s>>>(F, k, cols, cpb, c->ws);
     else if (NT == 7) gram_mfma_split_kernel<7><<<dim3(nblocks), dim3(256), 0, s>>>(F, k, cols, cpb, c->ws);
     else if (NT == 8) gram_mfma_split_kernel<8><<<dim3(nblocks), dim3(256), 0, s>>>(F, k, cols, cpb, c->ws);
+    else if (big_mfma) SGLCHK(k_gram_big_partials(s, F, k, cols, cpb, nblocks, c->ws));
     else {
         const size_t lds = sizeof(double) * 16 * (size_t)k;
         if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_valu_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));

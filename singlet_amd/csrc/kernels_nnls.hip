@@ -662,7 +662,10 @@ int k_nnls_percol(hipStream_t s, const double* G, int64_t gstride, const double*
     }
     // ranks 129 - 256, shared Gram or per-column Grams: four columns per wave, instances NR = 9 .. 16 (kernels_nnls_quad_big.hip;
     // SGL_NNLS_NO_QUAD_BIG=1: the wave kernel below -- A/B, bit-identity tests)
-    if (k > 128 && k <= 256 && !getenv("SGL_NNLS_NO_QUAD_GLOBAL") && !getenv("SGL_NNLS_NO_QUAD_BIG"))
+    // (measured at 30 000 x 200 000, profiles/r6_k_above_128.txt: nnls_h k = 130 78 -> 41 ms, 200 140 -> 75, 256 192 -> 110; the 30 000
+    //  columns of the W side gain up to k = 200 -- 8.8 -> 6.9 ms at k = 130 -- and lose above, where the instances spill: 20.1 -> 23.3
+    //  at k = 256: short launches keep the wave kernel above k = 208)
+    if (k > 128 && k <= 256 && (ncols >= long_launch || k <= 208) && !getenv("SGL_NNLS_NO_QUAD_GLOBAL") && !getenv("SGL_NNLS_NO_QUAD_BIG"))
         return k_nnls_quad_global_big(s, G, gstride, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
     int64_t blocks = (ncols + 3) / 4;
     if (blocks > 256 * 32) blocks = 256 * 32;

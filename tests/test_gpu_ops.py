@@ -117,7 +117,8 @@ def test_mask_gram_lists_short_columns(ctx, ora, nrow):
 
 
 @pytest.mark.parametrize("k,cols", [(1, 5), (8, 400), (16, 33), (30, 2000), (50, 777), (64, 300), (70, 129), (100, 50), (128, 300),
-                                    (129, 200), (300, 700), (520, 90)])
+                                    (129, 200), (144, 3), (160, 1000), (161, 517), (192, 64), (193, 4099), (224, 333), (225, 130), (256, 2050),
+                                    (257, 100), (300, 700), (520, 90)])
 def test_gram(ctx, ora, k, cols):
     F = np.random.default_rng(k * 1000 + cols).random((cols, k))
     G = ctx.op_gram(F)
@@ -480,6 +481,7 @@ def test_nnls_ranks_129_to_256_four_columns_per_wave_match_the_oracle_and_the_wa
     B = rng.normal(size=(ncols, k)) * 3 + 1.0
     X0 = np.abs(rng.normal(size=(ncols, k))) * (rng.random((ncols, k)) < 0.5) * 1e-3
     monkeypatch.delenv("SGL_NNLS_NO_QUAD_BIG", raising=False)
+    monkeypatch.setenv("SGL_NNLS_QUAD_GLOBAL_MIN_COLS", "1")      # (short launches above k = 208 keep the wave kernel: count as long)
     X, sweeps = ctx.op_nnls(G, B, X0, 0.01, 0.02)
     esw = 0
     E = np.empty_like(X0)
