@@ -417,3 +417,10 @@ void R_init_singlet_hip_shim(DllInfo* dll) {
     R_registerRoutines(dll, NULL, call_entries, NULL, NULL);
     R_useDynamicSymbols(dll, FALSE);
 }
+
+/* dyn.unload / library detach: the device blocks the library keeps between calls (its pool, and the resident matrix of
+ * SINGLET_HIP_CACHE=1) go back to the driver (include/singlet_hip.h: sgl_cache_release). */
+void R_unload_singlet_hip_shim(DllInfo* dll) {
+    (void)dll;
+    (void)sgl_cache_release();
+}
