@@ -320,7 +320,10 @@ def report(args, run):
                          "VALU instruction) and the round-4 ablations in profiles/README.md: 2.35 ns per entry tuple per CU for the loop "
                          "with either its FMAs or its LDS reads removed",
                "note": "the kernel is bound by LDS operand delivery and FP64 issue, which overlap incompletely at two waves per "
-                       "SIMD, not by HBM: the frac below cannot exceed hbm_floor_ms / loop_floor_ms with one LDS read per entry tuple"}
+                       "SIMD, not by HBM: the frac below cannot exceed hbm_floor_ms / loop_floor_ms with one LDS read per entry tuple.  "
+                       "CLOSED (round 6, DESIGN.md): three factors per lane (ranks 33 - 48) prices at 10.6 ms per pass against 10.2 -- an LDS "
+                       "read costs per instruction, ds_read_b64 as much as ds_read_b128 (profiles/r6_ubench_rates.txt) -- and an f32 copy of the "
+                       "operand in LDS at 10.6 ms too (a v_cvt_f64_f32 per factor at the FP64 issue rate)"}
     ceiling["max_frac_of_this_formulation"] = (ceiling["hbm_floor_ms"] / ceiling["loop_floor_ms"]) if tuples > 0 else None
     comm = run["comm"]
     default_shape = (args.genes, args.cells, args.k, args.inv_density) == (30000, 1000000, 50, 20)

@@ -615,6 +615,9 @@ static int launch_nnls_quad(hipStream_t s, const double* G, int64_t gstride, con
 int k_nnls_quad_global_big(hipStream_t s, const double* G, int64_t gstride, const double* B, double* X, const int64_t* col_nnz, int k,
                            int64_t ncols, double L1, double L2, unsigned long long* sweep_counter);   // kernels_nnls_quad_big.hip
 
+int k_nnls_quarter(hipStream_t s, const double* G, const double* B, double* X, const int64_t* col_nnz, int k, int64_t ncols, double L1, double L2,
+                   unsigned long long* sweep_counter);   // kernels_nnls_quarter.hip
+
 int k_nnls_percol(hipStream_t s, const double* G, int64_t gstride, const double* B, double* X, const int64_t* col_nnz,
                 int k, int64_t ncols, double L1, double L2, unsigned long long* sweep_counter) {
     if (ncols <= 0) return SGL_OK;
@@ -659,6 +662,15 @@ int k_nnls_percol(hipStream_t s, const double* G, int64_t gstride, const double*
             case 7: return launch_nnls_quad_global<7>(s, G, gstride, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
             default: return launch_nnls_quad_global<8>(s, G, gstride, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
         }
+    }
+    // ranks 129 - 256 against a SHARED Gram: four LANES per column, 16 columns per wave (kernels_nnls_quarter.hip) from 8192 columns
+    // on (SGL_NNLS_QUARTER_MIN_COLS; SGL_NNLS_NO_QUARTER=1: never -- A/B, bit-identity tests); shorter launches and per-column
+    // Grams take the four-columns-per-wave solve below
+    {
+        const char* qm = getenv("SGL_NNLS_QUARTER_MIN_COLS");
+        const int64_t quarter_min = (qm && atoll(qm) > 0) ? atoll(qm) : 8192;
+        if (gstride == 0 && k > 128 && k <= 256 && ncols >= quarter_min && !getenv("SGL_NNLS_NO_QUARTER"))
+            return k_nnls_quarter(s, G, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
     }
     // ranks 129 - 256, shared Gram or per-column Grams: four columns per wave, instances NR = 9 .. 16 (kernels_nnls_quad_big.hip;
     // SGL_NNLS_NO_QUAD_BIG=1: the wave kernel below -- A/B, bit-identity tests)

@@ -481,8 +481,9 @@ def test_nnls_ranks_129_to_256_four_columns_per_wave_match_the_oracle_and_the_wa
     B = rng.normal(size=(ncols, k)) * 3 + 1.0
     X0 = np.abs(rng.normal(size=(ncols, k))) * (rng.random((ncols, k)) < 0.5) * 1e-3
     monkeypatch.delenv("SGL_NNLS_NO_QUAD_BIG", raising=False)
+    monkeypatch.setenv("SGL_NNLS_NO_QUARTER", "1")
     monkeypatch.setenv("SGL_NNLS_QUAD_GLOBAL_MIN_COLS", "1")      # (short launches above k = 208 keep the wave kernel: count as long)
-    X, sweeps = ctx.op_nnls(G, B, X0, 0.01, 0.02)
+    X, sweeps = ctx.op_nnls(G, B, X0, 0.01, 0.02)                 # four columns per wave
     esw = 0
     E = np.empty_like(X0)
     for c in range(0, ncols):
@@ -490,8 +491,13 @@ def test_nnls_ranks_129_to_256_four_columns_per_wave_match_the_oracle_and_the_wa
         esw += it
     assert rel_fro(X, E) < 1e-10 and np.array_equal(X == 0, E == 0) and sweeps == esw
     monkeypatch.setenv("SGL_NNLS_NO_QUAD_BIG", "1")
-    Xw, sw = ctx.op_nnls(G, B, X0, 0.01, 0.02)
+    Xw, sw = ctx.op_nnls(G, B, X0, 0.01, 0.02)                    # one wave per column
     assert np.array_equal(Xw, X) and sw == sweeps
+    # four LANES per column (kernels_nnls_quarter.hip: the long launches of a plain fit), here forced onto the short launch
+    monkeypatch.delenv("SGL_NNLS_NO_QUARTER", raising=False)
+    monkeypatch.setenv("SGL_NNLS_QUARTER_MIN_COLS", "1")
+    Xq, sq = ctx.op_nnls(G, B, X0, 0.01, 0.02)
+    assert np.array_equal(Xq, X) and sq == sweeps
 
 
 @pytest.mark.parametrize("k", [7, 12, 50, 66, 72, 97, 104, 120])

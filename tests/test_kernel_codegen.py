@@ -220,6 +220,35 @@ def test_nnls_dpp_operands_have_no_valu_write_hazard(tmp_path):
     assert ms and int(ms.group(1)) <= 64, "NNLS lane kernel <50> spills %s bytes per lane" % (ms.group(1) if ms else "?")
 
 
+def test_four_lanes_per_column_solve_has_no_dpp_hazard_and_no_scratch(tmp_path_factory):
+    """nnls_quarter_kernel<KQ> (kernels_nnls_quarter.hip, ranks 129 - 256): the row update is inline-asm v_fmac_f64_dpp on Gram
+    pieces that must reach the FMAs straight from their loads (or a copy at least two instructions old): hipcc pads nothing
+    around inline asm.  Every instance: no VALU write of a DPP source within two instructions of its read, one DPP FMA per
+    (coordinate, entry of the lane's quarter), no scratch (the larger instances overflow into AGPRs, not memory)."""
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not installed")
+    text = _device_asm(os.path.join(CSRC, "kernels_nnls_quarter.hip"), tmp_path_factory.mktemp("asm"))
+    for kq in (36, 40, 44, 48, 52, 56, 60, 64):
+        m = re.search(r"^(_Z19nnls_quarter_kernelILi%dEE\w*):[^\n]*\n(.*?)s_endpgm" % kq, text, re.S | re.M)
+        assert m, "nnls_quarter_kernel<%d> not found" % kq
+        prev, n_dpp = [], 0
+        for line in m.group(2).splitlines():
+            code = line.split(";")[0].strip()
+            if not code or code.startswith(".") or code.endswith(":"):
+                continue
+            if "_dpp" in code:
+                n_dpp += 1
+                src0 = _vregs(_dst_src0(code)[1])
+                for pl in prev[-2:]:
+                    if pl.startswith("v_") and (_vregs(_dst_src0(pl)[0]) & src0):
+                        raise AssertionError("KQ=%d DPP hazard: %r followed by %r" % (kq, pl, code))
+            prev.append(code)
+        assert n_dpp >= 4 * kq * kq, (kq, n_dpp)
+        meta = text[text.index(".amdhsa_kernel " + m.group(1)):]
+        ms = re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", meta[:meta.index(".end_amdhsa_kernel")])
+        assert ms and int(ms.group(1)) == 0, (kq, ms.group(1) if ms else None)
+
+
 # ---- mask_gram_list_kernel: accumulator tiles in named AGPRs outside hipcc's allocation ------------------------------
 MASK_SRC = os.path.join(ROOT, "singlet_amd", "csrc", "kernels_mask.hip")
 
