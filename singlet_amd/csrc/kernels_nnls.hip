@@ -629,6 +629,10 @@ int k_nnls_percol(hipStream_t s, const double* G, int64_t gstride, const double*
     // triangles leave one wave per SIMD: nnls_h per masked iteration at 30 000 x 200 000 (LDS -> global): k = 32: 6.5 -> 7.6,
     // 36: 8.6 -> 9.0, 40: 10.1 -> 9.7, 44: 12.7 -> 10.9, 48: 16.9 -> 11.6; on the 30 000 columns of the W side the LDS solve
     // stays ahead up to k = 44.  (SGL_NNLS_QUAD_GLOBAL_FROM: the first rank that takes the global solve -- A/B tests)
+    // (Round 6: four LANES per column for per-column Grams too -- 16 columns per wave, each lane reading its KQ doubles of the
+    //  column's Gram row -- was built, bit-identical, and measured SLOWER at every rank: nnls_h per masked iteration at 30 000 x
+    //  200 000 k = 50 11.6 -> 18.5 ms, 100 36.3 -> 70.5 (profiles/r6_quarter_percol_ab.txt): these solves are bound by the reads of
+    //  the Gram rows, which 16-lane rows fetch as 128-byte pieces at four waves per SIMD; taken out again.)
     const char* qmin = getenv("SGL_NNLS_QUAD_GLOBAL_MIN_COLS");   // (tests lower it to reach the long-launch choices with small problems)
     const int64_t long_launch = (qmin && atoll(qmin) > 0) ? atoll(qmin) : 65536;
     const char* qfrom = getenv("SGL_NNLS_QUAD_GLOBAL_FROM");
