@@ -395,6 +395,31 @@ int k_mask_gram_cols(hipStream_t s, int64_t col0, int64_t ncols, int32_t nrow, c
         // 90.6; it does not pay with three quads (k = 60 47.2 -> 47.3, 76 70.7 -> 72.9, 90 96.0 -> 95.1) or below NT = 3
         // (k = 24 18.5 -> 22.8, 40 29.9 -> 29.8, 44 34.1 -> 35.9): those keep the tile count below, and so does the hashing kernel
         const int nt_full = k / 16, rem = k % 16;
+        // Round 6: the rows beyond 16 NT on the VALU (mask_gram_list_kernel<NT, 1, 0, 0, REMV>): REMV (NT + 1) v_fmac_f64_dpp per group
+        // against (NT + 1) quarter-MFMAs of ~22 cycles per remainder quad or NT + 1 MFMAs of 64 for a further tile row.  Priced at
+        // ~4.7 cycles per DPP FMA it should have won everywhere up to 12 rows; measured (mask phase per masked iteration at 30 000 x
+        // 200 000, ms, before -> after; profiles/r6_mask_gram_valu_remainder_ab.txt) it wins where the rows are few and the tile set
+        // small -- k = 20 15.9 -> 13.4, 34 23.8 -> 22.6, 40 27.0 -> 25.0, 50 34.3 -> 33.6, 66 50.3 -> 48.0 -- and loses or ties beyond:
+        // k = 44 29.6 -> 29.7 (12 rows), 56 37.6 -> 38.9 (8 rows at NT = 3), 60 43.4 -> 47.0 (12), 70 58.4 -> 58.8 (6 at NT = 4): an FMA
+        // on the remainder accumulators costs ~9 cycles here, not 4.7.  Kept: up to 4 rows at NT = 1, up to 8 at NT = 2, up to 2 at
+        // NT = 3 and 4.  SGL_MASK_GRAM_NO_REMV=1: the forms below (A/B, tests).
+        const int rv_max = nt_full == 1 ? 4 : (nt_full == 2 ? 8 : ((nt_full == 3 || nt_full == 4) ? 2 : 0));
+        if (lists && rem > 0 && rem <= rv_max && !getenv("SGL_MASK_GRAM_NO_REM") && !getenv("SGL_MASK_GRAM_NO_REMV")) {
+#define SGL_MGV(NT_, RV_) SGLCHK((launch_mask_gram_list<NT_, 1, 0, 0, RV_>(g, b, s, col0, ncols, col_nnz, L, F, G, k, Gcols, raw)))
+            const int rv = rem <= 2 ? 2 : (rem <= 4 ? 4 : 8);
+            switch (nt_full * 100 + rv) {
+                case 102: SGL_MGV(1, 2); break;
+                case 104: SGL_MGV(1, 4); break;
+                case 202: SGL_MGV(2, 2); break;
+                case 204: SGL_MGV(2, 4); break;
+                case 208: SGL_MGV(2, 8); break;
+                case 302: SGL_MGV(3, 2); break;
+                default: SGL_MGV(4, 2); break;
+            }
+#undef SGL_MGV
+            HIPCHK(hipGetLastError());
+            return SGL_OK;
+        }
         if (lists && rem > 4 && rem <= 8 && nt_full >= 3 && nt_full <= 5 && !getenv("SGL_MASK_GRAM_NO_REM") && !getenv("SGL_MASK_GRAM_NO_REM8")) {
 #define SGL_MGL(NT_, REM_) SGLCHK((launch_mask_gram_list<NT_, 1, 0, REM_>(g, b, s, col0, ncols, col_nnz, L, F, G, k, Gcols, raw)))
             switch (nt_full) {

@@ -85,12 +85,18 @@ def _mask_gram_oracle(ora, F, G, ncols, seed, inv_density, mask_t, col_off, row_
 
 @pytest.mark.parametrize("k", [1, 2, 5, 10, 16, 17, 18, 20, 21, 24, 25, 28, 30, 33, 36, 37, 40, 41, 44, 48, 50, 52, 53, 56, 57, 60, 64, 66, 69, 70, 72,
                                73, 76, 80, 84, 85, 88, 89, 92, 96, 98, 100, 104, 112, 128, 130])
-@pytest.mark.parametrize("use_lists", [False, True])
-def test_mask_gram_downdate(ctx, ora, k, use_lists):
+@pytest.mark.parametrize("use_lists", [False, True, "quarter_mfma_remainder"])
+def test_mask_gram_downdate(ctx, ora, k, use_lists, monkeypatch):
     """Per-column Gram downdates of predict_mask, by the hashing kernel and from the mask lists (every tile-set
-    instance: full blocks, remainder rows (one to three quads), a partial last block, two-part tile sets; k = 130: the VALU kernel,
+    instance: full blocks, remainder rows on the VALU (round 6: 2 - 12 rows beside 1 - 4 tile rows) or as one to three quads of
+    quarter-MFMAs (SGL_MASK_GRAM_NO_REMV=1: rounds 3 - 5), a partial last block, two-part tile sets; k = 130: the VALU kernel,
     which ignores the lists), both orientations with offsets, raw sums; several hundred drawn rows per column
     (the pipelined loop of the list kernel) down to none."""
+    if use_lists == "quarter_mfma_remainder":
+        monkeypatch.setenv("SGL_MASK_GRAM_NO_REMV", "1")
+        use_lists = True
+    else:
+        monkeypatch.delenv("SGL_MASK_GRAM_NO_REMV", raising=False)
     rng = np.random.default_rng(500 + k)
     nrow, ncols = 1500, 7
     F = rng.random((nrow, k)) + 0.1

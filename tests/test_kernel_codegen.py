@@ -220,6 +220,37 @@ def test_nnls_dpp_operands_have_no_valu_write_hazard(tmp_path):
     assert ms and int(ms.group(1)) <= 64, "NNLS lane kernel <50> spills %s bytes per lane" % (ms.group(1) if ms else "?")
 
 
+def test_list_downdate_valu_remainder_rows_have_no_dpp_hazard(mask_asm):
+    """mask_gram_list_kernel<NT, 1, 0, 0, REMV> (round 6): the rows beyond 16 NT are v_fmac_f64_dpp on the group's operand of block
+    NT, which must reach the FMAs straight from its load -- a VALU write of a DPP source needs two wait states hipcc does not pad
+    inside inline asm.  Every instance: REMV (NT + 1) DPP FMAs per group in the steady-state loop, none within two instructions of a
+    VALU write of its broadcast source, no scratch, at most 256 registers (two workgroups per CU)."""
+    found = 0
+    for m in re.finditer(r"^(_Z21mask_gram_list_kernelILi(\d+)ELi1ELi0ELi0ELi(\d+)EE\w*):[^\n]*\n(.*?)s_endpgm", mask_asm, re.S | re.M):
+        name, nt, remv, body = m.group(1), int(m.group(2)), int(m.group(3)), m.group(4)
+        if remv == 0:
+            continue
+        found += 1
+        prev, n_dpp = [], 0
+        for line in body.splitlines():
+            code = line.split(";")[0].strip()
+            if not code or code.startswith(".") or code.endswith(":"):
+                continue
+            if code.startswith("v_fmac_f64_dpp"):
+                n_dpp += 1
+                src0 = _vregs(_dst_src0(code)[1])
+                for pl in prev[-2:]:
+                    if pl.startswith("v_") and (_vregs(_dst_src0(pl)[0]) & src0):
+                        raise AssertionError("NT=%d REMV=%d DPP hazard: %r followed by %r" % (nt, remv, pl, code))
+            prev.append(code)
+        assert n_dpp >= 3 * remv * (nt + 1), (nt, remv, n_dpp)      # three groups per lap of the steady-state loop (+ the tails)
+        meta = mask_asm[mask_asm.index(".amdhsa_kernel " + name):]
+        meta = meta[:meta.index(".end_amdhsa_kernel")]
+        assert int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", meta).group(1)) == 0, (nt, remv)
+        assert int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", meta).group(1)) <= 256, (nt, remv)
+    assert found == 7, found
+
+
 def test_four_lanes_per_column_solve_has_no_dpp_hazard_and_no_scratch(tmp_path_factory):
     """nnls_quarter_kernel<KQ> (kernels_nnls_quarter.hip, ranks 129 - 256): the row update is inline-asm v_fmac_f64_dpp on Gram
     pieces that must reach the FMAs straight from their loads (or a copy at least two instructions old): hipcc pads nothing
