@@ -612,11 +612,26 @@ static int launch_nnls_quad(hipStream_t s, const double* G, int64_t gstride, con
     return SGL_OK;
 }
 
-int k_nnls_quad_global_big(hipStream_t s, const double* G, int64_t gstride, const double* B, double* X, const int64_t* col_nnz, int k,
-                           int64_t ncols, double L1, double L2, unsigned long long* sweep_counter);   // kernels_nnls_quad_big.hip
+int k_nnls_quad_global_big1(hipStream_t s, const double* G, int64_t gstride, const double* B, double* X, const int64_t* col_nnz, int k,
+                            int64_t ncols, double L1, double L2, unsigned long long* sweep_counter);   // kernels_nnls_quad_big1.hip: k <= 192
+int k_nnls_quad_global_big2(hipStream_t s, const double* G, int64_t gstride, const double* B, double* X, const int64_t* col_nnz, int k,
+                            int64_t ncols, double L1, double L2, unsigned long long* sweep_counter);   // kernels_nnls_quad_big2.hip: k <= 256
+static int k_nnls_quad_global_big(hipStream_t s, const double* G, int64_t gstride, const double* B, double* X, const int64_t* col_nnz, int k,
+                                  int64_t ncols, double L1, double L2, unsigned long long* sweep_counter) {
+    return k <= 192 ? k_nnls_quad_global_big1(s, G, gstride, B, X, col_nnz, k, ncols, L1, L2, sweep_counter)
+                    : k_nnls_quad_global_big2(s, G, gstride, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
+}
 
-int k_nnls_quarter(hipStream_t s, const double* G, const double* B, double* X, const int64_t* col_nnz, int k, int64_t ncols, double L1, double L2,
-                   unsigned long long* sweep_counter);   // kernels_nnls_quarter.hip
+int k_nnls_quarter_part1(hipStream_t s, const double* G, const double* B, double* X, const int64_t* col_nnz, int k, int64_t ncols, double L1, double L2,
+                         unsigned long long* sweep_counter);   // kernels_nnls_quarter1.hip: k <= 192
+int k_nnls_quarter_part2(hipStream_t s, const double* G, const double* B, double* X, const int64_t* col_nnz, int k, int64_t ncols, double L1, double L2,
+                         unsigned long long* sweep_counter);   // kernels_nnls_quarter2.hip: k <= 256
+static int k_nnls_quarter(hipStream_t s, const double* G, const double* B, double* X, const int64_t* col_nnz, int k, int64_t ncols, double L1, double L2,
+                          unsigned long long* sweep_counter) {
+    if (ncols <= 0) return SGL_OK;
+    return k <= 192 ? k_nnls_quarter_part1(s, G, B, X, col_nnz, k, ncols, L1, L2, sweep_counter)
+                    : k_nnls_quarter_part2(s, G, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
+}
 
 int k_nnls_percol(hipStream_t s, const double* G, int64_t gstride, const double* B, double* X, const int64_t* col_nnz,
                 int k, int64_t ncols, double L1, double L2, unsigned long long* sweep_counter) {
@@ -667,7 +682,7 @@ int k_nnls_percol(hipStream_t s, const double* G, int64_t gstride, const double*
             default: return launch_nnls_quad_global<8>(s, G, gstride, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
         }
     }
-    // ranks 129 - 256 against a SHARED Gram: four LANES per column, 16 columns per wave (kernels_nnls_quarter.hip) from 8192 columns
+    // ranks 129 - 256 against a SHARED Gram: four LANES per column, 16 columns per wave (nnls_quarter.h) from 8192 columns
     // on (SGL_NNLS_QUARTER_MIN_COLS; SGL_NNLS_NO_QUARTER=1: never -- A/B, bit-identity tests); shorter launches and per-column
     // Grams take the four-columns-per-wave solve below
     {
@@ -676,7 +691,7 @@ int k_nnls_percol(hipStream_t s, const double* G, int64_t gstride, const double*
         if (gstride == 0 && k > 128 && k <= 256 && ncols >= quarter_min && !getenv("SGL_NNLS_NO_QUARTER"))
             return k_nnls_quarter(s, G, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
     }
-    // ranks 129 - 256, shared Gram or per-column Grams: four columns per wave, instances NR = 9 .. 16 (kernels_nnls_quad_big.hip;
+    // ranks 129 - 256, shared Gram or per-column Grams: four columns per wave, instances NR = 9 .. 16 (kernels_nnls_quad_big1 / 2.hip;
     // SGL_NNLS_NO_QUAD_BIG=1: the wave kernel below -- A/B, bit-identity tests)
     // (measured at 30 000 x 200 000, profiles/r6_k_above_128.txt: nnls_h k = 130 78 -> 41 ms, 200 140 -> 75, 256 192 -> 110; the 30 000
     //  columns of the W side gain up to k = 200 -- 8.8 -> 6.9 ms at k = 130 -- and lose above, where the instances spill: 20.1 -> 23.3

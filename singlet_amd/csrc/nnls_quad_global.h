@@ -1,5 +1,5 @@
 // nnls_quad_global_kernel<NR>: four columns per wave, the Gram in global memory (kernels_nnls.hip: per-column Grams of the masked
-// path, k <= 128; kernels_nnls_quad_big.hip, round 6: NR = 9 .. 16 against the SHARED Gram of a plain fit at ranks 129 - 256).
+// path, k <= 128; kernels_nnls_quad_big1 / 2.hip, round 6: NR = 9 .. 16 against the SHARED Gram of a plain fit at ranks 129 - 256).
 #pragma once
 #include "sgl_internal.h"
 #include "nnls_static_for.h"

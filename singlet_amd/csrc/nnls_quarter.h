@@ -11,6 +11,7 @@
 // these ranks until this kernel) serves four: ~(40 + KQ) instructions per coordinate and 16 columns against ~60 per four.
 // Same operations in the same order per column as nnls_wave_kernel / the oracle: the same bits (tests/test_gpu_ops.py).
 // An instance KQ serves 4 KQ - 15 <= k <= 4 KQ.
+#pragma once
 #include "sgl_internal.h"
 #include "nnls_static_for.h"
 
@@ -139,18 +140,3 @@ static int launch_quarter(hipStream_t s, const double* G, const double* B, doubl
     return SGL_OK;
 }
 
-int k_nnls_quarter(hipStream_t s, const double* G, const double* B, double* X, const int64_t* col_nnz, int k, int64_t ncols, double L1, double L2,
-                   unsigned long long* sweep_counter) {
-    if (ncols <= 0) return SGL_OK;
-    switch ((k + 15) / 16) {
-        case 9: return launch_quarter<36>(s, G, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
-        case 10: return launch_quarter<40>(s, G, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
-        case 11: return launch_quarter<44>(s, G, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
-        case 12: return launch_quarter<48>(s, G, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
-        case 13: return launch_quarter<52>(s, G, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
-        case 14: return launch_quarter<56>(s, G, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
-        case 15: return launch_quarter<60>(s, G, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
-        case 16: return launch_quarter<64>(s, G, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
-        default: sgl_set_error("k_nnls_quarter: k=%d outside 129 .. 256", k); return SGL_EINVAL;
-    }
-}

@@ -477,7 +477,7 @@ def test_nnls(ctx, ora, k, L1, L2):
 @pytest.mark.parametrize("k", [129, 130, 144, 145, 160, 161, 176, 177, 192, 193, 208, 209, 224, 225, 240, 241, 255, 256])
 def test_nnls_ranks_129_to_256_four_columns_per_wave_match_the_oracle_and_the_wave_kernel(ctx, ora, k, monkeypatch):
     """Round 6: ranks 129 - 256 solve four columns per wave (nnls_quad_global_kernel<9 .. 16> against the shared Gram,
-    kernels_nnls_quad_big.hip) where they fell to the wave-per-column kernel: every instance at both ends of its rank range, a
+    kernels_nnls_quad_big1 / 2.hip) where they fell to the wave-per-column kernel: every instance at both ends of its rank range, a
     ragged column count (a partial quad), skipped columns; the oracle's nnls (src/singlet.cpp:229-250) with equal sweep totals, and
     the bits of the wave kernel."""
     rng = np.random.default_rng(1000 + k)
@@ -499,7 +499,7 @@ def test_nnls_ranks_129_to_256_four_columns_per_wave_match_the_oracle_and_the_wa
     monkeypatch.setenv("SGL_NNLS_NO_QUAD_BIG", "1")
     Xw, sw = ctx.op_nnls(G, B, X0, 0.01, 0.02)                    # one wave per column
     assert np.array_equal(Xw, X) and sw == sweeps
-    # four LANES per column (kernels_nnls_quarter.hip: the long launches of a plain fit), here forced onto the short launch
+    # four LANES per column (nnls_quarter.h: the long launches of a plain fit), here forced onto the short launch
     monkeypatch.delenv("SGL_NNLS_NO_QUARTER", raising=False)
     monkeypatch.setenv("SGL_NNLS_QUARTER_MIN_COLS", "1")
     Xq, sq = ctx.op_nnls(G, B, X0, 0.01, 0.02)

@@ -252,13 +252,13 @@ def test_list_downdate_valu_remainder_rows_have_no_dpp_hazard(mask_asm):
 
 
 def test_four_lanes_per_column_solve_has_no_dpp_hazard_and_no_scratch(tmp_path_factory):
-    """nnls_quarter_kernel<KQ> (kernels_nnls_quarter.hip, ranks 129 - 256): the row update is inline-asm v_fmac_f64_dpp on Gram
+    """nnls_quarter_kernel<KQ> (nnls_quarter.h, instances in kernels_nnls_quarter1 / 2.hip; ranks 129 - 256): the row update is inline-asm v_fmac_f64_dpp on Gram
     pieces that must reach the FMAs straight from their loads (or a copy at least two instructions old): hipcc pads nothing
     around inline asm.  Every instance: no VALU write of a DPP source within two instructions of its read, one DPP FMA per
     (coordinate, entry of the lane's quarter), no scratch (the larger instances overflow into AGPRs, not memory)."""
     if not os.path.exists(HIPCC):
         pytest.skip("hipcc not installed")
-    text = _device_asm(os.path.join(CSRC, "kernels_nnls_quarter.hip"), tmp_path_factory.mktemp("asm"))
+    text = "".join(_device_asm(os.path.join(CSRC, "kernels_nnls_quarter%d.hip" % part), tmp_path_factory.mktemp("asm")) for part in (1, 2))
     for kq in (36, 40, 44, 48, 52, 56, 60, 64):
         m = re.search(r"^(_Z19nnls_quarter_kernelILi%dEE\w*):[^\n]*\n(.*?)s_endpgm" % kq, text, re.S | re.M)
         assert m, "nnls_quarter_kernel<%d> not found" % kq
