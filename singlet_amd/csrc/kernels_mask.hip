@@ -502,6 +502,49 @@ int k_mask_gram_finalize(hipStream_t s, const double* G, const double* S, int k,
     return SGL_OK;
 }
 
+// The team's per-gene downdates travel as lower triangles (round 6): S_g is symmetric, so the reduce-scatter of the masked
+// W-update (multi.hip: k x k x genes doubles per rank and iteration, 2.4 GB at k = 100) moves k (k + 1) / 2 per gene instead of
+// k^2.  tri[c][i (i + 1) / 2 + j] = S[c][j * k + i] for j <= i; the sums over the ranks are element-wise either way: same bits.
+__global__ void tri_pack_kernel(const double* __restrict__ S, int k, int64_t ncols, double* __restrict__ tri) {
+    const int64_t T = (int64_t)k * (k + 1) / 2, n = T * ncols;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t c = e / T;
+        const int t = (int)(e - c * T);
+        int i = (int)((__builtin_sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+        while ((i + 1) * (i + 2) / 2 <= t) ++i;   // (guards the rounding of the square root)
+        while (i * (i + 1) / 2 > t) --i;
+        const int j = t - i * (i + 1) / 2;
+        tri[e] = S[c * (int64_t)k * k + (int64_t)j * k + i];
+    }
+}
+int k_tri_pack(hipStream_t s, const double* S, int k, int64_t ncols, double* tri) {
+    if (ncols <= 0) return SGL_OK;
+    const int64_t n = (int64_t)k * (k + 1) / 2 * ncols;
+    tri_pack_kernel<<<dim3((unsigned)std::min<int64_t>((n + 255) / 256, 8192)), dim3(256), 0, s>>>(S, k, ncols, tri);
+    HIPCHK(hipGetLastError());
+    return SGL_OK;
+}
+// mask_gram_finalize_kernel from packed triangles
+__global__ void mask_gram_finalize_tri_kernel(const double* __restrict__ G, const double* __restrict__ tri, int k, int64_t ncols,
+                                              double* __restrict__ out) {
+    const int64_t kk = (int64_t)k * k, n = kk * ncols, T = (int64_t)k * (k + 1) / 2;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t c = e / kk;
+        const int q = (int)(e - c * kk);
+        const int a = q / k, b = q % k, i = a > b ? a : b, j = a > b ? b : a;
+        double sub = tri[c * T + (int64_t)i * (i + 1) / 2 + j];
+        if (a == b) sub += 1e-15;
+        out[e] = G[q] - sub;
+    }
+}
+int k_mask_gram_finalize_tri(hipStream_t s, const double* G, const double* tri, int k, int64_t ncols, double* out) {
+    if (ncols <= 0) return SGL_OK;
+    const int64_t n = (int64_t)k * k * ncols;
+    mask_gram_finalize_tri_kernel<<<dim3((unsigned)std::min<int64_t>((n + 255) / 256, 8192)), dim3(256), 0, s>>>(G, tri, k, ncols, out);
+    HIPCHK(hipGetLastError());
+    return SGL_OK;
+}
+
 // ---------------------------------------------------------------- mse_test --
 // mse_test (src/singlet.cpp:536-568).  One wave per cell, LANES OVER THE FACTORS: h[:, cell] sits in
 // registers (one or two per lane), every 64-gene chunk is hashed one gene per lane, and for each drawn gene

@@ -777,6 +777,11 @@ static int team_mask_workspace(sgl_team* T) {
             const int64_t mb = (T->nrow + N - 1) / N;
             hipError_t e = sgl_pool_malloc((void**)&c->Sbuf, sizeof(double) * (size_t)mb * N * c->k * c->k);
             if (e != hipSuccess) { (void)hipGetLastError(); sgl_set_error("team: out of device memory for the per-gene downdates"); return SGL_ENOMEM; }
+            // what the reduce-scatter moves: the lower triangles (SGL_TEAM_FULL_S=1: the full blocks, rounds 2 - 5 -- A/B, tests)
+            if (!getenv("SGL_TEAM_FULL_S")) {
+                e = sgl_pool_malloc((void**)&c->Stri, sizeof(double) * (size_t)mb * N * c->k * (c->k + 1) / 2);
+                if (e != hipSuccess) { (void)hipGetLastError(); sgl_set_error("team: out of device memory for the per-gene downdates"); return SGL_ENOMEM; }
+            }
         }
     }
     return SGL_OK;
@@ -840,14 +845,21 @@ static int team_ard_iterate(sgl_team* T, double L1, double L2, uint64_t seed, ui
                                 c->cell_offset, c->Sbuf, ML));
         SGLCHK(sgl_phase_end(c, &pe));
         red[i] = Bw;
-        sb[i] = c->Sbuf;
+        if (c->Stri) {   // S_g is symmetric: its lower triangle travels, k (k + 1) / 2 doubles per gene instead of k^2
+            SGLCHK(sgl_phase_begin(c, SGL_PH_MASK, &pe));
+            SGLCHK(k_tri_pack(c->stream, c->Sbuf, k, mpad, c->Stri));
+            SGLCHK(sgl_phase_end(c, &pe));
+        }
+        sb[i] = c->Stri ? c->Stri : c->Sbuf;
         tail[i] = Gh;
         wbuf[i] = c->W;
         return SGL_OK;
     };
+    const bool tri = T->local[0]->Stri != nullptr;
+    const int64_t s_unit = tri ? (int64_t)k * (k + 1) / 2 : (int64_t)k * k;   // doubles per gene in the downdate exchange
     auto exchange_w = [&](int who) -> int {
         if (N <= 1) return SGL_OK;
-        return team_exchange(T, who, {{1, &red, (int64_t)k * mb, false}, {1, &sb, (int64_t)k * k * mb, false}, {0, &tail, (int64_t)k * k, false}});
+        return team_exchange(T, who, {{1, &red, (int64_t)k * mb, false}, {1, &sb, s_unit * mb, false}, {0, &tail, (int64_t)k * k, false}});
     };
     auto gene_block = [&](int i) -> int {   // every rank: its block of genes
         if (N <= 1) return SGL_OK;
@@ -865,7 +877,8 @@ static int team_ard_iterate(sgl_team* T, double L1, double L2, uint64_t seed, ui
         for (int64_t q0 = 0; q0 < ng; q0 += c->gcols_chunk) {
             const int64_t nq = std::min<int64_t>(c->gcols_chunk, ng - q0);
             SGLCHK(sgl_phase_begin(c, SGL_PH_MASK, &pe));
-            SGLCHK(k_mask_gram_finalize(c->stream, c->G, c->Sbuf + (size_t)(g0 + q0) * k * k, k, nq, c->Gcols));
+            if (c->Stri) SGLCHK(k_mask_gram_finalize_tri(c->stream, c->G, c->Stri + (size_t)(g0 + q0) * s_unit, k, nq, c->Gcols));
+            else SGLCHK(k_mask_gram_finalize(c->stream, c->G, c->Sbuf + (size_t)(g0 + q0) * k * k, k, nq, c->Gcols));
             SGLCHK(sgl_phase_end(c, &pe));
             SGLCHK(sgl_phase_begin(c, SGL_PH_NNLS_W, &pe));
             SGLCHK(k_nnls_percol(c->stream, c->Gcols, (int64_t)k * k, c->red + (size_t)(g0 + q0) * k, c->W + (size_t)(g0 + q0) * k,

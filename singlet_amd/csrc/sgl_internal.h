@@ -179,6 +179,7 @@ struct sgl_ctx {
     int64_t gcols_chunk = 0;
     double* Wd = nullptr;      // mse_test: W' = W^T diag(d) as k x m
     double* Sbuf = nullptr;    // team masked W-update: per-gene downdate partials, (gene blocks x team size) x k x k
+    double* Stri = nullptr;    // ... their lower triangles, what the reduce-scatter moves: (gene blocks x team size) x k (k + 1) / 2
     struct sgl_team* team = nullptr;   // native collective (multi.hip): the team this context is a rank of
     int team_rank = 0;
     double* ws = nullptr;   // partial-reduction workspace
@@ -331,6 +332,8 @@ int sgl_mask_list_select(sgl_ctx* c, int which, int64_t ncol, int32_t nrow, uint
 void sgl_mask_lists_free_all(sgl_ctx* c);
 bool sgl_mask_lists_release_kept(sgl_ctx* c);   // memory pressure: drop the kept (not the current) masks; true if anything was freed
 int k_mask_gram_finalize(hipStream_t s, const double* G, const double* S, int k, int64_t ncols, double* out);
+int k_tri_pack(hipStream_t s, const double* S, int k, int64_t ncols, double* tri);   // lower triangles of ncols symmetric k x k blocks
+int k_mask_gram_finalize_tri(hipStream_t s, const double* G, const double* tri, int k, int64_t ncols, double* out);
 int k_mse_test(sgl_ctx* c, const double* Wd, const double* H, int k, uint64_t seed, uint64_t inv_density,
                double* out_dev);
 int k_wd(hipStream_t s, const double* W, const double* d, int k, int64_t cols, double* Wd);

@@ -179,6 +179,7 @@ static void free_fit(sgl_ctx* c, bool keep_streams = false) {
     c->gcols_chunk = 0;
     dev_free(c->Wd);
     dev_free(c->Sbuf);
+    dev_free(c->Stri);
     nnls_scratch_free(c->nnls_scr);
     dev_free(c->link_h);
     dev_free(c->link_w);

@@ -208,6 +208,31 @@ def test_threaded_and_serial_team_drives_are_bit_identical(sa, ora, masked, monk
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("k,ranks", [(7, 2), (50, 3), (70, 8), (100, 4)])
+def test_sharded_masked_path_moves_triangles_with_the_same_bits(sa, ora, k, ranks, monkeypatch):
+    """Round 6: the per-gene Gram downdates of the sharded masked W-update are symmetric, so their reduce-scatter moves the lower
+    triangles -- k (k + 1) / 2 doubles per gene instead of k^2 (2.4 -> 1.2 GB per rank and iteration at k = 100).  The sums over the
+    ranks are element-wise either way: the fit must come out bit for bit as with the full blocks (SGL_TEAM_FULL_S=1)."""
+    m, n = 260, 700
+    A = to_dgc(sa, ora.synth_csc(m, n, 10))
+    w0 = ora.synth_winit(k, m)
+    out = {}
+    for full in (True, False):
+        if full:
+            monkeypatch.setenv("SGL_TEAM_FULL_S", "1")
+        else:
+            monkeypatch.delenv("SGL_TEAM_FULL_S", raising=False)
+        with sa.Multi([0] * ranks) as M:
+            M.upload(A)
+            M.fit_init(k, w0)
+            r = M.ard_run(0.0, 3, 0.01, 0.0, 31, 8, 1e9, 1)
+            out[full] = (M.get_factors(), (r["test_mse"], r["tol"], r["iter"]))
+    for a, b in zip(out[True][0], out[False][0]):
+        assert np.array_equal(a, b)
+    for a, b in zip(out[True][1], out[False][1]):
+        assert np.array_equal(a, b)
+
+
 def test_team_error_reaches_the_caller_from_a_worker_thread(sa, ora):
     """A failure inside a rank's worker thread (here: a rank above the library's limit, refused by every rank) comes back
     as the call's error with the rank's message, and the team stays usable."""
