@@ -344,7 +344,7 @@ static int upload_one(sgl_ctx* c, DevCSC& M, const double* x, const int32_t* i, 
     if (rc == SGL_OK && flag != 0) {
         sgl_set_error("not a valid dgCMatrix: %s%s%s", (flag & 1) ? "row index outside [0, nrow) " : "",
                       (flag & 2) ? "row indices not strictly ascending within a column " : "",
-                      (flag & 4) ? "non-finite value (NA / NaN / Inf) in the x slot" : "");
+                      (flag & 4) ? "non-finite value (NA / NaN / Inf) in the x slot -- refused here; singlet's CPU path would return all-NaN factors" : "");
         return SGL_EINVAL;
     }
     return rc;
@@ -398,7 +398,7 @@ static int upload_chunks(sgl_ctx* c, DevCSC& M, int32_t n_chunks, const double* 
     if (rc == SGL_OK && flag != 0) {
         sgl_set_error("not a valid dgCMatrix list: %s%s%s", (flag & 1) ? "row index outside [0, nrow) " : "",
                       (flag & 2) ? "row indices not strictly ascending within a column " : "",
-                      (flag & 4) ? "non-finite value (NA / NaN / Inf) in an x slot" : "");
+                      (flag & 4) ? "non-finite value (NA / NaN / Inf) in an x slot -- refused here; singlet's CPU path would return all-NaN factors" : "");
         return SGL_EINVAL;
     }
     return rc;
@@ -505,7 +505,7 @@ extern "C" int sgl_upload_dense(sgl_ctx* c, const double* A, int32_t nrow, int32
                              hipStreamSynchronize(c->stream) != hipSuccess)) rc = SGL_EHIP;
         dev_free(dflag);
         if (rc == SGL_EHIP) sgl_set_error("sgl_upload_dense: HIP call failed");
-        if (rc == SGL_OK && flag != 0) { sgl_set_error("sgl_upload_dense: non-finite value (NA / NaN / Inf) in the matrix"); rc = SGL_EINVAL; }
+        if (rc == SGL_OK && flag != 0) { sgl_set_error("sgl_upload_dense: non-finite value (NA / NaN / Inf) in the matrix -- refused here; singlet's CPU path would return all-NaN factors"); rc = SGL_EINVAL; }
         if (rc != SGL_OK) {   // the refused copy does not stay resident until the next upload
             (void)hipStreamSynchronize(c->stream);
             dev_free(c->Adense);
