@@ -70,9 +70,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KQ > 44 ? 1
             ++ran;
             if (go) tol = 0.0;
             const double* __restrict__ gp = G;   // row i of the running coordinate
-            double gn[NGQ];
+            double g2[2][NGQ];   // two row buffers by the parity of the coordinate: no copies (a VALU copy in front of a DPP read would also be a hazard)
 #pragma unroll
-            for (int m = 0; m < NGQ; ++m) gn[m] = gp[goff[m]];
+            for (int m = 0; m < NGQ; ++m) g2[0][m] = gp[goff[m]];
             double dn0 = Dl[0], dn1 = Dl[1];
             static_for<KP>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
@@ -80,15 +80,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KQ > 44 ? 1
                 bool run_i = i < k;
                 if (i < KLOW) { asm volatile("" : "+s"(one)); run_i = one != 0; }   // opaque, always true: one basic block per coordinate
                 if (run_i) {
-                    double grow[NGQ];
-#pragma unroll
-                    for (int m = 0; m < NGQ; ++m) grow[m] = gn[m];
+                    constexpr int pb = i & 1;
                     gp += k;
                     if constexpr (i + 1 < KP) {   // this lane's pieces of row i + 1, in flight during this coordinate
                         const bool more = (i + 1 < KLOW) || (i + 1 < k);
                         if (more) {
 #pragma unroll
-                            for (int m = 0; m < NGQ; ++m) gn[m] = gp[goff[m]];
+                            for (int m = 0; m < NGQ; ++m) g2[pb ^ 1][m] = gp[goff[m]];
                         }
                     }
                     const double gii = dn0, rii = dn1;
@@ -105,7 +103,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KQ > 44 ? 1
                     x[ii] = (q == owner) ? xv : x[ii];
                     static_for<KQ>([&](auto jc) {
                         constexpr int j = decltype(jc)::value;
-                        quarter_dpp_fmac<(j & 15)>(b[j], grow[j >> 4], nd);
+                        quarter_dpp_fmac<(j & 15)>(b[j], g2[pb][j >> 4], nd);
                     });
                     __builtin_amdgcn_sched_barrier(0);
                 }
