@@ -27,7 +27,7 @@
  *    reference's nnls / predict_mask have no limit, src/singlet.cpp:229-250, 436-466).  The tuned kernels cover
  *    k <= 128 (LDS-tiled accumulate, MFMA Grams and Gram downdates, lane NNLS); the plain fit runs ranks 129 - 256 on the
  *    same entry streams, with the Gram on the matrix cores and four lanes per column in the solve (round 6: an iteration
- *    at k = 130 costs 1.45 x one at k = 128); above 256, and for the masked Gram downdate above 128, generic kernels run
+ *    at k = 130 costs 1.3 x one at k = 128); above 256, and for the masked Gram downdate above 128, generic kernels run
  *    (wave-per-column NNLS, VALU Grams in several launches): correct, several times slower.
  *  - device memory: blocks of 64 MB and more that a call frees are kept for the next call (sgl_pool_info,
  *    sgl_cache_release; SGL_POOL=0 switches it off).

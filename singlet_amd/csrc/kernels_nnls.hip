@@ -623,14 +623,32 @@ static int k_nnls_quad_global_big(hipStream_t s, const double* G, int64_t gstrid
 }
 
 int k_nnls_quarter_part1(hipStream_t s, const double* G, const double* B, double* X, const int64_t* col_nnz, int k, int64_t ncols, double L1, double L2,
-                         unsigned long long* sweep_counter);   // kernels_nnls_quarter1.hip: k <= 192
+                         unsigned long long* sweep_counter, const int32_t* order, uint8_t* prev_it);   // kernels_nnls_quarter1.hip: k <= 192
 int k_nnls_quarter_part2(hipStream_t s, const double* G, const double* B, double* X, const int64_t* col_nnz, int k, int64_t ncols, double L1, double L2,
-                         unsigned long long* sweep_counter);   // kernels_nnls_quarter2.hip: k <= 256
+                         unsigned long long* sweep_counter, const int32_t* order, uint8_t* prev_it);   // kernels_nnls_quarter2.hip: k <= 256
 static int k_nnls_quarter(hipStream_t s, const double* G, const double* B, double* X, const int64_t* col_nnz, int k, int64_t ncols, double L1, double L2,
-                          unsigned long long* sweep_counter) {
+                          unsigned long long* sweep_counter, const int32_t* order = nullptr, uint8_t* prev_it = nullptr) {
     if (ncols <= 0) return SGL_OK;
-    return k <= 192 ? k_nnls_quarter_part1(s, G, B, X, col_nnz, k, ncols, L1, L2, sweep_counter)
-                    : k_nnls_quarter_part2(s, G, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
+    return k <= 192 ? k_nnls_quarter_part1(s, G, B, X, col_nnz, k, ncols, L1, L2, sweep_counter, order, prev_it)
+                    : k_nnls_quarter_part2(s, G, B, X, col_nnz, k, ncols, L1, L2, sweep_counter, order, prev_it);
+}
+
+// the four-lane solve of a plain fit's H side (ranks 129 - 256, the whole shard's columns) with its 16-column waves packed by the
+// sweep counts of the previous iteration's solve (the lane kernels' packing: counting sort on the device, then one launch)
+int k_nnls_quarter_packed(hipStream_t s, const double* G, const double* B, double* X, const int64_t* col_nnz, int k, int64_t ncols, double L1,
+                          double L2, unsigned long long* sweep_counter, const NnlsScratch* scr) {
+    const bool pack = scr != nullptr && scr->prev_it != nullptr && scr->pack_cap >= ncols && !getenv("SGL_NNLS_NO_PACK");
+    const int32_t* order = nullptr;
+    if (pack) {
+        const int nblocks = (int)((ncols + SGL_PACK_CPB - 1) / SGL_PACK_CPB);
+        uint32_t* n_dev = scr->sort_ws + (size_t)SGL_PACK_BINS * nblocks;
+        nnls_pack_hist_kernel<<<dim3((unsigned)nblocks), dim3(256), 0, s>>>(scr->prev_it, ncols, nblocks, scr->sort_ws);
+        nnls_pack_scan_kernel<<<dim3(1), dim3(1024), 0, s>>>(scr->sort_ws, SGL_PACK_BINS * nblocks, n_dev);
+        nnls_pack_scatter_kernel<<<dim3((unsigned)nblocks), dim3(256), 0, s>>>(scr->prev_it, ncols, nblocks, scr->sort_ws, scr->packed);
+        HIPCHK(hipGetLastError());
+        order = scr->packed;
+    }
+    return k_nnls_quarter(s, G, B, X, col_nnz, k, ncols, L1, L2, sweep_counter, order, pack ? scr->prev_it : nullptr);
 }
 
 int k_nnls_percol(hipStream_t s, const double* G, int64_t gstride, const double* B, double* X, const int64_t* col_nnz,

@@ -3,12 +3,12 @@
 #include "nnls_quarter.h"
 
 int k_nnls_quarter_part2(hipStream_t s, const double* G, const double* B, double* X, const int64_t* col_nnz, int k, int64_t ncols, double L1, double L2,
-                         unsigned long long* sweep_counter) {
+                         unsigned long long* sweep_counter, const int32_t* order, uint8_t* prev_it) {
     switch ((k + 15) / 16) {
-        case 13: return launch_quarter<52>(s, G, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
-        case 14: return launch_quarter<56>(s, G, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
-        case 15: return launch_quarter<60>(s, G, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
-        case 16: return launch_quarter<64>(s, G, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
+        case 13: return launch_quarter<52>(s, G, B, X, col_nnz, k, ncols, L1, L2, sweep_counter, order, prev_it);
+        case 14: return launch_quarter<56>(s, G, B, X, col_nnz, k, ncols, L1, L2, sweep_counter, order, prev_it);
+        case 15: return launch_quarter<60>(s, G, B, X, col_nnz, k, ncols, L1, L2, sweep_counter, order, prev_it);
+        case 16: return launch_quarter<64>(s, G, B, X, col_nnz, k, ncols, L1, L2, sweep_counter, order, prev_it);
         default: sgl_set_error("k_nnls_quarter: k=%d outside this part's ranks", k); return SGL_EINVAL;
     }
 }

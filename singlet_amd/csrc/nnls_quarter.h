@@ -29,7 +29,8 @@ __device__ __forceinline__ double quarter_from_row(double v, int src_lane) {
 template <int KQ>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KQ > 44 ? 1 : 2))) void nnls_quarter_kernel(
     const double* __restrict__ G, const double* __restrict__ B, double* __restrict__ X, const int64_t* __restrict__ col_nnz, int k,
-    int64_t ncols, double L1, double L2, unsigned long long* __restrict__ sweep_counter) {
+    int64_t ncols, double L1, double L2, unsigned long long* __restrict__ sweep_counter, const int32_t* __restrict__ order,
+    uint8_t* __restrict__ prev_it) {
     constexpr int KP = 4 * KQ, NGQ = (KQ + 15) / 16, KLOW = KP - 15;
     __shared__ __attribute__((aligned(16))) double Dl[2 * KP];   // (G_jj, 1 / G_jj)
     for (int j = threadIdx.x; j < KP; j += blockDim.x) {
@@ -51,7 +52,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KQ > 44 ? 1
     long long total_sweeps = 0, ran_total = 0;
     const int64_t ngroups = (ncols + 15) >> 4;
     for (int64_t grp = wave; grp < ngroups; grp += nwaves) {
-        const int64_t col = grp * 16 + c16;
+        // order (optional): the columns in descending order of the sweeps their previous solve needed (kernels_nnls.hip, "packing by
+        // sweep count"): the 16 columns of a wave then stop at about the same sweep.  A column's arithmetic does not depend on its place.
+        const int64_t pos = grp * 16 + c16;
+        const int64_t col = pos < ncols ? (order ? (int64_t)order[pos] : pos) : ncols;
         const bool valid = col < ncols && (col_nnz == nullptr || col_nnz[col] != 0);
         const double* bp = B + (valid ? col : 0) * k + q * KQ;
         double* xp = X + (valid ? col : 0) * k + q * KQ;
@@ -115,7 +119,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KQ > 44 ? 1
                 constexpr int j = decltype(jc)::value;
                 if (j < kq) xp[j] = x[j];
             });
-            if (q == 0) total_sweeps += it;
+            if (q == 0) {
+                total_sweeps += it;
+                if (prev_it != nullptr) prev_it[col] = (uint8_t)it;   // packing key of the next solve
+            }
         }
         ran_total += ran;
     }
@@ -130,10 +137,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KQ > 44 ? 1
 
 template <int KQ>
 static int launch_quarter(hipStream_t s, const double* G, const double* B, double* X, const int64_t* col_nnz, int k, int64_t ncols, double L1,
-                          double L2, unsigned long long* sweep_counter) {
+                          double L2, unsigned long long* sweep_counter, const int32_t* order, uint8_t* prev_it) {
     const int64_t ngroups = (ncols + 15) / 16;
     const int64_t wgs = std::max<int64_t>(1, std::min<int64_t>((ngroups + 3) / 4, 256 * (KQ > 44 ? 1 : 2)));
-    nnls_quarter_kernel<KQ><<<dim3((unsigned)wgs), dim3(256), 0, s>>>(G, B, X, col_nnz, k, ncols, L1, L2, sweep_counter);
+    nnls_quarter_kernel<KQ><<<dim3((unsigned)wgs), dim3(256), 0, s>>>(G, B, X, col_nnz, k, ncols, L1, L2, sweep_counter, order, prev_it);
     HIPCHK(hipGetLastError());
     return SGL_OK;
 }

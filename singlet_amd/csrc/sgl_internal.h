@@ -307,6 +307,9 @@ int k_nnls_lane(hipStream_t s, const double* Gpad, int KP, double* B, double* X,
                 int k, int64_t ncols, double L1, double L2, unsigned long long* sweep_counter, const NnlsScratch* scr,
                 bool pack_by_sweeps = false);
 int nnls_pack_alloc(NnlsScratch& sc, int64_t ncols);
+// ranks 129 - 256, shared Gram, all columns of the shard: four lanes per column, waves packed by the previous solve's sweep counts
+int k_nnls_quarter_packed(hipStream_t s, const double* G, const double* B, double* X, const int64_t* col_nnz, int k, int64_t ncols, double L1,
+                          double L2, unsigned long long* sweep_counter, const NnlsScratch* scr);
 // few columns against a shared Gram (k <= 64): four columns per wave, the Gram staged in LDS; B is read only
 int k_nnls_quad_shared(hipStream_t s, const double* G, const double* B, double* X, const int64_t* col_nnz, int k, int64_t ncols,
                        double L1, double L2, unsigned long long* sweep_counter);

@@ -729,7 +729,7 @@ static int fit_init_impl(sgl_ctx* c, int32_t k, const double* w_init, uint64_t s
     {
         const int64_t cap = std::max<int64_t>(c->A.ncol, c->A.nrow);
         if (k <= SGL_LANE_NNLS_MAX_K) SGLCHK(nnls_scratch_alloc(c->nnls_scr, cap, k));
-        if (k <= SGL_LANE_NNLS_MAX_K && c->A.ncol >= 65536) SGLCHK(nnls_pack_alloc(c->nnls_scr, c->A.ncol));   // sweep-count packing of the H-side solve (lane kernels; above k = 64 the generated two-lane solve)
+        if (k <= 256 && c->A.ncol >= 65536) SGLCHK(nnls_pack_alloc(c->nnls_scr, c->A.ncol));   // sweep-count packing of the H-side solve (lane kernels; above k = 64 the generated two-lane solve)
     }
     sgl_trace_setup("fit: factor buffers allocated");
     HIPCHK(hipMemsetAsync(c->W, 0, sizeof(double) * ((size_t)k * mpad + 2), c->stream));
@@ -837,6 +837,10 @@ int sgl_nnls_shared(sgl_ctx* c, const double* G, double* B, double* X, const int
         // the H side of a plain fit packs its waves by the sweep counts of the previous iteration (kernels_nnls.hip)
         return k_nnls_lane(c->stream, c->Gpad, KP, B, X, col_nnz, k, ncols, L1, L2, counter, &c->nnls_scr, h_side && ncols == c->A.ncol);
     }
+    // ranks 129 - 256, the H side of a plain fit: the four-lane solve with its waves packed by sweep counts
+    if (k > SGL_LANE_NNLS_MAX_K && k <= 256 && h_side && ncols == c->A.ncol && ncols >= 65536 && c->nnls_scr.prev_it != nullptr &&
+        !getenv("SGL_NNLS_NO_QUARTER"))
+        return k_nnls_quarter_packed(c->stream, G, B, X, col_nnz, k, ncols, L1, L2, counter, &c->nnls_scr);
     return k_nnls_percol(c->stream, G, 0, B, X, col_nnz, k, ncols, L1, L2, counter);
 }
 

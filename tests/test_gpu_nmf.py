@@ -597,12 +597,13 @@ def test_edge_arguments(sa, ora, ctx):
         sa.c_nmf(bad, None, 0.0, 1, False, 0.0, 0.0, 0.0, 0.0, 0, w0.T)
 
 
-@pytest.mark.parametrize("k", [24, 100])
+@pytest.mark.parametrize("k", [24, 100, 136])
 def test_nnls_packing_by_sweep_counts_is_bit_identical(sa, monkeypatch, k):
     """From the second iteration on the H-side solve takes its columns in descending order of the sweeps their previous
     solve needed (neighbours share a wave: less lock-step waste).  A column's arithmetic does not depend on its lane: the
     factors, tol trace and sweep totals are those of the unpacked solve, bit for bit (70 000 cells: above the packing
-    threshold; with and without the re-packing passes).  k = 100: the generated two-lane solve packs the same way."""
+    threshold; with and without the re-packing passes).  k = 100: the generated two-lane solve packs the same way; k = 136 (round 6):
+    the four-lanes-per-column solve of ranks 129 - 256 takes its 16-column waves in that order."""
     genes, cells = 1500, 70000
     runs = {}
     for repack in ("0", "32768"):
