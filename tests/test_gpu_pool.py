@@ -60,3 +60,37 @@ def test_pool_counts_as_free_memory_and_is_given_back_on_demand(sa):
     assert _cached(sa) >= held
     L.sgl_cache_release()
     assert _cached(sa) == 0
+
+
+def test_call_times_split_the_one_shot_call(sa):
+    """sgl_call_times_get: the wall-clock split of the calling thread's last one-shot call (what scripts/one_shot_rate.py reports
+    at configs 2 and 3): host -> device bytes = the dgCMatrix slots, the parts add up to the whole, and with SINGLET_HIP_CACHE=1 the
+    second call on the same host slots uploads nothing."""
+    import os
+    L = sa._lib.load()
+    genes, cells, k = 3000, 20000, 8
+    with sa.Context(0) as c:
+        c.synth(genes, cells, 20)
+        c.fit_init(k, None)
+        w0, _, _ = c.get_factors(h=False)
+        x, i, p = c.download(0)
+    A = sa.dgCMatrix(x, i, p.astype(np.int32), (genes, cells))
+    os.environ.pop("SINGLET_HIP_CACHE", None)
+    r = sa.c_nmf(A, None, 0.0, 5, False, 0.01, 0.01, 0.0, 0.0, 0, w0.T)
+    t = sa.call_times()
+    assert r["iter"] == 5 and t["cached"] == 0.0
+    assert t["h2d_bytes"] == 12.0 * A.nnz + 4.0 * (cells + 1)                       # x (8 B) + i (4 B) per non-zero + p; t(A) is built on the device
+    parts = t["h2d_s"] + t["validate_s"] + t["transpose_s"] + t["fit_init_s"] + t["iterate_s"] + t["d2h_s"]
+    assert 0.0 < parts <= t["total_s"] * 1.0001 and t["iterate_s"] > 0.0 and t["transpose_s"] > 0.0
+    os.environ["SINGLET_HIP_CACHE"] = "1"
+    try:
+        sa.c_nmf(A, None, 0.0, 2, False, 0.01, 0.01, 0.0, 0.0, 0, w0.T)
+        assert sa.call_times()["cached"] == 0.0 and sa.call_times()["h2d_bytes"] > 0    # this call uploaded and filled the cache
+        r2 = sa.c_nmf(A, None, 0.0, 5, False, 0.01, 0.01, 0.0, 0.0, 0, w0.T)
+        t2 = sa.call_times()
+        assert t2["cached"] == 1.0 and t2["h2d_bytes"] == 0.0 and t2["transpose_s"] == 0.0
+        for key in ("w", "d", "h"):
+            assert np.array_equal(r[key], r2[key]), key
+    finally:
+        os.environ.pop("SINGLET_HIP_CACHE", None)
+        L.sgl_cache_release()
