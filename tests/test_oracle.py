@@ -297,3 +297,31 @@ def test_live_reference_build_when_present(ora):
     for inv in (4, 20, 999):
         L.ref_draw_grid(9, inv, 123456, 50, 0, 700, buf.ctypes.data_as(C.POINTER(C.c_uint8)))
         assert np.array_equal(buf, ora.rng_mask(9, 123456, 50, 700, inv))
+
+
+def test_oracle_nnls_solves_the_problem_scipy_solves(ora):
+    """An independent check of WHAT the restated nnls (src/singlet.cpp:229-250) computes, by a different algorithm: for a positive
+    definite Gram a = F F^T and right-hand side b, coordinate descent on 1/2 x^T a x - b^T x over x >= 0 has the minimiser that
+    scipy's active-set NNLS finds for min |F^T x - y| with F y = b.  The reference's loop stops on a relative-change test
+    (tol / k <= 1e-8) or after 100 sweeps, so on a well-conditioned Gram the two agree to ~1e-7 of the largest entry (on positive, correlated factors only to ~1e-3), with the same support up to entries at that level, and the KKT
+    conditions hold at the oracle's solution.  Not a pin of the floating-point bits (nothing in this image can be: DESIGN.md
+    "Oracle status") -- a check that the restatement solves the right problem."""
+    from scipy.optimize import nnls as scipy_nnls
+    rng = np.random.default_rng(11)
+    for k, rows in ((6, 200), (20, 700), (50, 2000)):     # rows >> k: a well-conditioned Gram, so that the sweep cap and the loose stop do not bind
+        for _ in range(5):
+            F = rng.normal(size=(k, rows))     # k x rows, independent entries: a = F F^T is well conditioned (rows >> k)
+            a = F @ F.T
+            y = rng.normal(size=rows) + 0.5
+            b = F @ y
+            x, _, it = ora.nnls(a, b.copy(), np.zeros(k))
+            xs, _ = scipy_nnls(F.T, y, maxiter=50 * k)
+            assert 0 < it <= 100
+            scale = max(np.abs(xs).max(), 1e-12)
+            assert np.abs(x - xs).max() <= 1e-6 * scale, (k, np.abs(x - xs).max() / scale)
+            assert np.array_equal(x > 1e-5 * scale, xs > 1e-5 * scale)
+            # KKT at the oracle's x: gradient g = a x - b is ~0 on the support and >= 0 off it
+            g = a @ x - b
+            on = x > 1e-6 * scale
+            gs = np.abs(b).max()
+            assert np.abs(g[on]).max(initial=0.0) <= 1e-6 * gs and g[~on].min(initial=0.0) >= -1e-6 * gs
